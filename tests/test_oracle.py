@@ -1,0 +1,244 @@
+"""CPU tests: pin the oracle (oracle/frontend_ref.py) against the committed
+golden vectors (torch.stft outputs, tests/golden/make_golden.py) and against the
+known-answer vectors held by the reference's own tests (tests/golden/ref_kats.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import frontend_ref as R
+
+CASES = ["c1_mono_2s", "refdefault_stereo", "c5_stereo_short", "ragged_n256"]
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def kats(golden_dir):
+    with open(os.path.join(golden_dir, "ref_kats.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_stft_matches_torch_golden(golden_dir, name):
+    g = load(golden_dir, name)
+    n_fft, hop = int(g["n_fft"]), int(g["hop"])
+    spec = R.stft(g["wav"], n_fft, hop)  # [C,F,T]
+    assert spec.shape[-1] == int(g["n_frames"]) == 1 + g["wav"].shape[-1] // hop
+    assert spec.shape[-2] == n_fft // 2 + 1
+    fr = g["spec_frames"]
+    scale = np.abs(g["spec_re"] + 1j * g["spec_im"]).max()
+    assert np.abs(spec.real[:, :, fr] - g["spec_re"]).max() <= 2e-6 * scale
+    assert np.abs(spec.imag[:, :, fr] - g["spec_im"]).max() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fp32_stft_close_to_fp64_definition(golden_dir, name):
+    """Sizes the fp32 tolerance: golden (torch fp32) vs the fp64 definition."""
+    g = load(golden_dir, name)
+    spec64 = R.stft(g["wav"], int(g["n_fft"]), int(g["hop"]), dtype=np.float64)
+    fr = g["spec_frames"]
+    gold = g["spec_re"] + 1j * g["spec_im"]
+    scale = np.abs(gold).max()
+    assert np.abs(spec64[:, :, fr] - gold).max() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_chain_matches_golden(golden_dir, name):
+    g = load(golden_dir, name)
+    n_fft, hop, n_mel, sr = int(g["n_fft"]), int(g["hop"]), int(g["n_mel"]), float(g["sample_rate"])
+    mel = R.wav_to_mel(g["wav"][None], n_fft, hop, n_mel, sr)[0]  # [M,T,C]
+    assert mel.shape == g["mel"].shape
+    rel = np.abs(mel - g["mel"]) / np.maximum(np.abs(g["mel"]), 1e-3)
+    assert rel.max() <= 1e-5
+    logmel = R.wav_to_logmel(g["wav"][None], n_fft, hop, n_mel, sr)[0]
+    # compare in the normalised domain (log amplifies near the per-sample minimum)
+    assert np.abs(np.exp(logmel) - np.exp(g["logmel"])).max() <= 2e-6
+    assert logmel.min() == pytest.approx(np.log(1e-8), abs=1e-4)
+    assert logmel.max() == pytest.approx(0.0, abs=1e-6)
+
+
+def test_ref_layout_is_re_block_then_im_block():
+    spec = (np.arange(2 * 3 * 4).reshape(2, 3, 4) + 1j * (100 + np.arange(24).reshape(2, 3, 4))).astype(np.complex64)
+    out = R.to_ref_layout(spec)  # [F,T,2C]
+    assert out.shape == (3, 4, 4)
+    assert np.array_equal(out[..., 0], spec[0].real) and np.array_equal(out[..., 1], spec[1].real)
+    assert np.array_equal(out[..., 2], spec[0].imag) and np.array_equal(out[..., 3], spec[1].imag)
+
+
+def test_frame_indexing_impulse():
+    """Frame/bin indexing: a unit impulse at sample p shows up in frame t with
+    window weight hann[p - t*hop + n_fft/2] and linear phase."""
+    n_fft, hop, length, p = 64, 16, 400, 137
+    x = np.zeros((1, length), np.float32)
+    x[0, p] = 1.0
+    spec = R.stft(x, n_fft, hop, dtype=np.float64)[0]  # [F,T]
+    w = R.hann_periodic(n_fft, np.float64)
+    for t in range(spec.shape[1]):
+        n = p - (t * hop - n_fft // 2)
+        expect = np.zeros(n_fft // 2 + 1, complex)
+        if 0 <= n < n_fft:
+            expect = w[n] * np.exp(-2j * np.pi * np.arange(n_fft // 2 + 1) * n / n_fft)
+        assert np.allclose(spec[:, t], expect, atol=1e-12)
+
+
+def test_reflect_padding_edges():
+    n_fft, hop = 16, 4
+    x = np.arange(40, dtype=np.float64)[None]
+    fr = R.frame_signal(x, n_fft, hop)[0]
+    assert np.array_equal(fr[0, :9], np.arange(8, -1, -1))  # 8..1 reflected then 0
+    assert fr.shape[0] == 1 + 40 // hop
+    assert fr[-1, -1] == 2 * 39 - (10 * hop - 8 + 15)
+
+
+# ---- KATs from the reference's own tests -----------------------------------
+def test_kat_log_magphase(kats):
+    k = kats["log_magphase"]
+    out = R.log_magphase(np.array(k["specs"], np.float64), n_chan=k["n_chan"])
+    assert np.allclose(out, np.array(k["expected"]), atol=1e-6)
+
+
+def test_kat_phasors(kats):
+    k = kats["phasors"]
+    c = np.array(k["complex"], np.float32)
+    mp = np.array(k["magphase"], np.float32)
+    assert np.allclose(R.complex_to_magphase(c), mp, atol=1e-6)
+    assert np.allclose(R.magphase_to_complex(mp), c, atol=1e-6)
+
+
+@pytest.mark.parametrize("key", ["mask_axis0", "mask_axis1"])
+def test_kat_mask_apply(kats, key):
+    k = kats[key]
+    out = R.mask_apply(np.array(k["org"]), k["axis"], k["offsets"], k["sizes"])
+    assert out.dtype == np.array(k["org"]).dtype
+    assert np.array_equal(out, np.array(k["expected"]))
+
+
+def test_kat_random_shift(kats):
+    k = kats["random_shift"]
+    out = R.random_shift_apply(np.array(k["org"]), k["axis"], k["width"], k["offset"])
+    assert np.array_equal(out, np.array(k["expected"]))
+
+
+def test_kat_mel_shapes(kats):
+    k = kats["magphase_to_mel_shapes"]
+    f = R.magphase_to_mel(k["n_mels"])
+    for case in k["cases"]:
+        x = np.random.default_rng(0).standard_normal(case["in"]).astype(np.float32)
+        assert list(f(x).shape) == case["out"]
+    with pytest.raises(ValueError):
+        f(np.zeros((257, 4), np.float32))
+
+
+def test_minmax_norm_magphase_property():
+    rng = np.random.default_rng(5)
+    mag = rng.standard_normal((5, 10, 2))
+    ph = (2 * rng.random((5, 10, 2)) - 1) * np.pi
+    out = R.minmax_norm_magphase(np.concatenate([mag, ph], -1))
+    assert np.allclose(out.min(axis=(1, 2)), 0, atol=1e-6)
+    assert np.allclose(out.max(axis=(1, 2)), 1, atol=1e-6)
+
+
+def test_phase_vocoder_identity_and_shape(kats):
+    k = kats["phase_vocoder_shapes"]
+    spec = np.random.default_rng(1).standard_normal((k["n_freq"], k["time"], k["chan2"])).astype(np.float32)
+    assert R.phase_vocoder(spec, 1.0) is spec
+    for rate in k["rates"]:
+        out = R.phase_vocoder(spec, rate)
+        assert out.shape == (k["n_freq"], int(np.ceil(k["time"] / rate)), k["chan2"])
+
+
+# ---- mel matrix: structure + fp64 cross-check (TF parity itself is unpinned) -
+@pytest.mark.parametrize("m,f,sr,nnz", [(80, 257, 16000, 231), (64, 513, 16000, 461), (128, 1025, 22050, 676)])
+def test_mel_matrix_structure(golden_dir, m, f, sr, nnz):
+    w = R.linear_to_mel_weight_matrix(m, f, sr)
+    assert w.shape == (f, m) and w.dtype == np.float32
+    assert np.all(w[0] == 0) and w.min() >= 0 and w.max() <= 1
+    assert int((w > 0).sum()) == nnz
+    assert int((w > 0).sum(axis=1).max()) <= 2  # triangular: <=2 bands per bin
+    w64 = R.linear_to_mel_weight_matrix(m, f, sr, dtype=np.float64)
+    assert np.abs(w - w64).max() <= 2e-5  # fp32 recipe vs the fp64 formula
+    g = np.load(os.path.join(golden_dir, "mel_matrices.npz"))
+    dense = np.zeros((f, m), np.float32)
+    dense[g[f"w_{m}_{f}_{sr}_rows"], g[f"w_{m}_{f}_{sr}_cols"]] = g[f"w_{m}_{f}_{sr}_vals"]
+    assert np.array_equal(dense, w)
+
+
+def test_mel_matrix_hand_case():
+    """One-hot spectrum picks out a row of W; adjacent triangles sum to 1 between centres."""
+    w = R.linear_to_mel_weight_matrix(64, 513, 16000, dtype=np.float64)
+    mel_of = lambda hz: 1127.0 * np.log1p(hz / 700.0)
+    edges = np.linspace(mel_of(125.0), mel_of(3800.0), 66)
+    lin = np.linspace(0, 8000, 513)
+    inside = (mel_of(lin) > edges[1]) & (mel_of(lin) < edges[-2])
+    assert np.allclose(w[inside].sum(axis=1), 1.0, atol=1e-12)
+    x = np.zeros((513, 3, 2), np.float32)
+    x[100, 1, 0] = 2.0
+    out = R.magphase_to_mel(64, 513, 16000)(x)
+    assert np.allclose(out[:, 1, 0], 2.0 * R.linear_to_mel_weight_matrix(64, 513, 16000)[100])
+    assert np.all(out[:, 0] == 0) and np.all(out[:, 2] == 0)
+
+
+def test_mel_validation():
+    with pytest.raises(ValueError):
+        R.linear_to_mel_weight_matrix(0, 257, 16000)
+    with pytest.raises(ValueError):
+        R.linear_to_mel_weight_matrix(10, 257, 16000, lower_edge_hertz=4000, upper_edge_hertz=3800)
+    with pytest.raises(ValueError):
+        R.linear_to_mel_weight_matrix(10, 257, 16000, upper_edge_hertz=9000)
+
+
+def test_minmax_axes_and_safe_div():
+    x = np.random.default_rng(2).random((3, 4, 5, 2)).astype(np.float32)
+    out = R.minmax(x)
+    assert np.allclose(out.reshape(3, -1).min(1), 0) and np.allclose(out.reshape(3, -1).max(1), 1)
+    const = np.full((2, 3, 4, 1), 7.0, np.float32)
+    assert np.all(R.minmax(const) == 0)  # (x-min)/max(0,1e-8) = 0
+    assert np.allclose(R.log_on_mel(R.minmax(const)), np.log(np.float32(1e-8)))
+    # unbatched [M,T,C] reduces per mel row (metrics.py:53 quirk)
+    row = R.minmax(x[0])
+    assert np.allclose(row.reshape(4, -1).min(1), 0) and np.allclose(row.reshape(4, -1).max(1), 1)
+
+
+def test_mask_draw_distribution_bounds():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        off, size = R.mask_draw(rng, 50, 24, 6)
+        assert np.all(size < 24) and np.all(off >= 0) and np.all(off + size < 50 + (size == 0))
+    with pytest.raises(ValueError):
+        for _ in range(200):
+            R.mask_draw(rng, 4, 16, 1)
+
+
+def test_bands_in_chain_equal_masking_complex_spec():
+    rng = np.random.default_rng(3)
+    wav = R.normalize(rng.standard_normal((2, 1, 4000)).astype(np.float32))
+    tb = np.array([[[2, 3], [10, 0]], [[0, 1], [5, 5]]], np.int32)
+    fb = np.array([[[4, 6]], [[100, 15]]], np.int32)
+    mel = R.wav_to_mel(wav, 256, 128, 40, t_bands=tb, f_bands=fb)
+    for b in range(2):
+        spec = R.to_ref_layout(R.stft(wav[b], 256, 128))  # [F,T,2]
+        spec = R.augment_apply(spec, tb[b, :, 0], tb[b, :, 1], fb[b, :, 0], fb[b, :, 1])
+        ref = R.magphase_to_mel(40, 129, 16000)(R.complex_to_magphase(spec))
+        assert np.allclose(ref, mel[b], rtol=1e-5, atol=1e-6)
+
+
+def test_label_downsample_and_helpers():
+    y = np.zeros((2, 70, 3), np.float32)
+    y[0, :20, 0] = 1
+    y[1, 40:, 2] = 1
+    _, d = R.label_downsample(32)(None, y)
+    assert d.shape == (2, 3, 3)
+    assert d[0, 0, 0] == 1 and d[0, 1, 0] == 0 and d[1, 2, 2] == 1 and d[1, 1, 2] == 1
+    x = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    sm = R.stereo_mono(x)
+    assert sm.shape == (2, 3, 6) and np.array_equal(sm[..., 2], x[..., 0] + x[..., 1])
+    assert np.array_equal(sm[..., 5], x[..., 2] + x[..., 3])
+    assert R.mono_chan(x) is x
+    mc, _ = R.mono_chan(x[..., :2], 1)
+    assert np.array_equal(mc[..., 0], x[..., 0] + x[..., 1])
+    f = R.stft_filter(2)(x.reshape(4, 3, 2))
+    assert np.all(f[1:3] == 0) and np.all(f[0] == x.reshape(4, 3, 2)[0]) and np.all(f[3] == x.reshape(4, 3, 2)[3])
