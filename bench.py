@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X feature frontend.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the fused hot path (STFT -> magnitude -> mel -> per-sample
+min-max -> log, data resident in HBM) over BASELINE.json configs[1]: a batch of
+32 x 10 s mono 16 kHz clips, n_fft 1024, hop 256, 64 mel bands.  With N > 1 the
+driver launches one process per GPU (torch.distributed.run); every rank runs the
+same batch shape on its own clips (independent clips: no data-path collective,
+weak scaling) and the job throughput is the sum.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SR, N_FFT, HOP, N_MEL = 16000, 1024, 256, 64
+BATCH, SECONDS = 32, 10
+ALGO_BYTES_PER_AUDIO_S = 4 * SR + 4 * N_MEL * SR // HOP  # fp32 wave in + fp32 mel out = 80,000
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(wav_cpu: np.ndarray):
+    """Reference CPU path timed on this host (rank 0, N=1 only).  A = NumPy
+    restatement (oracle, single process); B = torch.stft + torch CPU ops with all
+    host threads (the engine the reference executes).  Reported value = the faster."""
+    from oracle import frontend_ref as R
+    from oracle.torch_cpu_ref import wav_to_logmel_cpu
+    cores = os.cpu_count() or 1
+    audio_s = wav_cpu.shape[0] * wav_cpu.shape[2] / SR
+    # A: NumPy, whole batch, a few repetitions (~10 s budget)
+    t0 = time.perf_counter()
+    R.wav_to_logmel(wav_cpu[:4], N_FFT, HOP, N_MEL, SR)
+    est = (time.perf_counter() - t0) * wav_cpu.shape[0] / 4
+    reps_a = max(1, min(5, int(8.0 / max(est, 1e-3))))
+    ta = []
+    for _ in range(reps_a):
+        t0 = time.perf_counter()
+        R.wav_to_logmel(wav_cpu, N_FFT, HOP, N_MEL, SR)
+        ta.append(time.perf_counter() - t0)
+    a_rate = audio_s / float(np.median(ta))
+    # B: torch CPU, all threads
+    torch.set_num_threads(cores)
+    w = torch.from_numpy(R.linear_to_mel_weight_matrix(N_MEL, N_FFT // 2 + 1, SR))
+    x = torch.from_numpy(wav_cpu)
+    for _ in range(2):
+        wav_to_logmel_cpu(x, w, N_FFT, HOP)
+    tb = []
+    t_end = time.perf_counter() + 8.0
+    while len(tb) < 5 or (time.perf_counter() < t_end and len(tb) < 200):
+        t0 = time.perf_counter()
+        wav_to_logmel_cpu(x, w, N_FFT, HOP)
+        tb.append(time.perf_counter() - t0)
+    b_rate = audio_s / float(np.median(tb))
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": round(max(a_rate, b_rate), 1), "unit": "audio-s/s", "cores": cores if b_rate >= a_rate else 1,
+        "kind": "port",
+        "sample": (f"same c2 batch (32 x 10 s); B=torch.stft+torch CPU ops, {cores} threads, median of {len(tb)} "
+                   f"runs = {b_rate:.0f}; A=NumPy oracle, 1 thread, median of {reps_a} = {a_rate:.0f}; CPU: {model}"),
+        "numpy_1thread": round(a_rate, 1), "torch_allthreads": round(b_rate, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket the dominant kernel with HIP events (roofline.achieved = null)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1 here)", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    from challenge_amd.frontend import FrontendPlan, normalize
+
+    length = SECONDS * SR
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    wav = torch.randn(BATCH, 1, length, generator=gen, device=dev, dtype=torch.float32)
+    wav = normalize(wav)  # reference normalisation x / (10 rms), data_utils.py:32-34
+    plan = FrontendPlan(N_FFT, HOP, N_MEL, SR, 1, BATCH, length, dev)
+    out = torch.empty((BATCH, N_MEL, plan.num_frames(length), 1), device=dev)
+
+    def step():
+        plan.wav_to_logmel(wav, minmax=True, log=True, out=out)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    plan.timing_enable(not args.no_kernel_events)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    n_ev, kernel_ms = plan.timing_read()
+    plan.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    audio_s_per_step = BATCH * SECONDS
+    value = world * audio_s_per_step * args.steps / elapsed
+    result = {
+        "metric": "audio-seconds/sec (STFT+mel+fwd) @16 kHz",
+        "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "c2: batch 32 x 10 s mono 16 kHz per GPU, n_fft 1024 hop 256 n_mel 64; "
+                               "fused STFT+magnitude+mel+min-max+log (frontend only, no collective)",
+                   "global_batch": world * BATCH, "parallelism": f"dp{world}"},
+    }
+    if rank == 0:
+        algo_bytes = ALGO_BYTES_PER_AUDIO_S * audio_s_per_step  # per launch
+        achieved = (algo_bytes / (kernel_ms * 1e-3) / 1e9) if n_ev and kernel_ms > 0 else None
+        result["roofline"] = {
+            "bound": "hbm", "kernel": "k_wav_to_mel<10>",
+            "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "kernel_ms": round(kernel_ms, 5) if n_ev else None, "launches_timed": n_ev,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(wav.cpu().numpy())
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""ctypes binding of the C ABI in include/iris_frontend.h.
+
+The library is built in-tree by ``__graft_entry__.build()`` (or ``make -C
+challenge_amd/csrc``).  Loading fails loudly: there is no pure-Python or CPU
+fallback for the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libiris_frontend.so")
+
+IRIS_F_MINMAX, IRIS_F_LOG, IRIS_F_NORMALIZE = 1, 2, 4
+
+# every symbol include/iris_frontend.h declares, with (restype, argtypes)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_fp = C.POINTER(C.c_float)
+SIGNATURES = {
+    "iris_abi_version": (_i, []),
+    "iris_last_error": (C.c_char_p, []),
+    "iris_mel_weight_matrix": (_i, [_i, _i, _f, _f, _f, _fp]),
+    "iris_plan_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _fp]),
+    "iris_plan_destroy": (_i, [_vp]),
+    "iris_plan_get_mel": (_i, [_vp, _fp]),
+    "iris_plan_num_frames": (_i, [_vp, _i]),
+    "iris_normalize_workspace": (_sz, [_i, _sz]),
+    "iris_normalize": (_i, [_vp, _vp, _i, _sz, _vp, _sz, _vp]),
+    "iris_stft": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "iris_complex_to_magphase": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "iris_magphase_to_complex": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "iris_magmel": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "iris_minmax_log_workspace": (_sz, [_i, _sz]),
+    "iris_minmax_log": (_i, [_vp, _i, _sz, _i, _i, _f, _f, _vp, _sz, _vp]),
+    "iris_wav_to_logmel": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "iris_mask_apply": (_i, [_vp, _sz, _sz, _sz, _i, _vp, _i, _sz, _vp]),
+    "iris_timing_enable": (_i, [_vp, _i]),
+    "iris_timing_read": (_i, [_vp, C.POINTER(_i), _fp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class IrisError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+
+def lib() -> C.CDLL:
+    """Load libiris_frontend.so (once).  Raises ImportError if it is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise ImportError(
+                        f"{LIB_PATH} is missing: the HIP frontend is not built "
+                        "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                        "`make -C challenge_amd/csrc`).  There is no CPU fallback.")
+                handle = C.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)  # AttributeError if the symbol is absent
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status == 0:
+        return
+    msg = lib().iris_last_error().decode("utf-8", "replace")
+    if status in (-1, -2, -3):  # bad argument / unsupported / capacity
+        raise ValueError(f"{what}: {msg} (status {status})")
+    raise IrisError(f"{what}: {msg} (status {status})")

@@ -1,0 +1,319 @@
+"""Torch-facing wrapper of the HIP frontend (C ABI: include/iris_frontend.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every numeric op on
+the hot path is a hand-written HIP kernel in csrc/iris_frontend.hip.  Tensors
+must be float32, contiguous and on a ROCm device -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+EPSILON = 1e-8
+
+
+def _require_device_f32(x: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(x).__name__}")
+    if not x.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {x.device}: the feature frontend runs only as HIP kernels on a "
+            "ROCm device (there is no CPU fallback); move the tensor to 'cuda'")
+    if x.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {x.dtype}")
+    return x.contiguous()
+
+
+def _stream_ptr(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _bands_arg(bands, batch: int, device: torch.device, name: str):
+    """bands: None or int tensor/array [B, n, 2] of (offset, size)."""
+    if bands is None:
+        return None, C.c_void_p(0), 0
+    t = torch.as_tensor(bands)
+    if t.dim() != 3 or t.shape[0] != batch or t.shape[2] != 2:
+        raise ValueError(f"{name} must have shape [batch={batch}, n, 2], got {tuple(t.shape)}")
+    t = t.to(device=device, dtype=torch.int32).contiguous()
+    if t.shape[1] == 0:
+        return None, C.c_void_p(0), 0
+    return t, C.c_void_p(t.data_ptr()), int(t.shape[1])
+
+
+def mel_weight_matrix(num_mel_bins: int = 20, num_spectrogram_bins: int = 129,
+                      sample_rate: float = 8000, lower_edge_hertz: float = 125.0,
+                      upper_edge_hertz: float = 3800.0) -> np.ndarray:
+    """W[F, M] as the reference's closure builds it (transforms.py:55-56), via
+    the library's host routine (fp32 recipe).  Raises ValueError on bad edges."""
+    out = np.empty((num_spectrogram_bins, num_mel_bins), np.float32)
+    rc = N.lib().iris_mel_weight_matrix(int(num_mel_bins), int(num_spectrogram_bins),
+                                        float(sample_rate), float(lower_edge_hertz),
+                                        float(upper_edge_hertz),
+                                        out.ctypes.data_as(C.POINTER(C.c_float)))
+    N.check(rc, "iris_mel_weight_matrix")
+    return out
+
+
+class FrontendPlan:
+    """State of `Spectrogram(n_fft, power=None)` (data_utils.py:17) plus the
+    `magphase_to_mel(...)` closure (transforms.py:51-56) on one device."""
+
+    def __init__(self, n_fft: int = 512, hop: Optional[int] = None, n_mel: int = 80,
+                 sample_rate: float = 16000, channels: int = 1, max_batch: int = 64,
+                 max_len: int = 160000, device=None, lower_edge_hertz: float = 125.0,
+                 upper_edge_hertz: float = 3800.0, mel_matrix: Optional[np.ndarray] = None):
+        self._handle = None
+        lib = N.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("FrontendPlan needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback for the feature frontend")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"FrontendPlan device must be a ROCm device, got {self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n_fft, self.hop = int(n_fft), int(n_fft // 2 if hop is None else hop)
+        self.n_mel, self.n_bins = int(n_mel), int(n_fft) // 2 + 1
+        self.sample_rate, self.channels = float(sample_rate), int(channels)
+        self.max_batch, self.max_len = int(max_batch), int(max_len)
+        mel_ptr = None
+        if mel_matrix is not None:
+            mel_matrix = np.ascontiguousarray(mel_matrix, np.float32)
+            if mel_matrix.shape != (self.n_bins, self.n_mel):
+                raise ValueError(f"mel_matrix must be [{self.n_bins}, {self.n_mel}]")
+            mel_ptr = mel_matrix.ctypes.data_as(C.POINTER(C.c_float))
+        handle = C.c_void_p()
+        rc = lib.iris_plan_create(C.byref(handle), self.device.index, self.n_fft, self.hop,
+                                  self.n_mel, self.n_bins, self.sample_rate,
+                                  float(lower_edge_hertz), float(upper_edge_hertz), self.channels,
+                                  self.max_batch, self.max_len, mel_ptr)
+        N.check(rc, "iris_plan_create")
+        self._handle = handle
+        self._lock = threading.Lock()
+
+    def close(self) -> None:
+        if self._handle is not None:
+            N.lib().iris_plan_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- introspection ---------------------------------------------------
+    def num_frames(self, length: int) -> int:
+        return 1 + int(length) // self.hop
+
+    @property
+    def mel_matrix(self) -> np.ndarray:
+        out = np.empty((self.n_bins, self.n_mel), np.float32)
+        N.check(N.lib().iris_plan_get_mel(self._handle, out.ctypes.data_as(C.POINTER(C.c_float))),
+                "iris_plan_get_mel")
+        return out
+
+    def _check_wav(self, wav: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
+        wav = _require_device_f32(wav, "wav")
+        if wav.device != self.device:
+            raise RuntimeError(f"wav is on {wav.device}, plan is on {self.device}")
+        if wav.dim() != 3 or wav.shape[1] != self.channels:
+            raise ValueError(f"wav must be [B, C={self.channels}, L], got {tuple(wav.shape)}")
+        return wav, int(wav.shape[0]), int(wav.shape[2])
+
+    # ---- ops ---------------------------------------------------------------
+    def stft(self, wav: torch.Tensor) -> torch.Tensor:
+        """wav [B,C,L] -> spec [B,F,T,2C] (load_wav, data_utils.py:17-27)."""
+        wav, b, length = self._check_wav(wav)
+        t = self.num_frames(length)
+        spec = torch.empty((b, self.n_bins, t, 2 * self.channels), dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            rc = N.lib().iris_stft(self._handle, wav.data_ptr(), spec.data_ptr(), b, length,
+                                   _stream_ptr(self.device))
+        N.check(rc, "iris_stft")
+        return spec
+
+    def magmel(self, spec: torch.Tensor, is_magphase: bool = False, t_bands=None, f_bands=None) -> torch.Tensor:
+        """spec [B,F,T,2C] -> mel [B,M,T,C] (complex_to_magphase + magphase_to_mel)."""
+        spec = _require_device_f32(spec, "spec")
+        if spec.dim() != 4 or spec.shape[1] != self.n_bins or spec.shape[3] != 2 * self.channels:
+            raise ValueError(f"spec must be [B, {self.n_bins}, T, {2 * self.channels}], got {tuple(spec.shape)}")
+        b, t = int(spec.shape[0]), int(spec.shape[2])
+        mel = torch.empty((b, self.n_mel, t, self.channels), dtype=torch.float32, device=spec.device)
+        tb, tbp, ntb = _bands_arg(t_bands, b, spec.device, "t_bands")
+        fb, fbp, nfb = _bands_arg(f_bands, b, spec.device, "f_bands")
+        if b == 0 or t == 0:
+            return mel
+        with self._lock, torch.cuda.device(self.device):
+            rc = N.lib().iris_magmel(self._handle, spec.data_ptr(), mel.data_ptr(), b, t,
+                                     1 if is_magphase else 0, tbp, ntb, fbp, nfb, _stream_ptr(self.device))
+        N.check(rc, "iris_magmel")
+        return mel
+
+    def wav_to_logmel(self, wav: torch.Tensor, minmax: bool = True, log: bool = True,
+                      normalize: bool = False, t_bands=None, f_bands=None,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The fused hot path: wav [B,C,L] -> log-mel [B,M,T,C]."""
+        wav, b, length = self._check_wav(wav)
+        t = self.num_frames(length)
+        if out is None:
+            out = torch.empty((b, self.n_mel, t, self.channels), dtype=torch.float32, device=self.device)
+        else:
+            out = _require_device_f32(out, "out")
+            if tuple(out.shape) != (b, self.n_mel, t, self.channels):
+                raise ValueError(f"out must be {(b, self.n_mel, t, self.channels)}, got {tuple(out.shape)}")
+        tb, tbp, ntb = _bands_arg(t_bands, b, self.device, "t_bands")
+        fb, fbp, nfb = _bands_arg(f_bands, b, self.device, "f_bands")
+        flags = (N.IRIS_F_MINMAX if minmax else 0) | (N.IRIS_F_LOG if log else 0) | \
+            (N.IRIS_F_NORMALIZE if normalize else 0)
+        with self._lock, torch.cuda.device(self.device):
+            rc = N.lib().iris_wav_to_logmel(self._handle, wav.data_ptr(), out.data_ptr(), b, length, flags,
+                                            tbp, ntb, fbp, nfb, _stream_ptr(self.device))
+        N.check(rc, "iris_wav_to_logmel")
+        return out
+
+    # ---- bench hooks ---------------------------------------------------------
+    def timing_enable(self, enable: bool = True) -> None:
+        N.check(N.lib().iris_timing_enable(self._handle, 1 if enable else 0), "iris_timing_enable")
+
+    def timing_read(self) -> Tuple[int, float]:
+        n, ms = C.c_int(0), C.c_float(0)
+        N.check(N.lib().iris_timing_read(self._handle, C.byref(n), C.byref(ms)), "iris_timing_read")
+        return n.value, ms.value
+
+
+# ---------------------------------------------------------------------------
+# plan-free ops (run on the tensor's device / current stream)
+# ---------------------------------------------------------------------------
+def normalize(wav: torch.Tensor) -> torch.Tensor:
+    """wav / (10 rms) with the rms over the whole tensor for [C,L] input
+    (data_utils.py:32-34) or per leading item for [B,C,L]."""
+    wav = _require_device_f32(wav, "wav")
+    if wav.dim() not in (2, 3):
+        raise ValueError("wav must be [C, L] or [B, C, L]")
+    n_rows = 1 if wav.dim() == 2 else int(wav.shape[0])
+    row_len = wav.numel() // max(n_rows, 1)
+    out = torch.empty_like(wav)
+    lib = N.lib()
+    ws = torch.empty(max(int(lib.iris_normalize_workspace(n_rows, row_len)), 1), dtype=torch.float32,
+                     device=wav.device)
+    with torch.cuda.device(wav.device):
+        rc = lib.iris_normalize(wav.data_ptr(), out.data_ptr(), n_rows, row_len, ws.data_ptr(), ws.numel(),
+                                _stream_ptr(wav.device))
+    N.check(rc, "iris_normalize")
+    return out
+
+
+def minmax_log(x: torch.Tensor, do_minmax: bool = True, do_log: bool = True, eps_div: float = EPSILON,
+               eps_log: float = EPSILON) -> torch.Tensor:
+    """Out-of-place min-max over every axis except 0, then ln(x + eps)."""
+    x = _require_device_f32(x, "x").clone()
+    if x.dim() < 1 or x.numel() == 0:
+        return x
+    n_rows = int(x.shape[0])
+    row_len = x.numel() // n_rows
+    lib = N.lib()
+    ws = torch.empty(max(int(lib.iris_minmax_log_workspace(n_rows, row_len)), 1), dtype=torch.float32,
+                     device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.iris_minmax_log(x.data_ptr(), n_rows, row_len, 1 if do_minmax else 0, 1 if do_log else 0,
+                                 float(eps_div), float(eps_log), ws.data_ptr(), ws.numel(),
+                                 _stream_ptr(x.device))
+    N.check(rc, "iris_minmax_log")
+    return x
+
+
+def complex_to_magphase(x: torch.Tensor) -> torch.Tensor:
+    x = _require_device_f32(x, "complex_tensor")
+    c2 = int(x.shape[-1])
+    if c2 % 2:
+        raise ValueError("last axis must hold [re block, im block] (even length)")
+    out = torch.empty_like(x)
+    if x.numel():
+        with torch.cuda.device(x.device):
+            rc = N.lib().iris_complex_to_magphase(x.data_ptr(), out.data_ptr(), x.numel() // c2, c2 // 2,
+                                                  _stream_ptr(x.device))
+        N.check(rc, "iris_complex_to_magphase")
+    return out
+
+
+def magphase_to_complex(x: torch.Tensor) -> torch.Tensor:
+    x = _require_device_f32(x, "magphase")
+    c2 = int(x.shape[-1])
+    if c2 % 2:
+        raise ValueError("last axis must hold [mag block, phase block] (even length)")
+    out = torch.empty_like(x)
+    if x.numel():
+        with torch.cuda.device(x.device):
+            rc = N.lib().iris_magphase_to_complex(x.data_ptr(), out.data_ptr(), x.numel() // c2, c2 // 2,
+                                                  _stream_ptr(x.device))
+        N.check(rc, "iris_magphase_to_complex")
+    return out
+
+
+def mask_apply(x: torch.Tensor, axis: int, bands, outer_per_group: Optional[int] = None) -> torch.Tensor:
+    """Zero the bands [offset, offset+size) along `axis` (out of place).
+
+    bands: int [n, 2] (one group for the whole tensor) or [G, n, 2] with
+    `outer_per_group` leading-index rows per group."""
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise RuntimeError("mask_apply runs as a HIP kernel: x must be a tensor on a ROCm device")
+    if x.element_size() not in (4, 8):
+        raise TypeError(f"mask_apply supports 4- and 8-byte dtypes, got {x.dtype}")
+    x = x.contiguous().clone()
+    axis = axis % x.dim()
+    n_outer = int(np.prod(x.shape[:axis], dtype=np.int64)) if axis > 0 else 1
+    n_inner = int(np.prod(x.shape[axis + 1:], dtype=np.int64)) if axis + 1 < x.dim() else 1
+    b = torch.as_tensor(bands).to(device=x.device, dtype=torch.int32)
+    if b.dim() == 2:
+        b = b[None]
+    if b.dim() != 3 or b.shape[-1] != 2:
+        raise ValueError("bands must be [n, 2] or [G, n, 2]")
+    b = b.contiguous()
+    groups = int(b.shape[0])
+    if outer_per_group is None:
+        outer_per_group = max(n_outer // groups, 1) if groups > 1 else max(n_outer, 1)
+    if groups * outer_per_group < n_outer:
+        raise ValueError("bands groups do not cover the outer extent")
+    if x.numel() and b.shape[1]:
+        with torch.cuda.device(x.device):
+            rc = N.lib().iris_mask_apply(x.data_ptr(), n_outer, int(x.shape[axis]), n_inner, x.element_size(),
+                                         b.data_ptr(), int(b.shape[1]), int(outer_per_group),
+                                         _stream_ptr(x.device))
+        N.check(rc, "iris_mask_apply")
+    return x
+
+
+# ---------------------------------------------------------------------------
+# plan cache for the closure-style API of transforms.py
+# ---------------------------------------------------------------------------
+_plans = {}
+_plans_lock = threading.Lock()
+
+
+def get_plan(device, n_fft: int, hop: Optional[int], n_mel: int, sample_rate: float, channels: int,
+             batch: int, length: int, **mel_kw) -> FrontendPlan:
+    """Cached plan with capacity >= (batch, length); grown geometrically."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    hop = n_fft // 2 if hop is None else hop
+    key = (device.index, n_fft, hop, n_mel, float(sample_rate), channels, tuple(sorted(mel_kw.items())))
+    with _plans_lock:
+        plan = _plans.get(key)
+        if plan is None or plan.max_batch < batch or plan.max_len < length:
+            cap_b = max(batch, plan.max_batch if plan else 0)
+            cap_l = max(length, plan.max_len if plan else 0, n_fft)
+            if plan is not None:  # grow with headroom
+                cap_b, cap_l = max(cap_b, 2 * plan.max_batch), max(cap_l, plan.max_len)
+            plan = FrontendPlan(n_fft, hop, n_mel, sample_rate, channels, cap_b, cap_l, device, **mel_kw)
+            _plans[key] = plan
+        return plan

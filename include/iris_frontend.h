@@ -1,0 +1,189 @@
+/*
+ * iris_frontend.h -- C ABI of the MI355X (gfx950) audio feature frontend.
+ *
+ * Drop-in boundary for the reference's feature hot path.  The reference
+ * (IRIS-AUDIO/challenge) has no FFI of its own -- its boundary is a set of
+ * Python callables.  This header is what a binding for
+ * those callables binds to; every entry point cites the reference interface it
+ * replaces (file:line in the upstream tree).  INTEGRATION.md shows the ctypes
+ * stub a maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / framework types.
+ *  - Every tensor argument is a DEVICE pointer owned by the caller (e.g. the
+ *    PyTorch caching allocator).  Entry points never allocate, never free and
+ *    never synchronise: all work is enqueued on the caller's `stream`
+ *    (a hipStream_t passed as void*; NULL = the default stream).  They are
+ *    therefore safe to capture into a hipGraph.
+ *  - A plan owns its device tables (window, twiddles, mel bands) and a small
+ *    workspace.  A plan is bound to one device; calls on one plan must be
+ *    issued from one thread at a time (the workspace is shared); distinct plans
+ *    are independent.
+ *  - Return value: 0 = ok; negative = IRIS_E_* (bad argument / unsupported
+ *    shape); positive = hipError_t passed through.  iris_last_error() returns a
+ *    thread-local description of the last failure on this thread.
+ *  - All arithmetic is IEEE fp32.  Layouts are row-major ("C order").
+ *
+ * Tensor layouts (reference conventions)
+ *    wav   [B, C, L]        fp32 waveform, 16 kHz or any rate
+ *    spec  [B, F, T, 2C]    complex STFT, re block then im block on the last
+ *                           axis: [..., :C] = re, [..., C:] = im
+ *                           (pipeline.py:131-133, data_utils.py:26-27)
+ *    mel   [B, M, T, C]     (transforms.py:58-68)
+ *    F = n_fft/2 + 1,  T = 1 + L / hop  (torch.stft center=True)
+ */
+#ifndef IRIS_FRONTEND_H
+#define IRIS_FRONTEND_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRIS_ABI_VERSION 1
+
+enum {
+    IRIS_OK = 0,
+    IRIS_E_INVALID = -1,     /* null pointer, non-positive size, inconsistent arguments */
+    IRIS_E_UNSUPPORTED = -2, /* shape outside what the kernels are built for */
+    IRIS_E_CAPACITY = -3,    /* batch / length larger than the plan was created for */
+    IRIS_E_NOMEM = -4
+};
+
+/* flags for iris_wav_to_logmel */
+enum {
+    IRIS_F_MINMAX = 1,    /* apply per-sample min-max (data_utils.py:37-47) */
+    IRIS_F_LOG = 2,       /* apply ln(x + 1e-8)       (data_utils.py:50-55) */
+    IRIS_F_NORMALIZE = 4  /* apply x / (10 rms) per clip first (data_utils.py:32-34) */
+};
+
+typedef struct iris_plan iris_plan;
+
+int iris_abi_version(void);
+const char* iris_last_error(void);
+
+/*
+ * Host-side helper.  W[F, M] of tf.signal.linear_to_mel_weight_matrix as the
+ * reference builds it once per closure (transforms.py:55-56): HTK mel scale,
+ * triangles linear in mel, DC bin zeroed, all arithmetic fp32.
+ * `out` is HOST memory, n_bins * n_mel floats, row-major [n_bins][n_mel].
+ */
+int iris_mel_weight_matrix(int n_mel, int n_bins, float sample_rate,
+                           float lower_hz, float upper_hz, float* out_host);
+
+/*
+ * Plan: the state the closure magphase_to_mel(num_mel_bins,
+ * num_spectrogram_bins, sample_rate, **kw) (transforms.py:51-56) and
+ * torchaudio.transforms.Spectrogram(n_fft, power=None) (data_utils.py:17) hold.
+ *
+ *   n_fft       power of two in [256, 2048]; window = periodic Hann(n_fft)
+ *   hop         > 0 (Spectrogram default: n_fft / 2)
+ *   n_mel       M >= 1
+ *   n_bins      must equal n_fft/2 + 1
+ *   channels    C >= 1 audio channels per clip
+ *   max_batch, max_len   capacity of the workspace (clips, samples per channel)
+ *   mel_host    optional HOST [n_bins*n_mel] matrix to use instead of the
+ *               built-in recipe (any non-negative matrix; band structure is
+ *               detected); NULL = iris_mel_weight_matrix(...)
+ */
+int iris_plan_create(iris_plan** out, int device, int n_fft, int hop, int n_mel,
+                     int n_bins, float sample_rate, float lower_hz, float upper_hz,
+                     int channels, int max_batch, int max_len, const float* mel_host);
+int iris_plan_destroy(iris_plan* plan);
+
+/* Copy the plan's mel matrix [n_bins*n_mel] to HOST memory. */
+int iris_plan_get_mel(const iris_plan* plan, float* out_host);
+/* Frames for a clip of `len` samples: 1 + len / hop. */
+int iris_plan_num_frames(const iris_plan* plan, int len);
+
+/*
+ * normalize (data_utils.py:32-34):  out[r] = wav[r] / (10 * sqrt(mean(wav[r]^2)))
+ * per row r of wav[n_rows, row_len]; one row = all C*L samples of one clip (the
+ * reference takes the rms over every channel jointly).  out may alias wav.
+ * workspace: DEVICE scratch of iris_normalize_workspace(n_rows, row_len) floats.
+ * Runs on the current HIP device.
+ */
+size_t iris_normalize_workspace(int n_rows, size_t row_len);
+int iris_normalize(const float* wav, float* out, int n_rows, size_t row_len, float* workspace,
+                   size_t workspace_floats, void* stream);
+
+/*
+ * STFT of load_wav (data_utils.py:17-27): reflect-pad n_fft/2, frame at `hop`,
+ * periodic Hann, one-sided FFT, no normalisation, written in the reference's
+ * [B, F, T, 2C] re-block / im-block layout.
+ */
+int iris_stft(iris_plan* plan, const float* wav, float* spec, int batch, int len,
+              void* stream);
+
+/*
+ * complex_to_magphase (transforms.py:111-123) on n_outer rows of 2C floats:
+ * out[..., :C] = sqrt(re^2 + im^2), out[..., C:] = atan2(im, re).
+ * magphase_to_complex (transforms.py:126-134) is the inverse.
+ */
+int iris_complex_to_magphase(const float* in, float* out, size_t n_outer, int channels,
+                             void* stream);
+int iris_magphase_to_complex(const float* in, float* out, size_t n_outer, int channels,
+                             void* stream);
+
+/*
+ * complex_to_magphase + magphase_to_mel fused (transforms.py:111-123, :58-70,
+ * call sites sj_train.py:119-120): mel[b,m,t,c] = sum_f W[f,m] * |spec[b,f,t,c]|.
+ * `is_magphase` != 0: `spec` already holds magnitudes in [..., :C] (the phase
+ * half is ignored, transforms.py:64), i.e. plain magphase_to_mel.
+ * t_bands / f_bands: optional DEVICE int32 [B, n, 2] (offset, size) bands zeroed
+ * along time / linear frequency before the reduction -- SpecAugment `mask`
+ * (transforms.py:12-40) as `augment` applies it (data_utils.py:58-61) and
+ * stft_filter (data_utils.py:126-136).  NULL / 0 = none.
+ */
+int iris_magmel(iris_plan* plan, const float* spec, float* mel, int batch, int n_frames,
+                int is_magphase, const int32_t* t_bands, int n_t_bands,
+                const int32_t* f_bands, int n_f_bands, void* stream);
+
+/*
+ * minmax + log_on_mel (data_utils.py:37-55; fused twin trainer.py:63-77),
+ * in place on x[n_rows, row_len]: per row (x - min) / max(max - min, eps_div)
+ * when do_minmax, then ln(x + eps_log) when do_log.  A batched [B,M,T,C] tensor
+ * is n_rows = B; the unbatched [M,T,C] call of metrics.py:53 is n_rows = M
+ * (the reference reduces "every axis except 0").
+ * workspace: DEVICE scratch of iris_minmax_log_workspace(n_rows, row_len)
+ * floats (may be NULL when !do_minmax).  Runs on the current HIP device.
+ */
+size_t iris_minmax_log_workspace(int n_rows, size_t row_len);
+int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minmax, int do_log, float eps_div,
+                    float eps_log, float* workspace, size_t workspace_floats, void* stream);
+
+/*
+ * The fused hot path: [normalize ->] STFT -> magnitude -> band masks -> mel
+ * [-> min-max] [-> log] without materialising the spectrum
+ * (load_wav data_utils.py:22-23 + sj_train.py:108-123).  flags = IRIS_F_*.
+ */
+int iris_wav_to_logmel(iris_plan* plan, const float* wav, float* out, int batch, int len,
+                       int flags, const int32_t* t_bands, int n_t_bands,
+                       const int32_t* f_bands, int n_f_bands, void* stream);
+
+/*
+ * mask apply (transforms.py:12-40, deterministic part): x viewed as
+ * [n_outer, axis_len, n_inner]; elements whose axis index falls in any band
+ * [offset_i, offset_i + size_i) are set to zero (= multiply by the product of
+ * the 0/1 masks, in x's dtype).  bands: DEVICE int32 [n_groups, n_bands, 2];
+ * outer index o uses group o / outer_per_group (one group per sample).
+ * elem_size 4 or 8 bytes (float32/int32 or float64/int64).  In place.
+ */
+int iris_mask_apply(void* x, size_t n_outer, size_t axis_len, size_t n_inner, int elem_size,
+                    const int32_t* bands, int n_bands, size_t outer_per_group, void* stream);
+
+/*
+ * Per-kernel timing for bench.py: when enabled, the dominant kernel of
+ * iris_wav_to_logmel is bracketed by hipEvents on the launch stream.
+ * iris_timing_read synchronises those events and returns the number of
+ * launches recorded since the last reset and their mean duration in ms.
+ */
+int iris_timing_enable(iris_plan* plan, int enable);
+int iris_timing_read(iris_plan* plan, int* n_launches, float* mean_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRIS_FRONTEND_H */

@@ -150,9 +150,14 @@ def magphase_to_complex(x: np.ndarray) -> np.ndarray:
 # R3: mel filterbank                                      transforms.py:51-77
 # --------------------------------------------------------------------------
 def _hertz_to_mel(f, dtype):
+    """1127 * ln(1 + f/700) in `dtype`.  The logarithm is the correctly rounded
+    one (evaluated in float64, rounded once to `dtype`) so that the C++ host code
+    of the product and this restatement agree bit for bit; TF's Eigen log may
+    differ in the last bit, which moves W entries by up to ~1e-5 (see header)."""
     f = np.asarray(f, dtype=dtype)
-    return (dtype(_MEL_HIGH_FREQUENCY_Q)
-            * np.log(dtype(1.0) + f / dtype(_MEL_BREAK_FREQUENCY_HERTZ))).astype(dtype)
+    arg = (dtype(1.0) + f / dtype(_MEL_BREAK_FREQUENCY_HERTZ)).astype(dtype)
+    ln = np.log(arg.astype(np.float64)).astype(dtype)
+    return (dtype(_MEL_HIGH_FREQUENCY_Q) * ln).astype(dtype)
 
 
 def _linspace(start, stop, num, dtype):

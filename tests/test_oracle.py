@@ -242,3 +242,15 @@ def test_label_downsample_and_helpers():
     assert np.array_equal(mc[..., 0], x[..., 0] + x[..., 1])
     f = R.stft_filter(2)(x.reshape(4, 3, 2))
     assert np.all(f[1:3] == 0) and np.all(f[0] == x.reshape(4, 3, 2)[0]) and np.all(f[3] == x.reshape(4, 3, 2)[3])
+
+
+def test_torch_cpu_baseline_matches_numpy_oracle():
+    import torch
+    from oracle.torch_cpu_ref import wav_to_logmel_cpu
+    rng = np.random.default_rng(4)
+    wav = R.normalize(rng.standard_normal((3, 2 * 5000)).astype(np.float32)).reshape(3, 2, 5000)
+    w = R.linear_to_mel_weight_matrix(64, 513, 16000)
+    out = wav_to_logmel_cpu(torch.from_numpy(wav), torch.from_numpy(w), 1024, 256).numpy()
+    ref = R.wav_to_logmel(wav, 1024, 256, 64, 16000)
+    assert out.shape == ref.shape
+    assert np.abs(np.exp(out) - np.exp(ref)).max() <= 5e-6
