@@ -185,7 +185,12 @@ def test_normalize_flag_and_op(dev):
     assert np.abs(single - ref_norm[1]).max() <= 1e-6 * np.abs(ref_norm).max()
     plan = FE().FrontendPlan(512, 256, 80, 16000, 2, 3, 7000, dev)
     fused = plan.wav_to_logmel(torch.from_numpy(raw).to(dev), minmax=False, log=False, normalize=True).cpu().numpy()
-    assert rel_err(fused, R.wav_to_mel(ref_norm, 512, 256, 80, 16000)) <= 1e-5
+    ref = R.wav_to_mel(ref_norm, 512, 256, 80, 16000)
+    # IRIS_F_NORMALIZE folds 1/(10 rms) into the window, so the FFT input is rounded
+    # differently from the oracle's (which rounds x/rms to fp32 first): compare at 2e-6
+    # of full scale instead of per-element relative error.
+    assert np.abs(fused - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert rel_err(fused, ref, floor=0.05) <= 1e-5
 
 
 def test_minmax_log_generic(dev):
