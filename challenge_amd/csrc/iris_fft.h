@@ -10,6 +10,10 @@
 //   * the real spectrum follows from X[k] = E + w^k O, X[NC-k] = conj(E - w^k O)
 //     with E = (Z[k] + conj Z[NC-k]) / 2, O = (Z[k] - conj Z[NC-k]) / 2i.
 // No barrier is needed: a wave's DS instructions execute in issue order.
+//
+// A complex number is a 2-wide float vector (one 64-bit register pair), so that a
+// complex add/sub is ONE packed-f32 instruction (v_pk_add_f32) and a complex
+// multiply is two (v_pk_mul_f32 + v_pk_fma_f32 with op_sel / neg modifiers).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -17,13 +21,22 @@ namespace iris {
 
 constexpr int kWave = 64;
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+typedef float cf __attribute__((ext_vector_type(2)));  // (re, im)
+
+__device__ __forceinline__ cf mk(float re, float im) {
+    cf r = {re, im};
+    return r;
 }
-// multiply by -i
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+// a + (-i) b  and  a - (-i) b      ((-i) b = (b.im, -b.re)).  Written as one packed FMA
+// with a (+-1, -+1) constant: the swap of b folds into op_sel, the sign sits in the
+// constant, the product by +-1 is exact -- so each is ONE instruction.
+__device__ __forceinline__ cf add_mi(cf a, cf b) { return __builtin_elementwise_fma(b.yx, mk(1.0f, -1.0f), a); }
+__device__ __forceinline__ cf sub_mi(cf a, cf b) { return __builtin_elementwise_fma(b.yx, mk(-1.0f, 1.0f), a); }
+// a * w = a.re * w + a.im * (-w.im, w.re)
+__device__ __forceinline__ cf cmul(cf a, cf w) {
+    const cf t = a.yy * mk(-w.y, w.x);
+    return __builtin_elementwise_fma(a.xx, w, t);
+}
 
 // cos/sin(2 pi k / 16), k = 0..7
 __device__ constexpr float kC16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
@@ -33,20 +46,43 @@ __device__ constexpr float kS16[8] = {0.0f, 0.38268343236508977f, 0.707106781186
 
 // In-place forward DFT of R points, natural-order output.
 template <int R>
-__device__ __forceinline__ void dft(float2 (&v)[R]) {
+__device__ __forceinline__ void dft(cf (&v)[R]) {
     if constexpr (R == 2) {
-        float2 a = v[0], b = v[1];
-        v[0] = cadd(a, b);
-        v[1] = csub(a, b);
+        const cf a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
     } else if constexpr (R == 4) {
-        float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
-        float2 t2 = cadd(v[1], v[3]), t3 = mul_mi(csub(v[1], v[3]));
-        v[0] = cadd(t0, t2);
-        v[1] = cadd(t1, t3);
-        v[2] = csub(t0, t2);
-        v[3] = csub(t1, t3);
+        const cf t0 = v[0] + v[2], t1 = v[0] - v[2];
+        const cf t2 = v[1] + v[3], t3 = v[1] - v[3];
+        v[0] = t0 + t2;
+        v[1] = add_mi(t1, t3);
+        v[2] = t0 - t2;
+        v[3] = sub_mi(t1, t3);
+    } else if constexpr (R == 8) {
+        // decimation in frequency: 24 complex add/sub (one packed instruction each) + two
+        // rotations by (1 -+ i)/sqrt(2) (one packed add + one packed multiply each)
+        constexpr float r = 0.70710678118654752f;
+        const cf a0 = v[0] + v[4], a1 = v[1] + v[5], a2 = v[2] + v[6], a3 = v[3] + v[7];
+        const cf d0 = v[0] - v[4], d1 = v[1] - v[5], d2 = v[2] - v[6], d3 = v[3] - v[7];
+        {
+            const cf s0 = a0 + a2, s1 = a1 + a3, t0 = a0 - a2, t1 = a1 - a3;
+            v[0] = s0 + s1;
+            v[4] = s0 - s1;
+            v[2] = add_mi(t0, t1);
+            v[6] = sub_mi(t0, t1);
+        }
+        {
+            const cf e1 = add_mi(d1, d1) * r;   // W8^1 d1 = r (d.re + d.im, d.im - d.re)
+            const cf e3 = sub_mi(d3, d3) * -r;  // W8^3 d3 = -r (d.re - d.im, d.re + d.im)
+            const cf s0 = add_mi(d0, d2), t0 = sub_mi(d0, d2);
+            const cf s1 = e1 + e3, t1 = e1 - e3;
+            v[1] = s0 + s1;
+            v[5] = s0 - s1;
+            v[3] = add_mi(t0, t1);
+            v[7] = sub_mi(t0, t1);
+        }
     } else {
-        float2 e[R / 2], o[R / 2];
+        cf e[R / 2], o[R / 2];
 #pragma unroll
         for (int i = 0; i < R / 2; ++i) {
             e[i] = v[2 * i];
@@ -57,20 +93,30 @@ __device__ __forceinline__ void dft(float2 (&v)[R]) {
 #pragma unroll
         for (int k = 0; k < R / 2; ++k) {
             constexpr int step = 16 / R;
-            // W_R^k = cos - i sin
-            float2 w = make_float2(kC16[k * step], -kS16[k * step]);
-            float2 t = (k == 0) ? o[k] : cmul(o[k], w);
-            v[k] = cadd(e[k], t);
-            v[k + R / 2] = csub(e[k], t);
+            const cf w = mk(kC16[k * step], -kS16[k * step]);  // W_R^k = cos - i sin
+            const cf t = (k == 0) ? o[k] : cmul(o[k], w);
+            v[k] = e[k] + t;
+            v[k + R / 2] = e[k] - t;
         }
     }
 }
 
-// LDS padding: one complex slot per 8 keeps the stride-R writes of a stage and
-// the unit-stride reads of the next on distinct banks.
-__device__ __forceinline__ int lds_pad(int i) { return i + (i >> 3); }
-constexpr int lds_padded(int n) { return n + (n >> 3); }
+// LDS padding.  DS accesses of 8 bytes are serviced in groups of 16 consecutive
+// lanes over 16 slots of 8 bytes, so an access is conflict-free when the 16 lanes
+// of a group hit 16 distinct slots (complex index mod 16).  pad(i) = i + PM*(i>>4)
+// moves whole 16-point blocks, so the unit-stride reads of a stage (16 aligned
+// consecutive points per group) stay conflict-free for any PM, and PM is chosen per
+// exchange so that the strided writes of the producing stage are conflict-free too:
+//   NS == 1 or NS >= 16 : PM = 1;   otherwise PM = 16/R (R >= 4) or NS (R == 2).
+// Every address a stage touches is pad(base) + compile-time offset (no carry into
+// the block index), i.e. one base VGPR per access pattern + immediate offsets.
+template <int PM>
+__device__ __forceinline__ constexpr int lds_pad(int i) { return i + PM * (i >> 4); }
+constexpr int stage_pm(int NS, int R) { return (NS == 1 || NS >= 16) ? 1 : (R == 2 ? NS : 16 / R); }
+constexpr int lds_padded(int n, int pm_max) { return n + pm_max * (n >> 4) + 1; }  // +1: slot NC is addressable
 
+// Orders this wave's LDS accesses for the compiler; a wave's DS instructions execute
+// in issue order, so no hardware wait is needed between a write and a dependent read.
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -81,11 +127,11 @@ __device__ __forceinline__ void wave_sync_lds() {
 // NS = product of the radices of the earlier stages.  tw: (P/R)*(R-1) per-lane
 // twiddles exp(-2 pi i ((lane + 64u) mod NS) t / (NS R)), index u*(R-1) + t-1.
 template <int P, int R, int NS, bool LAST>
-__device__ __forceinline__ void fft_stage(float2 (&x)[P], const float2* tw, float2* lds, int lane) {
-    constexpr int U = P / R;
+__device__ __forceinline__ void fft_stage(cf (&x)[P], const cf* tw, cf* lds, int lane) {
+    constexpr int U = P / R, PM = stage_pm(NS, R);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        float2 v[R];
+        cf v[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) v[t] = x[u + t * U];
         if constexpr (NS > 1) {
@@ -98,46 +144,43 @@ __device__ __forceinline__ void fft_stage(float2 (&x)[P], const float2* tw, floa
             for (int t = 0; t < R; ++t) x[u + t * U] = v[t];
         } else {
             const int b = lane + kWave * u;
-            const int base = (b / NS) * (NS * R) + (b % NS);
+            cf* wp = lds + lds_pad<PM>((b / NS) * (NS * R) + (b % NS));
 #pragma unroll
-            for (int t = 0; t < R; ++t) lds[lds_pad(base + t * NS)] = v[t];
+            for (int t = 0; t < R; ++t) wp[lds_pad<PM>(t * NS)] = v[t];
         }
     }
     if constexpr (!LAST) {
         wave_sync_lds();
+        const cf* rp = lds + lds_pad<PM>(lane);
 #pragma unroll
-        for (int q = 0; q < P; ++q) x[q] = lds[lds_pad(lane + kWave * q)];
+        for (int q = 0; q < P; ++q) x[q] = rp[lds_pad<PM>(kWave * q)];
         wave_sync_lds();
     }
 }
 
-// Per-size configuration: radix sequence and table sizes.
+// Per-size configuration: points per lane, table sizes, largest pad multiplier.
 template <int LOG2N>
 struct FftCfg;
 
 template <>
 struct FftCfg<11> {  // n_fft 2048: NC 1024 = 16 * 16 * 4
-    static constexpr int P = 16, NSTAGE = 3, NTW = 15 + 4 * 3;
-    static constexpr int radix(int s) { return s < 2 ? 16 : 4; }
+    static constexpr int P = 16, NSTAGE = 3, NTW = 15 + 4 * 3, PMMAX = 1;
 };
 template <>
 struct FftCfg<10> {  // n_fft 1024: NC 512 = 8 * 8 * 8
-    static constexpr int P = 8, NSTAGE = 3, NTW = 7 + 7;
-    static constexpr int radix(int) { return 8; }
+    static constexpr int P = 8, NSTAGE = 3, NTW = 7 + 7, PMMAX = 2;
 };
 template <>
 struct FftCfg<9> {  // n_fft 512: NC 256 = 4 * 4 * 4 * 4
-    static constexpr int P = 4, NSTAGE = 4, NTW = 3 * 3;
-    static constexpr int radix(int) { return 4; }
+    static constexpr int P = 4, NSTAGE = 4, NTW = 3 * 3, PMMAX = 4;
 };
 template <>
 struct FftCfg<8> {  // n_fft 256: NC 128 = 2^7
-    static constexpr int P = 2, NSTAGE = 7, NTW = 6;
-    static constexpr int radix(int) { return 2; }
+    static constexpr int P = 2, NSTAGE = 7, NTW = 6, PMMAX = 8;
 };
 
 template <int LOG2N>
-__device__ __forceinline__ void fft_frame(float2 (&x)[FftCfg<LOG2N>::P], const float2* tw, float2* lds, int lane) {
+__device__ __forceinline__ void fft_frame(cf (&x)[FftCfg<LOG2N>::P], const cf* tw, cf* lds, int lane) {
     if constexpr (LOG2N == 11) {
         fft_stage<16, 16, 1, false>(x, nullptr, lds, lane);
         fft_stage<16, 16, 16, false>(x, tw, lds, lane);
@@ -161,12 +204,5 @@ __device__ __forceinline__ void fft_frame(float2 (&x)[FftCfg<LOG2N>::P], const f
         fft_stage<2, 2, 64, true>(x, tw + 5, lds, lane);
     }
 }
-
-// Device tables of a plan, all [count][64] float2, lane-minor.
-struct FftTables {
-    const float2* tw;    // [NTW][64]   stage twiddles
-    const float2* post;  // [P/2][64]   exp(-2 pi i (lane + 64 q) / n_fft)
-    const float2* win;   // [P][64]     (hann[2n], hann[2n+1]), n = lane + 64 q
-};
 
 }  // namespace iris

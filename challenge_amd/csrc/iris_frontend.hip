@@ -17,6 +17,13 @@
 
 using namespace iris;
 
+// Diagnostic build (make diag): IRIS_ABLATE=<bits> skips phases of the fused kernel and
+// records per-workgroup clock stamps.  In the product build every check folds away.
+#ifndef IRIS_DIAG
+#define IRIS_DIAG 0
+#endif
+#define ABL(bit) (IRIS_DIAG && (a.ablate & (bit)))
+
 // ---------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------
@@ -49,16 +56,18 @@ struct iris_plan {
     std::vector<float> mel;  // [F][M]
     int max_band_len, k_need;
     // device tables
-    float2* d_tw;
-    float2* d_post;
-    float2* d_win;
-    int* d_band_lo;
-    float* d_wband;  // [max_band_len][M]
-    float* d_mel;    // [F][M] dense (for magmel)
-    int* d_band_len;
+    float* d_consts;  // per-lane constant block [NV4][64][4]
+    int* d_band_lo;   // [M] first non-zero bin of each band (magmel)
+    int* d_band_len;  // [M]
+    float* d_mel;     // [F][M] dense (magmel)
+    int* d_fband_lo;  // [M] fused kernel: first bin read, clamped so lo + rows <= limit
+    float* d_wband;   // [rows][M] fused kernel: 0.5 * W[lo + i][m]
+    int rows, need_hi, mel_mode;
     float* d_ws;  // workspace
+    unsigned long long* d_dbg;  // diagnostic stamps
     size_t ws_floats;
-    int tile_frames;  // frames per workgroup tile of the fused kernel
+    int num_cu;
+    int chunk_target;  // 0 = auto; frames per chunk of the fused kernel (IRIS_CHUNK_FRAMES)
     // timing
     bool timing;
     std::vector<hipEvent_t> ev;  // pairs
@@ -131,190 +140,409 @@ __device__ __forceinline__ bool in_bands(const int* bands, int n, int idx) {
 // frame -> spectrum pieces shared by the fused and the STFT kernels
 // ---------------------------------------------------------------------------
 template <int LOG2N>
-__device__ __forceinline__ void load_frame(float2 (&x)[FftCfg<LOG2N>::P], const float* clip, int len, int start,
+__device__ __forceinline__ void load_frame(cf (&x)[FftCfg<LOG2N>::P], const float* clip, int len, int start,
                                            int lane) {
     constexpr int N = 1 << LOG2N, P = FftCfg<LOG2N>::P;
     const bool interior = (start >= 0) && (start + N <= len) &&
                           ((reinterpret_cast<uintptr_t>(clip + start) & 7) == 0);
     if (interior) {  // wave-uniform
-        const float2* p = reinterpret_cast<const float2*>(clip + start);
+        const cf* p = reinterpret_cast<const cf*>(clip + start);
 #pragma unroll
         for (int q = 0; q < P; ++q) x[q] = p[lane + kWave * q];
     } else {
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             const int n = start + 2 * (lane + kWave * q);
-            x[q].x = clip[reflect_idx(n, len)];
-            x[q].y = clip[reflect_idx(n + 1, len)];
+            x[q] = mk(clip[reflect_idx(n, len)], clip[reflect_idx(n + 1, len)]);
         }
     }
 }
 
 // x[q] = Z[lane + 64 q] -> Xlo[q] = X[k], Xhi[q] = X[NC - k], k = lane + 64 q, q < P/2.
-// Uses the wave's LDS buffer; ends with the buffer free for reuse.
-template <int LOG2N, bool HI>
-__device__ __forceinline__ void untangle(const float2 (&x)[FftCfg<LOG2N>::P], const float2* post, float2* lds,
-                                         int lane, float2 (&xlo)[FftCfg<LOG2N>::P / 2],
-                                         float2 (&xhi)[FftCfg<LOG2N>::P / 2]) {
-    constexpr int NC = (1 << LOG2N) / 2, P = FftCfg<LOG2N>::P;
+// HALF = false leaves out the factor 0.5 (outputs are 2 X).  Uses the wave's LDS
+// buffer; ends with the buffer free for reuse.
+template <int LOG2N, bool HI, bool HALF>
+__device__ __forceinline__ void untangle(const cf (&x)[FftCfg<LOG2N>::P], const cf* post, cf* lds, int lane,
+                                         cf (&xlo)[FftCfg<LOG2N>::P / 2], cf (&xhi)[FftCfg<LOG2N>::P / 2]) {
+    constexpr int P = FftCfg<LOG2N>::P;
+    // partners of k = lane + 64 q (q < P/2) are NC - k = (64 - lane) + 64 (P - 1 - q), i.e.
+    // rows P/2 .. P-1 (lane 0 reads row P - q, lane 0): only the upper half is ever fetched
+    cf* wp = lds + lds_pad<1>(lane);
 #pragma unroll
-    for (int q = 0; q < P; ++q) lds[lds_pad(lane + kWave * q)] = x[q];
+    for (int q = P / 2; q < P; ++q) wp[lds_pad<1>(kWave * q)] = x[q];
     wave_sync_lds();
+    // lane 0, q 0 pairs with itself (slot NC is addressable but unused)
+    const cf* rp = lds + lds_pad<1>(kWave - lane);
 #pragma unroll
     for (int q = 0; q < P / 2; ++q) {
-        const int k = lane + kWave * q;
-        const float2 zk = x[q];
-        const float2 zp = lds[lds_pad((NC - k) & (NC - 1))];
-        const float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y - zp.y));
-        const float2 o = make_float2(0.5f * (zk.y + zp.y), -0.5f * (zk.x - zp.x));
-        const float2 wo = cmul(post[q], o);
-        xlo[q] = cadd(e, wo);
+        const cf zk = x[q];
+        cf zp = rp[lds_pad<1>(kWave * (P - 1 - q))];
+        if (q == 0 && lane == 0) zp = zk;
+        const cf zc = mk(zp.x, -zp.y);  // conj(Z[NC-k])
+        cf e = zk + zc;                 // 2 E
+        const cf d = zk - zc;           // 2 i O
+        cf o = mk(d.y, -d.x);           // 2 O
+        if constexpr (HALF) {
+            e *= 0.5f;
+            o *= 0.5f;
+        }
+        const cf wo = cmul(o, post[q]);
+        xlo[q] = e + wo;
         if constexpr (HI) {
-            const float2 d = csub(e, wo);
-            xhi[q] = make_float2(d.x, -d.y);
+            const cf t = e - wo;
+            xhi[q] = mk(t.x, -t.y);
         }
     }
     wave_sync_lds();
 }
 
-__device__ __forceinline__ float cabs_rn(float2 v) { return __builtin_amdgcn_sqrtf(fmaf(v.x, v.x, v.y * v.y)); }
+__device__ __forceinline__ float cabs_rn(cf v) { return __builtin_amdgcn_sqrtf(fmaf(v.x, v.x, v.y * v.y)); }
 
 // ---------------------------------------------------------------------------
-// K1: fused wav -> mel magnitudes (+ per-tile min/max partials)
-//   grid  = B * tiles_per_clip workgroups of 256 threads (4 waves)
-//   tile  = `tile_frames` consecutive frames of one clip, all C channels
-//   LDS   = 4 wave buffers (FFT exchange / magnitudes) + [M][tile_frames*C+1] out tile
+// per-lane constant block: every lane's twiddles / untangle twiddles / window /
+// register mel weights, packed so that a wave fetches it with NV4 coalesced
+// 16-byte loads issued back to back (one wait), layout [NV4][64 lanes][4 floats]
 // ---------------------------------------------------------------------------
+constexpr int kMelRegs = 20;  // register mel window: 5 x 16-byte LDS reads
+
+template <int LOG2N>
+struct ConstLayout {
+    static constexpr int NTW = FftCfg<LOG2N>::NTW, P = FftCfg<LOG2N>::P;
+    static constexpr int OFF_TW = 0, OFF_POST = 2 * NTW, OFF_WIN = OFF_POST + P, OFF_WREG = OFF_WIN + 2 * P,
+                         OFF_LO = OFF_WREG + kMelRegs, NF = OFF_LO + 1, NV4 = (NF + 3) / 4;
+};
+
+template <int LOG2N>
+__device__ __forceinline__ void load_consts(const float* consts, int lane, cf (&tw)[FftCfg<LOG2N>::NTW],
+                                            cf (&post)[FftCfg<LOG2N>::P / 2], cf (&win)[FftCfg<LOG2N>::P],
+                                            float (&wreg)[kMelRegs], int& lo0) {
+    using CL = ConstLayout<LOG2N>;
+    float cv[CL::NV4 * 4];
+    const float4* src = reinterpret_cast<const float4*>(consts);
+#pragma unroll
+    for (int v = 0; v < CL::NV4; ++v) {
+        const float4 t = src[v * kWave + lane];
+        cv[4 * v + 0] = t.x;
+        cv[4 * v + 1] = t.y;
+        cv[4 * v + 2] = t.z;
+        cv[4 * v + 3] = t.w;
+    }
+#pragma unroll
+    for (int i = 0; i < CL::NTW; ++i) tw[i] = mk(cv[CL::OFF_TW + 2 * i], cv[CL::OFF_TW + 2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < CL::P / 2; ++i) post[i] = mk(cv[CL::OFF_POST + 2 * i], cv[CL::OFF_POST + 2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < CL::P; ++i) win[i] = mk(cv[CL::OFF_WIN + 2 * i], cv[CL::OFF_WIN + 2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < kMelRegs; ++i) wreg[i] = cv[CL::OFF_WREG + i];
+    lo0 = __float_as_int(cv[CL::OFF_LO]);
+}
+
+// ---------------------------------------------------------------------------
+// K1: fused wav -> mel magnitudes (+ per-chunk min/max partials)
+//   work unit = chunk: `chunk_frames` consecutive frames of one clip, all C channels
+//   grid      = min(#chunks, fused_occ per CU) workgroups of 4 waves looping over chunks
+//   per wave  = one frame at a time:
+//                 LDS-DMA (global_load_lds) of the NEXT frame into the wave's frame
+//                 buffer -- no VGPRs, reflect padding resolved in the DMA's per-lane
+//                 source address -- while the current frame is windowed, transformed
+//                 (registers + private padded LDS exchanges), untangled, |X| written
+//                 to LDS and reduced over the banded mel weights
+//   LDS       = per wave [frame buffer N floats | exchange buffer] | out tile
+//               [M][chunk_frames*C+1] | red[32] | mel table (mode 1)
+//   MELMODE 0 = band weights in registers (M <= 64, band length <= 16): each lane reads
+//               a 16-byte-aligned window of 20 magnitudes with 5 ds_read_b128
+//           1 = band table staged in LDS, 2 = band table read from global (L1/L2)
+//   HI        = some band needs bins above n_fft/4 (both halves of the untangle)
+//   BANDS     = SpecAugment / filter bands present
+// ---------------------------------------------------------------------------
+constexpr int kFusedWaves = 4;   // waves per workgroup
+// workgroups per CU (= waves per SIMD): 3 -> <= 168 VGPRs; n_fft 2048 keeps 16 points per
+// lane and needs the 256-VGPR budget of 2
+constexpr int fused_occ(int log2n) { return log2n >= 11 ? 2 : 3; }
+
 struct FusedArgs {
     const float* wav;    // [B, C, L]
     float* out;          // [B, M, T, C]
-    float* partial;      // [B, tiles, 2] min, max
+    float* partial;      // [B, chunks_per_clip, 2] min, max
     const float* sumsq;  // nullable [B, n_sq] partial sums of squares (normalize)
     int n_sq;
-    FftTables tab;
-    const int* band_lo;    // [M]
-    const float* wband;    // [max_len][M]
-    int max_len, k_need;
+    const float* consts;  // per-lane constant block (ConstLayout)
+    const int* band_lo;   // [M] first bin read by band m (clamped so lo + rows <= limit)
+    const float* wband;   // [rows][M], 0.5 * W[lo + i][m]
+    int rows;
     const int* t_bands;  // nullable [B, n_tb, 2]
     int n_tb;
     const int* f_bands;  // nullable [B, n_fb, 2]
     int n_fb;
-    int B, C, L, T, hop, M, tile_frames, tiles_per_clip;
+    int B, C, L, T, hop, M;
+    int chunk_frames, chunks_per_clip, n_chunks;
+    int ablate;  // diagnostic only (IRIS_ABLATE): skip phases, results are wrong when non-zero
+    unsigned long long* dbg;  // diagnostic only: [4] shader-clock / 100 MHz stamps of workgroup 0
 };
 
+// LDS-DMA of one frame.  Inline asm on purpose: hipcc drains an LDS-DMA it knows about
+// (s_waitcnt vmcnt(0)) before the next DS access that might alias it, which would
+// serialise the prefetch with the FFT.  Hidden from the compiler the DMA stays in flight
+// across the whole frame computation; the kernel waits for it by hand right before it
+// reads the frame buffer.  M0 = wave-uniform LDS byte address (saved / restored inside
+// the statement); the instruction offset applies to the global and the LDS address alike.
+//   dma_frame_x4: frame interior and 16-byte aligned -> N/256 pieces of 16 B per lane,
+//                 source = SGPR base + lane*16 + imm
+//   dma_frame_x1: any frame -> N/64 pieces of 4 B per lane with per-lane source
+//                 addresses (reflect padding costs nothing extra)
 template <int LOG2N>
-__global__ __launch_bounds__(256) void k_wav_to_mel(const FusedArgs a) {
+__device__ __forceinline__ void dma_frame_x4(const float* src /*uniform*/, unsigned fbuf_lds, unsigned lane16) {
+    static_assert(LOG2N >= 8 && LOG2N <= 11, "");
+    unsigned keep;
+    if constexpr (LOG2N == 8)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src), "s"(fbuf_lds) : "memory");
+    else if constexpr (LOG2N == 9)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src), "s"(fbuf_lds) : "memory");
+    else if constexpr (LOG2N == 10)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src), "s"(fbuf_lds) : "memory");
+    else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src), "s"(fbuf_lds) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src + 1024), "s"(fbuf_lds + 4096) : "memory");
+    }
+}
+
+__device__ __forceinline__ void glds4(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int LOG2N>
+__device__ __forceinline__ void dma_frame_x1(const float* clip, int len, int start, unsigned fbuf_lds, int lane) {
+    constexpr int N = 1 << LOG2N;
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < N / 64; ++i)
+        glds4(clip + reflect_idx(start + 64 * i + lane, len), __builtin_amdgcn_readfirstlane(fbuf_lds + 256 * i));
+}
+
+template <int LOG2N>
+__device__ __forceinline__ void dma_frame(const float* clip, int len, int start, unsigned fbuf_lds, int lane) {
+    constexpr int N = 1 << LOG2N;
+    // clip/start are wave-uniform by construction; make that provable for the "s" operands
+    const uint64_t u = reinterpret_cast<uint64_t>(clip + start);
+    const uint32_t ulo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t uhi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    const float* src = reinterpret_cast<const float*>(((uint64_t)uhi << 32) | ulo);
+    start = __builtin_amdgcn_readfirstlane(start);
+    if ((start >= 0) && (start + N <= len) && ((ulo & 15u) == 0))
+        dma_frame_x4<LOG2N>(src, fbuf_lds, (unsigned)lane * 16u);
+    else
+        dma_frame_x1<LOG2N>(clip, len, start, fbuf_lds, lane);
+}
+
+template <int LOG2N, int MELMODE, bool HI, bool BANDS>
+__global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_mel(const FusedArgs a) {
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
     constexpr int F = NC + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = wg / a.tiles_per_clip, tile = wg - b * a.tiles_per_clip;
-    const int t0 = tile * a.tile_frames;
-    const int nt = min(a.tile_frames, a.T - t0);
-    const int tile_stride = a.tile_frames * a.C + 1;
+    // the wave index is uniform: keep it (and everything derived from it) in SGPRs
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile_stride = a.chunk_frames * a.C + 1;
 
-    constexpr int kWaveBufBytes = lds_padded(NC) * 8;
-    float2* lds = reinterpret_cast<float2*>(smem + wv * kWaveBufBytes);
+    constexpr int kXBufBytes = (lds_padded(NC, FftCfg<LOG2N>::PMMAX) * 8 + 15) & ~15;
+    constexpr int kWaveBytes = N * 4 + kXBufBytes;
+    const float* fbuf = reinterpret_cast<const float*>(smem + wv * kWaveBytes);
+    const unsigned fbuf_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + wv * kWaveBytes));
+    cf* lds = reinterpret_cast<cf*>(smem + wv * kWaveBytes + N * 4);
     float* magbuf = reinterpret_cast<float*>(lds);
-    float* tile_out = reinterpret_cast<float*>(smem + 4 * kWaveBufBytes);
-    float* red = tile_out + a.M * tile_stride;  // [16]
+    float* tile_out = reinterpret_cast<float*>(smem + kFusedWaves * kWaveBytes);
+    float* red = tile_out + a.M * tile_stride;  // [32]
+    float* wtab = red + 32;                     // MELMODE 1: [rows][M] then int lo[M]
+    int* lotab = reinterpret_cast<int*>(wtab + a.rows * a.M);
 
-    // per-lane constants
-    float2 tw[NTW], post[P / 2], win[P];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) tw[i] = a.tab.tw[i * kWave + lane];
-#pragma unroll
-    for (int i = 0; i < P / 2; ++i) post[i] = a.tab.post[i * kWave + lane];
-#pragma unroll
-    for (int i = 0; i < P; ++i) win[i] = a.tab.win[i * kWave + lane];
-
-    if (a.sumsq != nullptr) {  // normalize: fold 1 / (10 rms) into the window
-        float s = 0.f;
-        for (int i = lane; i < a.n_sq; i += kWave) s += a.sumsq[(size_t)b * a.n_sq + i];
-        s = wave_sum(s);
-        const float rms10 = sqrtf(s / ((float)a.C * (float)a.L)) * 10.0f;
-        const float inv = 1.0f / rms10;
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            win[i].x *= inv;
-            win[i].y *= inv;
-        }
+    unsigned long long real_entry = 0;
+    if ABL(512) real_entry = __builtin_amdgcn_s_memrealtime();
+    // per-lane constants, resident for the whole kernel
+    cf tw[NTW], post[P / 2], win[P];
+    float wreg[kMelRegs];
+    int lo0;
+    load_consts<LOG2N>(a.consts, lane, tw, post, win, wreg, lo0);
+    if constexpr (MELMODE == 1) {
+        for (int i = threadIdx.x; i < a.rows * a.M; i += blockDim.x) wtab[i] = a.wband[i];
+        for (int i = threadIdx.x; i < a.M; i += blockDim.x) lotab[i] = a.band_lo[i];
+        __syncthreads();
     }
+    const float4* mag4 = reinterpret_cast<const float4*>(magbuf + lo0);  // lo0 is a multiple of 4
+    float* my_tile = tile_out + lane * tile_stride;
 
-    const int* tb = a.t_bands ? a.t_bands + (size_t)b * a.n_tb * 2 : nullptr;
-    const int* fb = a.f_bands ? a.f_bands + (size_t)b * a.n_fb * 2 : nullptr;
-    const bool need_hi = a.k_need > NC / 2;
+    unsigned long long stamp0 = 0, real0 = 0;
+    if ABL(512) {
+        stamp0 = __builtin_amdgcn_s_memtime();
+        real0 = __builtin_amdgcn_s_memrealtime();
+    }
+    const int g0 = xcd_remap(blockIdx.x, gridDim.x);
+    for (int chunk = g0; chunk < a.n_chunks; chunk += gridDim.x) {
+        const int b = chunk / a.chunks_per_clip, ci = chunk - b * a.chunks_per_clip;
+        const int t0 = ci * a.chunk_frames;
+        const int nt = min(a.chunk_frames, a.T - t0);
+        const int* tb = nullptr;
+        const int* fb = nullptr;
+        if constexpr (BANDS) {
+            tb = a.t_bands ? a.t_bands + (size_t)b * a.n_tb * 2 : nullptr;
+            fb = a.f_bands ? a.f_bands + (size_t)b * a.n_fb * 2 : nullptr;
+        }
+        const float* clip0 = a.wav + (size_t)b * a.C * a.L;
 
-    const int nwf = nt * a.C;  // wave-frames in this tile
-    for (int f = wv; f < nwf; f += 4) {
-        const int tl = f / a.C, c = f - tl * a.C;
-        const int t = t0 + tl;
-        bool masked = false;
-        if (tb) masked = in_bands(tb, a.n_tb, t);
-        if (masked) {  // wave-uniform
-            for (int m = lane; m < a.M; m += kWave) tile_out[m * tile_stride + f] = 0.f;
-            continue;
+        float scale = 1.0f;  // normalize: |X| is linear in the waveform, so 1 / (10 rms) scales the mel
+        if (a.sumsq != nullptr) {
+            float s = 0.f;
+            for (int i = lane; i < a.n_sq; i += kWave) s += a.sumsq[(size_t)b * a.n_sq + i];
+            s = wave_sum(s);
+            scale = 1.0f / (sqrtf(s / ((float)a.C * (float)a.L)) * 10.0f);
         }
-        const float* clip = a.wav + ((size_t)b * a.C + c) * a.L;
-        float2 x[P];
-        load_frame<LOG2N>(x, clip, a.L, t * a.hop - N / 2, lane);
+
+        const int nwf = nt * a.C;  // wave-frames in this chunk: f = tl * C + c
+        int f = wv, tl = wv / a.C, c = wv - tl * a.C;
+        if (f < nwf && !ABL(8))
+            dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds, lane);
+        while (f < nwf) {
+            // frame f has landed; pull it into registers, then reuse the buffer for the next one
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            cf x[P];
+            {
+                const cf* fb2 = reinterpret_cast<const cf*>(fbuf) + lane;
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            x[q].x *= win[q].x;
-            x[q].y *= win[q].y;
-        }
-        fft_frame<LOG2N>(x, tw, lds, lane);
-        float2 xlo[P / 2], xhi[P / 2];
-        if (need_hi) {
-            untangle<LOG2N, true>(x, post, lds, lane, xlo, xhi);
-#pragma unroll
-            for (int q = 0; q < P / 2; ++q) {
-                const int k = lane + kWave * q;
-                magbuf[k] = cabs_rn(xlo[q]);
-                magbuf[NC - k] = cabs_rn(xhi[q]);
+                for (int q = 0; q < P; ++q) x[q] = fb2[kWave * q];
             }
-            if (lane == 0) magbuf[NC / 2] = cabs_rn(x[P / 2]);
-        } else {
-            untangle<LOG2N, false>(x, post, lds, lane, xlo, xhi);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int fcur = f, tcur = t0 + tl;
+            f += kFusedWaves;
+            c += kFusedWaves;
+            while (c >= a.C) {
+                c -= a.C;
+                ++tl;
+            }
+            if (f < nwf && !ABL(8))
+                dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds, lane);
+
+            if constexpr (BANDS) {
+                const bool masked = tb ? in_bands(tb, a.n_tb, tcur) : false;  // wave-uniform
+                if (masked) {
+                    for (int m = lane; m < a.M; m += kWave) tile_out[m * tile_stride + fcur] = 0.f;
+                    continue;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q) x[q] *= win[q];
+            if (!ABL(1)) fft_frame<LOG2N>(x, tw, lds, lane);
+            cf xlo[P / 2], xhi[P / 2];
+            // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)
+            if (!ABL(2)) {
+                untangle<LOG2N, HI, false>(x, post, lds, lane, xlo, xhi);
+            } else {
+#pragma unroll
+                for (int q = 0; q < P / 2; ++q) xlo[q] = xhi[q] = x[q];
+            }
 #pragma unroll
             for (int q = 0; q < P / 2; ++q) magbuf[lane + kWave * q] = cabs_rn(xlo[q]);
-        }
-        wave_sync_lds();
-        if (fb) {
-            for (int i = 0; i < a.n_fb; ++i) {
-                const int off = fb[2 * i], end = min(off + fb[2 * i + 1], F);
-                for (int k = off + lane; k < end; k += kWave) magbuf[k] = 0.f;
+            if constexpr (HI) {
+                float* mhi = magbuf + NC - lane;
+#pragma unroll
+                for (int q = 0; q < P / 2; ++q) mhi[-kWave * q] = cabs_rn(xhi[q]);
+                if (lane == 0) magbuf[NC / 2] = 2.0f * cabs_rn(x[P / 2]);
+            }
+            wave_sync_lds();
+            if constexpr (BANDS) {
+                if (fb) {
+                    for (int i = 0; i < a.n_fb; ++i) {
+                        const int off = fb[2 * i], end = min(off + fb[2 * i + 1], F);
+                        for (int k = off + lane; k < end; k += kWave) magbuf[k] = 0.f;
+                    }
+                    wave_sync_lds();
+                }
+            }
+            if constexpr (MELMODE == 0) {
+                float acc = 0.f;
+                if (!ABL(4)) {
+#pragma unroll
+                    for (int i = 0; i < kMelRegs / 4; ++i) {
+                        const float4 m4 = mag4[i];
+                        acc = fmaf(wreg[4 * i + 0], m4.x, acc);
+                        acc = fmaf(wreg[4 * i + 1], m4.y, acc);
+                        acc = fmaf(wreg[4 * i + 2], m4.z, acc);
+                        acc = fmaf(wreg[4 * i + 3], m4.w, acc);
+                    }
+                } else {
+                    acc = magbuf[lane];
+                }
+                if (lane < a.M) my_tile[fcur] = acc * scale;
+            } else {
+                for (int m = lane; m < a.M; m += kWave) {
+                    float acc = 0.f;
+                    if constexpr (MELMODE == 1) {
+                        const int lo = lotab[m];
+                        for (int i = 0; i < a.rows; ++i) acc = fmaf(wtab[i * a.M + m], magbuf[lo + i], acc);
+                    } else {
+                        const int lo = a.band_lo[m];
+                        for (int i = 0; i < a.rows; ++i) acc = fmaf(a.wband[i * a.M + m], magbuf[lo + i], acc);
+                    }
+                    tile_out[m * tile_stride + fcur] = acc * scale;
+                }
             }
             wave_sync_lds();
         }
-        for (int m = lane; m < a.M; m += kWave) {
-            const int lo = a.band_lo[m];
-            float acc = 0.f;
-            for (int i = 0; i < a.max_len; ++i) {
-                const float w = a.wband[i * a.M + m];
-                acc = fmaf(w, magbuf[min(lo + i, F - 1)], acc);
-            }
-            tile_out[m * tile_stride + f] = acc;
-        }
-        wave_sync_lds();
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // write the tile: for each m a contiguous run of nt*C floats
-    const int run = nt * a.C;
-    float mn = INFINITY, mx = -INFINITY;
-    for (int idx = threadIdx.x; idx < a.M * run; idx += blockDim.x) {
-        const int m = idx / run, r = idx - m * run;
-        const float v = tile_out[m * tile_stride + r];
-        a.out[(((size_t)b * a.M + m) * a.T + t0) * a.C + r] = v;
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+        // write the chunk: wave per mel row, a contiguous run of nt*C floats each
+        const int run = nt * a.C;
+        float mn = INFINITY, mx = -INFINITY;
+        for (int m = wv; m < a.M; m += kFusedWaves) {
+            float* dst = a.out + (((size_t)b * a.M + m) * a.T + t0) * a.C;
+            const float* srow = tile_out + m * tile_stride;
+            for (int r = lane; r < run; r += kWave) {
+                const float v = srow[r];
+                if (!ABL(16)) dst[r] = v;
+                mn = fminf(mn, v);
+                mx = fmaxf(mx, v);
+            }
+        }
+        block_minmax(mn, mx, red);  // ends with every thread past the tile reads
+        if (threadIdx.x == 0) {
+            a.partial[(size_t)chunk * 2 + 0] = mn;
+            a.partial[(size_t)chunk * 2 + 1] = mx;
+        }
+        __syncthreads();
     }
-    block_minmax(mn, mx, red);
-    if (threadIdx.x == 0) {
-        a.partial[((size_t)b * a.tiles_per_clip + tile) * 2 + 0] = mn;
-        a.partial[((size_t)b * a.tiles_per_clip + tile) * 2 + 1] = mx;
+    if (ABL(512) && threadIdx.x == 0 && a.dbg) {
+        if (blockIdx.x == 0) {
+            a.dbg[0] = __builtin_amdgcn_s_memtime() - stamp0;
+            a.dbg[1] = __builtin_amdgcn_s_memrealtime() - real0;
+        }
+        a.dbg[4 + 3 * blockIdx.x + 0] = real_entry;
+        a.dbg[4 + 3 * blockIdx.x + 1] = real0;
+        a.dbg[4 + 3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -324,7 +552,7 @@ __global__ __launch_bounds__(256) void k_wav_to_mel(const FusedArgs a) {
 struct StftArgs {
     const float* wav;
     float* spec;
-    FftTables tab;
+    const float* consts;
     int B, C, L, T, hop, tile_frames, tiles_per_clip;
 };
 
@@ -333,7 +561,7 @@ __global__ __launch_bounds__(256) void k_stft(const StftArgs a) {
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
     constexpr int F = NC + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int b = wg / a.tiles_per_clip, tile = wg - b * a.tiles_per_clip;
     const int t0 = tile * a.tile_frames;
@@ -341,32 +569,26 @@ __global__ __launch_bounds__(256) void k_stft(const StftArgs a) {
     const int C2 = 2 * a.C;
     const int row = a.tile_frames * C2 + 1;  // odd stride: conflict-free column writes
 
-    constexpr int kWaveBufBytes = lds_padded(NC) * 8;
-    float2* lds = reinterpret_cast<float2*>(smem + wv * kWaveBufBytes);
+    constexpr int kWaveBufBytes = (lds_padded(NC, FftCfg<LOG2N>::PMMAX) * 8 + 15) & ~15;
+    cf* lds = reinterpret_cast<cf*>(smem + wv * kWaveBufBytes);
     float* tile_out = reinterpret_cast<float*>(smem + 4 * kWaveBufBytes);  // [F][row]
 
-    float2 tw[NTW], post[P / 2], win[P];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) tw[i] = a.tab.tw[i * kWave + lane];
-#pragma unroll
-    for (int i = 0; i < P / 2; ++i) post[i] = a.tab.post[i * kWave + lane];
-#pragma unroll
-    for (int i = 0; i < P; ++i) win[i] = a.tab.win[i * kWave + lane];
+    cf tw[NTW], post[P / 2], win[P];
+    float wreg_unused[kMelRegs];
+    int lo_unused;
+    load_consts<LOG2N>(a.consts, lane, tw, post, win, wreg_unused, lo_unused);
 
     const int nwf = nt * a.C;
     for (int f = wv; f < nwf; f += 4) {
         const int tl = f / a.C, c = f - tl * a.C;
         const float* clip = a.wav + ((size_t)b * a.C + c) * a.L;
-        float2 x[P];
+        cf x[P];
         load_frame<LOG2N>(x, clip, a.L, (t0 + tl) * a.hop - N / 2, lane);
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            x[q].x *= win[q].x;
-            x[q].y *= win[q].y;
-        }
+        for (int q = 0; q < P; ++q) x[q] *= win[q];
         fft_frame<LOG2N>(x, tw, lds, lane);
-        float2 xlo[P / 2], xhi[P / 2];
-        untangle<LOG2N, true>(x, post, lds, lane, xlo, xhi);
+        cf xlo[P / 2], xhi[P / 2];
+        untangle<LOG2N, true, true>(x, post, lds, lane, xlo, xhi);
         const int col = tl * C2 + c;
 #pragma unroll
         for (int q = 0; q < P / 2; ++q) {
@@ -658,6 +880,15 @@ static int fft_ntw(int log2n) {
     }
 }
 static int fft_p(int log2n) { return (1 << log2n) / 2 / 64; }
+static size_t wave_buf_bytes(int log2n) {
+    const int NC = (1 << log2n) / 2;
+    switch (log2n) {
+        case 11: return (size_t)lds_padded(NC, FftCfg<11>::PMMAX) * 8;
+        case 10: return (size_t)lds_padded(NC, FftCfg<10>::PMMAX) * 8;
+        case 9: return (size_t)lds_padded(NC, FftCfg<9>::PMMAX) * 8;
+        default: return (size_t)lds_padded(NC, FftCfg<8>::PMMAX) * 8;
+    }
+}
 
 static void build_tables(int log2n, std::vector<float2>& tw, std::vector<float2>& post, std::vector<float2>& win) {
     const int N = 1 << log2n, NC = N / 2, P = fft_p(log2n);
@@ -706,19 +937,54 @@ static int upload(T** dst, const std::vector<T>& src) {
     return IRIS_OK;
 }
 
-static size_t fused_lds_bytes(const iris_plan* p, int tile_frames) {
-    const int NC = p->n_fft / 2;
-    return 4 * (size_t)lds_padded(NC) * 8 + ((size_t)p->n_mel * (tile_frames * p->channels + 1) + 16) * 4;
+static size_t fused_lds_bytes(const iris_plan* p, int chunk_frames) {
+    const size_t xbuf = (wave_buf_bytes(p->log2n) + 15) & ~(size_t)15;
+    size_t bytes = (size_t)kFusedWaves * ((size_t)p->n_fft * 4 + xbuf);
+    bytes += ((size_t)p->n_mel * (chunk_frames * p->channels + 1) + 32) * 4;
+    if (p->mel_mode == 1) bytes += ((size_t)p->rows * p->n_mel + p->n_mel) * 4;
+    return bytes;
+}
+
+typedef void (*fused_kernel_t)(const FusedArgs);
+
+template <int LOG2N, int MELMODE>
+static fused_kernel_t fused_kernel_hb(bool hi, bool bands) {
+    if (hi) return bands ? k_wav_to_mel<LOG2N, MELMODE, true, true> : k_wav_to_mel<LOG2N, MELMODE, true, false>;
+    return bands ? k_wav_to_mel<LOG2N, MELMODE, false, true> : k_wav_to_mel<LOG2N, MELMODE, false, false>;
+}
+template <int LOG2N>
+static fused_kernel_t fused_kernel_m(int mel_mode, bool hi, bool bands) {
+    if (mel_mode == 0) return fused_kernel_hb<LOG2N, 0>(hi, bands);
+    if (mel_mode == 1) return fused_kernel_hb<LOG2N, 1>(hi, bands);
+    return fused_kernel_hb<LOG2N, 2>(hi, bands);
+}
+static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands) {
+    switch (log2n) {
+        case 11: return fused_kernel_m<11>(mel_mode, hi, bands);
+        case 10: return fused_kernel_m<10>(mel_mode, hi, bands);
+        case 9: return fused_kernel_m<9>(mel_mode, hi, bands);
+        default: return fused_kernel_m<8>(mel_mode, hi, bands);
+    }
+}
+static const void* stft_kernel(int log2n) {
+    switch (log2n) {
+        case 11: return (const void*)k_stft<11>;
+        case 10: return (const void*)k_stft<10>;
+        case 9: return (const void*)k_stft<9>;
+        default: return (const void*)k_stft<8>;
+    }
 }
 
 // Dynamic LDS above the 64 KiB default must be opted into once per kernel.
-template <int LOG2N>
-static hipError_t allow_big_lds() {
+static hipError_t allow_big_lds(const iris_plan* p) {
     constexpr int kMaxLds = 160 * 1024;
-    hipError_t e = hipFuncSetAttribute((const void*)k_wav_to_mel<LOG2N>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_stft<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    hipError_t e;
+    for (int bands = 0; bands < 2; ++bands) {
+        e = hipFuncSetAttribute((const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands != 0),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+        if (e != hipSuccess) return e;
+    }
+    return hipFuncSetAttribute(stft_kernel(p->log2n), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
 }
 
 extern "C" int iris_abi_version(void) { return IRIS_ABI_VERSION; }
@@ -754,9 +1020,10 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->sample_rate = sample_rate;
     p->lower_hz = lower_hz;
     p->upper_hz = upper_hz;
-    p->d_tw = p->d_post = p->d_win = nullptr;
-    p->d_band_lo = p->d_band_len = nullptr;
+    p->d_consts = nullptr;
+    p->d_band_lo = p->d_band_len = p->d_fband_lo = nullptr;
     p->d_wband = p->d_mel = p->d_ws = nullptr;
+    p->d_dbg = nullptr;
     p->timing = false;
     p->ev_used = 0;
 
@@ -788,9 +1055,29 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
         p->max_band_len = std::max(p->max_band_len, len[m]);
         p->k_need = std::max(p->k_need, lo[m] + len[m]);
     }
-    std::vector<float> wband((size_t)std::max(p->max_band_len, 1) * n_mel, 0.f);
-    for (int m = 0; m < n_mel; ++m)
-        for (int i = 0; i < len[m]; ++i) wband[(size_t)i * n_mel + m] = p->mel[(size_t)(lo[m] + i) * n_mel + m];
+    // fused kernel tables: which half of the spectrum it must produce, and per band a
+    // window of `rows` bins [flo, flo + rows) inside the bins the kernel writes
+    const int NC = n_fft / 2;
+    p->need_hi = p->k_need > NC / 2 ? 1 : 0;
+    // bins the kernel writes to its magnitude buffer: [0, limit)
+    const int limit = p->need_hi ? ((n_bins + 3) & ~3) : NC / 2;
+    if (n_mel <= 64 && p->max_band_len + 3 <= kMelRegs && limit >= kMelRegs) {
+        p->mel_mode = 0;  // 16-byte aligned register window of kMelRegs bins per band
+        p->rows = kMelRegs;
+    } else {
+        p->rows = std::min(std::max(p->max_band_len, 1), limit);
+        p->mel_mode = ((size_t)p->rows * n_mel + n_mel) * 4 <= 32 * 1024 ? 1 : 2;
+    }
+    std::vector<int> flo(n_mel, 0);
+    std::vector<float> wband((size_t)p->rows * n_mel, 0.f);
+    for (int m = 0; m < n_mel; ++m) {
+        int first = p->mel_mode == 0 ? (lo[m] & ~3) : lo[m];
+        flo[m] = std::max(0, std::min(first, limit - p->rows));
+        for (int i = 0; i < p->rows; ++i) {
+            const int f = flo[m] + i;
+            wband[(size_t)i * n_mel + m] = f < n_bins ? 0.5f * p->mel[(size_t)f * n_mel + m] : 0.f;
+        }
+    }
 
     DeviceGuard guard(device);
     if (!guard.ok) {
@@ -799,32 +1086,57 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     }
     std::vector<float2> tw, post, win;
     build_tables(log2n, tw, post, win);
+    // pack the per-lane constant block (ConstLayout)
+    const int ntw = fft_ntw(log2n), P = fft_p(log2n);
+    const int off_post = 2 * ntw, off_win = off_post + P, off_wreg = off_win + 2 * P, off_lo = off_wreg + kMelRegs;
+    const int nv4 = (off_lo + 1 + 3) / 4;
+    std::vector<float> consts((size_t)nv4 * 64 * 4, 0.f);
+    auto put = [&](int lane, int idx, float v) { consts[((size_t)(idx / 4) * 64 + lane) * 4 + (idx % 4)] = v; };
+    for (int lane = 0; lane < 64; ++lane) {
+        for (int i = 0; i < ntw; ++i) {
+            put(lane, 2 * i, tw[(size_t)i * 64 + lane].x);
+            put(lane, 2 * i + 1, tw[(size_t)i * 64 + lane].y);
+        }
+        for (int i = 0; i < P / 2; ++i) {
+            put(lane, off_post + 2 * i, post[(size_t)i * 64 + lane].x);
+            put(lane, off_post + 2 * i + 1, post[(size_t)i * 64 + lane].y);
+        }
+        for (int i = 0; i < P; ++i) {
+            put(lane, off_win + 2 * i, win[(size_t)i * 64 + lane].x);
+            put(lane, off_win + 2 * i + 1, win[(size_t)i * 64 + lane].y);
+        }
+        if (p->mel_mode == 0 && lane < n_mel) {
+            for (int i = 0; i < p->rows; ++i) put(lane, off_wreg + i, wband[(size_t)i * n_mel + lane]);
+            float bits;
+            memcpy(&bits, &flo[lane], sizeof(float));
+            put(lane, off_lo, bits);
+        }
+    }
     int rc;
-    if ((rc = upload(&p->d_tw, tw)) || (rc = upload(&p->d_post, post)) || (rc = upload(&p->d_win, win)) ||
+    if ((rc = upload(&p->d_consts, consts)) ||
         (rc = upload(&p->d_band_lo, lo)) || (rc = upload(&p->d_band_len, len)) ||
-        (rc = upload(&p->d_wband, wband)) || (rc = upload(&p->d_mel, p->mel))) {
+        (rc = upload(&p->d_fband_lo, flo)) || (rc = upload(&p->d_wband, wband)) ||
+        (rc = upload(&p->d_mel, p->mel))) {
         iris_plan_destroy(p);
         return rc;
     }
 
     {
-        hipError_t e;
-        switch (log2n) {
-            case 11: e = allow_big_lds<11>(); break;
-            case 10: e = allow_big_lds<10>(); break;
-            case 9: e = allow_big_lds<9>(); break;
-            default: e = allow_big_lds<8>(); break;
-        }
+        hipError_t e = allow_big_lds(p);
         if (e != hipSuccess) {
             iris_plan_destroy(p);
             return fail((int)e, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
         }
     }
-    // tile size of the fused kernel: 16 frames unless LDS says otherwise
-    p->tile_frames = 16;
-    if (const char* e = getenv("IRIS_TILE_FRAMES")) p->tile_frames = std::max(1, atoi(e));
-    while (p->tile_frames > 1 && fused_lds_bytes(p, p->tile_frames) > 64 * 1024) p->tile_frames /= 2;
-    if (fused_lds_bytes(p, p->tile_frames) > 160 * 1024) {
+    {
+        int cu = 0;
+        hipError_t e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device);
+        if (e != hipSuccess || cu <= 0) cu = 256;
+        p->num_cu = cu;
+    }
+    p->chunk_target = 0;
+    if (const char* e = getenv("IRIS_CHUNK_FRAMES")) p->chunk_target = std::max(0, atoi(e));
+    if (fused_lds_bytes(p, 1) > 160 * 1024) {
         iris_plan_destroy(p);
         return fail(IRIS_E_UNSUPPORTED, "n_mel=%d x channels=%d does not fit the LDS out tile", n_mel, channels);
     }
@@ -834,6 +1146,8 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     const int t_max = 1 + max_len / hop;
     const size_t wav_row = (size_t)channels * max_len;
     p->ws_floats = 2 * (size_t)max_batch * t_max + (size_t)max_batch * ((wav_row + kChunk - 1) / kChunk) + 64;
+    (void)hipMalloc((void**)&p->d_dbg, (4 + 3 * 4096) * sizeof(unsigned long long));
+    if (p->d_dbg) (void)hipMemset(p->d_dbg, 0, (4 + 3 * 4096) * sizeof(unsigned long long));
     hipError_t e = hipMalloc((void**)&p->d_ws, p->ws_floats * sizeof(float));
     if (e != hipSuccess) {
         iris_plan_destroy(p);
@@ -846,12 +1160,36 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
 extern "C" int iris_plan_destroy(iris_plan* p) {
     if (!p) return IRIS_OK;
     DeviceGuard guard(p->device);
+    if (p->d_dbg && getenv("IRIS_ABLATE") && (atoi(getenv("IRIS_ABLATE")) & 512)) {
+        std::vector<unsigned long long> h(4 + 3 * 4096, 0);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h.data(), p->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[iris dbg] workgroup 0: %llu shader cycles, %llu x 10 ns -> %.3f GHz\n", h[0], h[1],
+                h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0.0);
+        unsigned long long e0 = ~0ull, e1 = 0, l0 = ~0ull, l1 = 0, x0 = ~0ull, x1 = 0;
+        double pro = 0, loop = 0;
+        int n = 0;
+        for (int i = 0; i < 4096; ++i) {
+            const unsigned long long* r = &h[4 + 3 * i];
+            if (!r[0]) continue;
+            ++n;
+            e0 = std::min(e0, r[0]); e1 = std::max(e1, r[0]);
+            l0 = std::min(l0, r[1]); l1 = std::max(l1, r[1]);
+            x0 = std::min(x0, r[2]); x1 = std::max(x1, r[2]);
+            pro += (double)(r[1] - r[0]); loop += (double)(r[2] - r[1]);
+        }
+        if (n)
+            fprintf(stderr, "[iris dbg] %d workgroups (last launch): entry spread %.2f us, loop-start spread %.2f us, "
+                    "exit spread %.2f us, first entry -> last exit %.2f us, mean prologue %.2f us, mean loop %.2f us\n",
+                    n, (e1 - e0) * 0.01, (l1 - l0) * 0.01, (x1 - x0) * 0.01, (x1 - e0) * 0.01, pro / n * 0.01,
+                    loop / n * 0.01);
+    }
+    (void)hipFree(p->d_dbg);
     for (hipEvent_t ev : p->ev) (void)hipEventDestroy(ev);
-    (void)hipFree(p->d_tw);
-    (void)hipFree(p->d_post);
-    (void)hipFree(p->d_win);
+    (void)hipFree(p->d_consts);
     (void)hipFree(p->d_band_lo);
     (void)hipFree(p->d_band_len);
+    (void)hipFree(p->d_fband_lo);
     (void)hipFree(p->d_wband);
     (void)hipFree(p->d_mel);
     (void)hipFree(p->d_ws);
@@ -924,7 +1262,7 @@ extern "C" int iris_stft(iris_plan* p, const float* wav, float* spec, int batch,
     StftArgs a;
     a.wav = wav;
     a.spec = spec;
-    a.tab = FftTables{p->d_tw, p->d_post, p->d_win};
+    a.consts = p->d_consts;
     a.B = batch;
     a.C = p->channels;
     a.L = len;
@@ -932,7 +1270,7 @@ extern "C" int iris_stft(iris_plan* p, const float* wav, float* spec, int batch,
     a.hop = p->hop;
     const int NC = p->n_fft / 2, F = NC + 1;
     int tf = 16;
-    auto lds_of = [&](int t) { return 4 * (size_t)lds_padded(NC) * 8 + (size_t)F * (t * 2 * p->channels + 1) * 4; };
+    auto lds_of = [&](int t) { return 4 * ((wave_buf_bytes(p->log2n) + 15) & ~(size_t)15) + (size_t)F * (t * 2 * p->channels + 1) * 4; };
     while (tf > 1 && lds_of(tf) > 64 * 1024) tf /= 2;
     if (lds_of(tf) > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_stft: channels=%d too large", p->channels);
     a.tile_frames = tf;
@@ -1021,10 +1359,18 @@ extern "C" int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minm
     return IRIS_OK;
 }
 
-template <int LOG2N>
-static hipError_t launch_fused(const FusedArgs& a, int grid, size_t lds, hipStream_t s) {
-    k_wav_to_mel<LOG2N><<<grid, 256, lds, s>>>(a);
-    return hipGetLastError();
+// Chunk geometry of the fused kernel: fused_occ() workgroups per CU, every workgroup one
+// chunk when the problem is large enough, chunks never span clips.
+static void fused_geometry(const iris_plan* p, int batch, int T, int* chunk_frames, int* chunks_per_clip) {
+    const int slots = p->num_cu * fused_occ(p->log2n);
+    const long total = (long)batch * T;
+    int cap = 128;  // frames; keeps the LDS out tile <= 48 KiB
+    while (cap > 1 && (size_t)p->n_mel * (cap * p->channels + 1) * 4 > 48 * 1024) cap /= 2;
+    int target = p->chunk_target > 0 ? p->chunk_target : (int)((total + slots - 1) / slots);
+    target = std::max(std::min(target, cap), std::min(8, cap));
+    const int cpc = (T + target - 1) / target;
+    *chunks_per_clip = cpc;
+    *chunk_frames = (T + cpc - 1) / cpc;
 }
 
 extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, int batch, int len, int flags,
@@ -1040,11 +1386,10 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     FusedArgs a;
     a.wav = wav;
     a.out = out;
-    a.tab = FftTables{p->d_tw, p->d_post, p->d_win};
-    a.band_lo = p->d_band_lo;
+    a.consts = p->d_consts;
+    a.band_lo = p->d_fband_lo;
     a.wband = p->d_wband;
-    a.max_len = p->max_band_len;
-    a.k_need = p->k_need;
+    a.rows = p->rows;
     a.t_bands = n_tb ? t_bands : nullptr;
     a.n_tb = n_tb;
     a.f_bands = n_fb ? f_bands : nullptr;
@@ -1055,9 +1400,12 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     a.T = 1 + len / p->hop;
     a.hop = p->hop;
     a.M = p->n_mel;
-    a.tile_frames = p->tile_frames;
-    a.tiles_per_clip = (a.T + a.tile_frames - 1) / a.tile_frames;
-    const size_t n_partial = 2 * (size_t)batch * a.tiles_per_clip;
+    a.ablate = 0;
+    if (const char* e = getenv("IRIS_ABLATE")) a.ablate = atoi(e);
+    a.dbg = p->d_dbg;
+    fused_geometry(p, batch, a.T, &a.chunk_frames, &a.chunks_per_clip);
+    a.n_chunks = batch * a.chunks_per_clip;
+    const size_t n_partial = 2 * (size_t)a.n_chunks;
     a.partial = p->d_ws;
     a.sumsq = nullptr;
     a.n_sq = 0;
@@ -1071,8 +1419,9 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         a.sumsq = sq;
     }
     if (n_partial > p->ws_floats) return fail(IRIS_E_CAPACITY, "iris_wav_to_logmel: workspace too small");
-    const int grid = batch * a.tiles_per_clip;
-    const size_t lds = fused_lds_bytes(p, a.tile_frames);
+    const int grid = std::min(a.n_chunks, p->num_cu * fused_occ(p->log2n));
+    const size_t lds = fused_lds_bytes(p, a.chunk_frames);
+    if (lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_wav_to_logmel: LDS tile too large (%zu B)", lds);
 
     const bool timed = p->timing && p->ev_used < kMaxTimedLaunches;
     if (timed) {
@@ -1083,13 +1432,9 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         }
         HIP_TRY(hipEventRecord(p->ev[2 * p->ev_used], s));
     }
-    hipError_t e;
-    switch (p->log2n) {
-        case 11: e = launch_fused<11>(a, grid, lds, s); break;
-        case 10: e = launch_fused<10>(a, grid, lds, s); break;
-        case 9: e = launch_fused<9>(a, grid, lds, s); break;
-        default: e = launch_fused<8>(a, grid, lds, s); break;
-    }
+    const bool bands = (a.t_bands != nullptr) || (a.f_bands != nullptr);
+    fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands)<<<grid, 64 * kFusedWaves, lds, s>>>(a);
+    hipError_t e = hipGetLastError();
     HIP_TRY(e);
     if (timed) {
         HIP_TRY(hipEventRecord(p->ev[2 * p->ev_used + 1], s));
@@ -1099,7 +1444,7 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     if (do_minmax || do_log) {
         const size_t row_len = (size_t)p->n_mel * a.T * p->channels;
         const unsigned n_chunks = (unsigned)((row_len + kChunk - 1) / kChunk);
-        k_minmax_log_apply<<<dim3(n_chunks, batch), 256, 0, s>>>(out, p->d_ws, a.tiles_per_clip, row_len, do_minmax,
+        k_minmax_log_apply<<<dim3(n_chunks, batch), 256, 0, s>>>(out, p->d_ws, a.chunks_per_clip, row_len, do_minmax,
                                                                do_log, 1e-8f, 1e-8f);
         HIP_TRY(hipGetLastError());
     }
