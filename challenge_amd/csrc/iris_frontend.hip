@@ -51,6 +51,7 @@ static int fail(int code, const char* fmt, ...) {
 struct iris_plan {
     int device;
     int n_fft, log2n, hop, n_mel, n_bins, channels, max_batch, max_len;
+    bool mel_only;  // n_fft == 0: only iris_magmel is available
     float sample_rate, lower_hz, upper_hz;
     // host copies
     std::vector<float> mel;  // [F][M]
@@ -995,21 +996,31 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
                                 int max_len, const float* mel_host) {
     if (!out) return fail(IRIS_E_INVALID, "iris_plan_create: out is NULL");
     *out = nullptr;
-    const int log2n = ilog2_exact(n_fft);
-    if (log2n < 8 || log2n > 11)
-        return fail(IRIS_E_UNSUPPORTED, "n_fft=%d: must be a power of two in [256, 2048]", n_fft);
-    if (hop <= 0) return fail(IRIS_E_INVALID, "hop=%d must be positive", hop);
+    // n_fft == 0: mel-only plan (iris_magmel on any n_bins >= 2; no FFT entry points)
+    const bool mel_only = (n_fft == 0);
+    int log2n = mel_only ? 8 : ilog2_exact(n_fft);
+    if (!mel_only && (log2n < 8 || log2n > 11))
+        return fail(IRIS_E_UNSUPPORTED, "n_fft=%d: must be a power of two in [256, 2048] (or 0 for a mel-only plan)",
+                    n_fft);
     if (n_mel <= 0) return fail(IRIS_E_INVALID, "n_mel=%d must be positive", n_mel);
-    if (n_bins != n_fft / 2 + 1)
-        return fail(IRIS_E_INVALID, "n_bins=%d must equal n_fft/2+1=%d", n_bins, n_fft / 2 + 1);
     if (channels <= 0 || max_batch <= 0) return fail(IRIS_E_INVALID, "channels and max_batch must be positive");
-    if (max_len <= n_fft / 2)
-        return fail(IRIS_E_INVALID, "max_len=%d must exceed n_fft/2 (reflect padding)", max_len);
+    if (mel_only) {
+        if (n_bins < 2) return fail(IRIS_E_INVALID, "n_bins=%d must be >= 2", n_bins);
+        hop = 1;
+        max_len = std::max(max_len, 1);
+    } else {
+        if (hop <= 0) return fail(IRIS_E_INVALID, "hop=%d must be positive", hop);
+        if (n_bins != n_fft / 2 + 1)
+            return fail(IRIS_E_INVALID, "n_bins=%d must equal n_fft/2+1=%d", n_bins, n_fft / 2 + 1);
+        if (max_len <= n_fft / 2)
+            return fail(IRIS_E_INVALID, "max_len=%d must exceed n_fft/2 (reflect padding)", max_len);
+    }
 
     iris_plan* p = new (std::nothrow) iris_plan();
     if (!p) return fail(IRIS_E_NOMEM, "out of host memory");
     p->device = device;
     p->n_fft = n_fft;
+    p->mel_only = mel_only;
     p->log2n = log2n;
     p->hop = hop;
     p->n_mel = n_mel;
@@ -1057,7 +1068,7 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     }
     // fused kernel tables: which half of the spectrum it must produce, and per band a
     // window of `rows` bins [flo, flo + rows) inside the bins the kernel writes
-    const int NC = n_fft / 2;
+    const int NC = mel_only ? 2 * (n_bins - 1) / 2 : n_fft / 2;
     p->need_hi = p->k_need > NC / 2 ? 1 : 0;
     // bins the kernel writes to its magnitude buffer: [0, limit)
     const int limit = p->need_hi ? ((n_bins + 3) & ~3) : NC / 2;
@@ -1121,7 +1132,7 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
         return rc;
     }
 
-    {
+    if (!mel_only) {
         hipError_t e = allow_big_lds(p);
         if (e != hipSuccess) {
             iris_plan_destroy(p);
@@ -1136,7 +1147,7 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     }
     p->chunk_target = 0;
     if (const char* e = getenv("IRIS_CHUNK_FRAMES")) p->chunk_target = std::max(0, atoi(e));
-    if (fused_lds_bytes(p, 1) > 160 * 1024) {
+    if (!mel_only && fused_lds_bytes(p, 1) > 160 * 1024) {
         iris_plan_destroy(p);
         return fail(IRIS_E_UNSUPPORTED, "n_mel=%d x channels=%d does not fit the LDS out tile", n_mel, channels);
     }
@@ -1210,6 +1221,7 @@ extern "C" int iris_plan_num_frames(const iris_plan* p, int len) {
 
 static int check_wav_args(const iris_plan* p, const void* a, const void* b, int batch, int len, const char* who) {
     if (!p || !a || !b) return fail(IRIS_E_INVALID, "%s: NULL argument", who);
+    if (p->mel_only) return fail(IRIS_E_UNSUPPORTED, "%s: plan was created mel-only (n_fft = 0)", who);
     if (batch <= 0 || len <= 0) return fail(IRIS_E_INVALID, "%s: batch=%d len=%d must be positive", who, batch, len);
     if (batch > p->max_batch || len > p->max_len)
         return fail(IRIS_E_CAPACITY, "%s: batch=%d len=%d exceed plan capacity (%d, %d)", who, batch, len,

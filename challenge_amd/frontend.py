@@ -99,6 +99,30 @@ class FrontendPlan:
         self._handle = handle
         self._lock = threading.Lock()
 
+    @classmethod
+    def mel_only(cls, n_mel: int, n_bins: int, channels: int, max_batch: int, device,
+                 mel_matrix: np.ndarray) -> "FrontendPlan":
+        """Plan for magphase_to_mel on spectra of an arbitrary bin count (no FFT ops)."""
+        self = cls.__new__(cls)
+        self._handle = None
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n_fft, self.hop, self.n_mel, self.n_bins = 0, 1, int(n_mel), int(n_bins)
+        self.sample_rate, self.channels = 0.0, int(channels)
+        self.max_batch, self.max_len = int(max_batch), 1
+        mel_matrix = np.ascontiguousarray(mel_matrix, np.float32)
+        if mel_matrix.shape != (self.n_bins, self.n_mel):
+            raise ValueError(f"mel_matrix must be [{self.n_bins}, {self.n_mel}]")
+        handle = C.c_void_p()
+        rc = N.lib().iris_plan_create(C.byref(handle), self.device.index, 0, 1, self.n_mel, self.n_bins, 1.0, 0.0,
+                                      0.5, self.channels, self.max_batch, 1,
+                                      mel_matrix.ctypes.data_as(C.POINTER(C.c_float)))
+        N.check(rc, "iris_plan_create")
+        self._handle = handle
+        self._lock = threading.Lock()
+        return self
+
     def close(self) -> None:
         if self._handle is not None:
             N.lib().iris_plan_destroy(self._handle)

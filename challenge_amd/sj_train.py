@@ -1,0 +1,562 @@
+"""Drop-in counterpart of the reference's sj_train.py for the VAD CNN/CRNN path
+(sj_train.py:20-255, :402-529): same flags, `make_dataset`, `custom_scheduler`,
+`adaptive_clip_grad`, `CustomModel.train_step`, `define_keras_model`, `get_model`,
+`main`.  The model is a torch nn.Module on PyTorch-ROCm (MIOpen / hipBLASLt -- not
+hand-written, per the north star); the feature frontend feeding it is the HIP library.
+Data parallelism (absent in the reference) is one process per GPU with
+torch.distributed over RCCL: DistributedDataParallel all-reduces the gradients in
+buckets overlapped with backward; AGC and clipvalue then act on the averaged gradients,
+identically on every rank.
+
+Out of scope here: model_type 'eff' / 'se' branches
+(sj_train.py:258-401), metrics/er_score (metrics.py stays untouched)."""
+from __future__ import annotations
+
+import argparse
+import csv
+import math
+import os
+import time
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import data_utils as _du
+from . import frontend as _fe
+from .data_utils import (augment, label_downsample, log_on_mel, minmax, mono_chan, multiply_label,  # noqa: F401
+                         random_merge_aug, stereo_mono, stft_filter, to_frame_labels)
+from .dataset import AUTOTUNE, Dataset
+from .pipeline import make_pipeline
+from .transforms import complex_to_magphase, magphase_to_mel
+from .utils import label_downsample_model, load_data, sigmoid_focal_crossentropy, unitwise_norm
+
+
+class ARGS:
+    """Same flags and defaults as sj_train.py:20-71, plus the knobs the reference has no
+    equivalent for (synthetic data, device, distributed launch)."""
+
+    def __init__(self) -> None:
+        self.args = argparse.ArgumentParser()
+        a = self.args.add_argument
+        a('--name', type=str, default='')
+        a('--gpus', type=str, default='-1')
+        a('--model', type=int, default=0)
+        a('--model_type', type=str, default='vad', choices=['vad', 'eff', 'se'])
+        a('--v', type=int, default=1)
+        a('--pretrain', type=bool, default=False)
+        a('--n_layers', type=int, default=0)
+        a('--n_dim', type=int, default=256)
+        a('--n_chan', type=int, default=2)
+        a('--n_classes', type=int, default=3)
+        a('--patience', type=int, default=10)
+        # DATA
+        a('--mse_multiplier', type=int, default=1)
+        a('--datapath', type=str, default='/root/datasets/Interspeech2020/generate_wavs/codes')
+        a('--background_sounds', type=str, default='drone_normed_complex_v4.pickle')
+        a('--voices', type=str, default='voice_normed_complex_v3.pickle')
+        a('--labels', type=str, default='voice_labels_mfc_v3.npy')
+        a('--noises', type=str, default='noises_specs_v2.pickle')
+        a('--test_background_sounds', type=str, default='test_drone_normed_complex_v2.pickle')
+        a('--test_voices', type=str, default='test_voice_normed_complex.pickle')
+        a('--test_labels', type=str, default='test_voice_labels_mfc.npy')
+        a('--n_mels', type=int, default=80)
+        # TRAINING
+        a('--optimizer', type=str, default='adam', choices=['adam', 'sgd', 'rmsprop', 'adabelief'])
+        a('--lr', type=float, default=1e-3)
+        a('--end_lr', type=float, default=1e-4)
+        a('--lr_power', type=float, default=0.5)
+        a('--lr_div', type=float, default=2)
+        a('--clipvalue', type=float, default=0.01)
+        a('--epochs', type=int, default=300)
+        a('--batch_size', type=int, default=12)
+        a('--n_frame', type=int, default=512)
+        a('--steps_per_epoch', type=int, default=100)
+        a('--l1', type=float, default=0)
+        a('--l2', type=float, default=1e-6)
+        a('--loss', type=str, default='BCE')
+        # AUGMENTATION
+        a('--snr', type=float, default=-20)
+        a('--max_voices', type=int, default=7)
+        a('--max_noises', type=int, default=2)
+        # not in the reference
+        a('--synthetic', action='store_true', help='synthetic sources instead of the pickled datasets')
+        a('--online_stft', action='store_true',
+          help='generate waveforms and run the fused HIP frontend (STFT on line) instead of mixing spectra')
+        a('--no_clipvalue_after_agc', action='store_true',
+          help="skip Adam's element-wise clipvalue (TF < 2.4 behaviour of the custom train_step)")
+        a('--validation_steps', type=int, default=16)
+
+    def get(self, argv=None):
+        return self.args.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------
+# dataset assembly                                            sj_train.py:74-130
+# ---------------------------------------------------------------------------
+def complex_to_mel(n_mels: int, num_spectrogram_bins: int = 257, sample_rate: float = 16000, **kwargs):
+    """complex_to_magphase + magphase_to_mel as ONE kernel (sj_train.py:119-120 maps them
+    one after the other; the phase computed by the first is discarded by the second)."""
+    to_mel = magphase_to_mel(n_mels, num_spectrogram_bins, sample_rate, **kwargs)
+    n_fft = 2 * (num_spectrogram_bins - 1)
+    plans = {}
+
+    def _complex_to_mel(x, y=None):
+        if not x.is_cuda or n_fft not in (256, 512, 1024, 2048):
+            out = to_mel(complex_to_magphase(x))
+        else:
+            chan = x.shape[-1] // 2
+            key = (x.device.index, chan)
+            plan = plans.get(key)
+            if plan is None or plan.max_batch < x.shape[0]:
+                plan = _fe.FrontendPlan(n_fft, None, n_mels, sample_rate, chan, max(int(x.shape[0]), 1), n_fft,
+                                        x.device, mel_matrix=to_mel.mel_matrix)
+                plans[key] = plan
+            out = plan.magmel(x.float(), is_magphase=False)
+        return out if y is None else (out, y)
+    return _complex_to_mel
+
+
+def synthetic_sources(n_chan: int = 2, n_classes: int = 3, freq: int = 257, n_bg: int = 8, n_voice: int = 24,
+                      n_noise: int = 12, seed: int = 0):
+    """Random stand-ins for the pickled datasets of sj_train.py:79-89: lists of
+    [freq, t_i, 2*chan] float32 spectra and integer class labels."""
+    rng = np.random.default_rng(seed)
+    backgrounds = [rng.standard_normal((freq, int(rng.integers(300, 900)), 2 * n_chan)).astype(np.float32) * 0.1
+                   for _ in range(n_bg)]
+    voices = []
+    for _ in range(n_voice):
+        t = int(rng.integers(40, 200))
+        v = np.abs(rng.standard_normal((freq, t, 2 * n_chan))).astype(np.float32)
+        v[:, int(t * 0.8):] = 0  # trailing silence, as padded voices have
+        voices.append(v)
+    labels = rng.integers(0, n_classes, size=n_voice)
+    noises = [rng.standard_normal((freq, int(rng.integers(20, 120)), 2 * n_chan)).astype(np.float32) * 0.3
+              for _ in range(n_noise)]
+    return backgrounds, voices, labels, noises
+
+
+def make_dataset(config, training=True, n_classes=3, sources=None):
+    """Stage order of sj_train.py:74-130.  `sources` = (backgrounds, voices, labels, noises)
+    overrides the pickle files (used with --synthetic and by the tests)."""
+    if sources is None and getattr(config, 'synthetic', False):
+        sources = synthetic_sources(2, n_classes, seed=0 if training else 1)
+    if sources is None:
+        if not os.path.exists(config.datapath):
+            config.datapath = ''
+        if training:
+            backgrounds = load_data(os.path.join(config.datapath, config.background_sounds))
+            voices = load_data(os.path.join(config.datapath, config.voices))
+            labels = load_data(os.path.join(config.datapath, config.labels))
+        else:
+            backgrounds = load_data(os.path.join(config.datapath, config.test_background_sounds))
+            voices = load_data(os.path.join(config.datapath, config.test_voices))
+            labels = load_data(os.path.join(config.datapath, config.test_labels))
+        if labels.max() - 1 != config.n_classes:
+            labels //= 10
+        noises = load_data(os.path.join(config.datapath, config.noises))
+    else:
+        backgrounds, voices, labels, noises = sources
+    labels = np.eye(n_classes, dtype='float32')[np.asarray(labels)]  # to one-hot vectors
+
+    pipeline = make_pipeline(backgrounds, voices, labels, noises, n_frame=config.n_frame,
+                             max_voices=config.max_voices, max_noises=config.max_noises, n_classes=n_classes,
+                             snr=config.snr, min_ratio=1,
+                             seperate_noise_voice=config.model_type == 'se' and config.v == 9)
+    if config.model_type == 'se' and config.v == 9:
+        raise NotImplementedError("model_type 'se' is outside the accelerated path (SURVEY.md section 2)")
+    pipeline = pipeline.map(to_frame_labels)
+    if training:
+        pipeline = pipeline.map(augment)
+    if config.n_chan == 1:
+        pipeline = pipeline.map(mono_chan)
+    elif config.n_chan == 3:
+        pipeline = pipeline.map(stereo_mono)
+    elif config.n_chan > 3:
+        pipeline = pipeline.map(random_merge_aug(config.n_chan))
+    if 'filter' in config.name:
+        pipeline = pipeline.map(stft_filter(int(round(200 / (16000 / 256)))))
+    pipeline = pipeline.batch(config.batch_size, drop_remainder=False)
+    n_bins = int(np.asarray(backgrounds[0]).shape[0])
+    pipeline = pipeline.map(complex_to_mel(config.n_mels, n_bins))  # :119-120 fused
+    if 'nominmax' not in config.name:
+        pipeline = pipeline.map(_du.minmax_log_on_mel)  # :121-123 fused
+    else:
+        pipeline = pipeline.map(log_on_mel)
+    if config.v in label_downsample_model:
+        pipeline = pipeline.map(label_downsample(32))
+    elif config.v == 5:
+        pipeline = pipeline.map(label_downsample(config.n_frame // (config.n_frame * 256 // 16000)))
+    if config.loss.upper() in ('MSE', 'MAE'):
+        pipeline = pipeline.map(multiply_label(config.mse_multiplier))
+    return pipeline.prefetch(AUTOTUNE)
+
+
+class WaveFrontend:
+    """MI355X-native on-line variant of the chain: waveforms [B, C, L] on the device ->
+    SpecAugment bands drawn per sample -> fused HIP kernel (STFT, magnitude, masks, mel,
+    min-max, log) -> [B, M, T, C].  Equivalent to load_wav + augment + complex_to_magphase
+    + magphase_to_mel + minmax + log_on_mel without materialising the spectrum."""
+
+    def __init__(self, n_fft=1024, hop=256, n_mels=64, sample_rate=16000, n_chan=1, batch=64, length=130816,
+                 device=None, training=True, filter_bins: int = 0, do_minmax: bool = True):
+        self.plan = _fe.FrontendPlan(n_fft, hop, n_mels, sample_rate, n_chan, batch, length, device)
+        self.training, self.filter_bins, self.do_minmax = training, filter_bins, do_minmax
+        self.rng = np.random.default_rng(0)
+
+    def draw_bands(self, batch: int, n_time: int):
+        tb = np.stack([_du.augment_draw(n_time, self.plan.n_bins, self.rng)[0] for _ in range(batch)])
+        fb = np.stack([_du.augment_draw(n_time, self.plan.n_bins, self.rng)[1] for _ in range(batch)])
+        return tb, fb
+
+    def __call__(self, wav: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        b, n_time = wav.shape[0], self.plan.num_frames(wav.shape[2])
+        tb = fb = None
+        if self.training:
+            tb, fb = self.draw_bands(b, n_time)
+        if self.filter_bins:
+            flt = np.tile(np.array([[[1, self.filter_bins]]], np.int32), (b, 1, 1))
+            fb = flt if fb is None else np.concatenate([fb, flt], axis=1)
+        return self.plan.wav_to_logmel(wav, minmax=self.do_minmax, log=True, t_bands=tb, f_bands=fb, out=out)
+
+
+# ---------------------------------------------------------------------------
+# schedule, AGC                                             sj_train.py:133-155
+# ---------------------------------------------------------------------------
+def custom_scheduler(d_model, warmup_steps=4000, lr_div=2):
+    """lr(step) = d_model^-0.5 * min((step+1)^-0.5, (step+1) * warmup^-1.5) / lr_div, with
+    `step` the EPOCH index as Keras' LearningRateScheduler passes it (sj_train.py:501-503)."""
+    d_model = float(d_model)
+
+    def _scheduler(step):
+        step = float(step + 1)
+        arg1 = step ** -0.5
+        arg2 = step * (warmup_steps ** -1.5)
+        return d_model ** -0.5 * min(arg1, arg2) / lr_div
+    return _scheduler
+
+
+def adaptive_clip_grad(parameters, gradients, clip_factor=0.01, eps=1e-3):
+    """Adaptive gradient clipping (sj_train.py:145-155): per output unit, rescale g to
+    max_norm = max(||p||, eps) * clip_factor where ||g|| >= max_norm."""
+    new_grads = []
+    for params, grads in zip(parameters, gradients):
+        if grads is None:
+            new_grads.append(None)
+            continue
+        p_norm = unitwise_norm(params.detach())
+        max_norm = torch.clamp(p_norm, min=eps) * clip_factor
+        grad_norm = unitwise_norm(grads)
+        clipped = grads * (max_norm / torch.clamp(grad_norm, min=1e-6))
+        new_grads.append(torch.where(grad_norm < max_norm, grads, clipped))
+    return new_grads
+
+
+# ---------------------------------------------------------------------------
+# model                                                     sj_train.py:191-255
+# ---------------------------------------------------------------------------
+class _ConvBNReLU(nn.Sequential):
+    def __init__(self, cin, cout, k=3, bn=True):
+        layers = [nn.Conv2d(cin, cout, k, padding=k // 2)]
+        if bn:
+            layers.append(nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01))  # Keras BN defaults
+        layers.append(nn.ReLU(inplace=True))
+        super().__init__(*layers)
+
+
+class ConvMPBlock(nn.Module):
+    """num_convs x [Conv3x3 'same' (+BN) + ReLU] + MaxPool 2x2 'same' (sj_train.py:191-201)."""
+
+    def __init__(self, cin, num_convs=2, fsize=32, kernel_size=3, BN=False, MP=True):
+        super().__init__()
+        self.convs = nn.Sequential(*[_ConvBNReLU(cin if i == 0 else fsize, fsize, kernel_size, BN)
+                                     for i in range(num_convs)])
+        self.pool = nn.MaxPool2d(2, 2, ceil_mode=True) if MP else nn.Identity()
+
+    def forward(self, x):
+        return self.pool(self.convs(x))
+
+
+class FullyConnectedLayer(nn.Module):
+    """Dense (+BN over the feature axis) + activation on [B, T, units] (sj_train.py:204-211)."""
+
+    def __init__(self, cin, nodes=512, act='relu', BN=False):
+        super().__init__()
+        self.fc = nn.Linear(cin, nodes)
+        self.bn = nn.BatchNorm1d(nodes, eps=1e-3, momentum=0.01) if BN else None
+        self.act = {'relu': nn.ReLU(inplace=True), 'sigmoid': nn.Sigmoid()}[act]
+
+    def forward(self, x):
+        x = self.fc(x)
+        if self.bn is not None:
+            x = self.bn(x.transpose(1, 2)).transpose(1, 2)
+        return self.act(x)
+
+
+class _Bottleneck(nn.Module):  # v == 7 residual block (sj_train.py:230-241)
+    def __init__(self, c):
+        super().__init__()
+        self.body = nn.Sequential(_ConvBNReLU(c, c // 4, 1), _ConvBNReLU(c // 4, c // 4, 3), _ConvBNReLU(c // 4, c, 1))
+
+    def forward(self, x):
+        return self.body(x) + x
+
+
+class _SmoothPool(nn.Module):  # v == 6 (sj_train.py:225-229): avg (1,k) then max (1,2k), stride 1, 'same'
+    def __init__(self, k):
+        super().__init__()
+        self.k = max(int(k), 1)
+
+    @staticmethod
+    def _same(x, k, mode):
+        if k <= 1:
+            return x
+        left = (k - 1) // 2
+        right = k - 1 - left
+        F = torch.nn.functional
+        if mode == 'max':
+            return F.max_pool2d(F.pad(x, (left, right), value=float('-inf')), (1, k), 1)
+        ones = torch.ones((1, 1, 1, x.shape[-1]), dtype=x.dtype, device=x.device)
+        cnt = F.avg_pool2d(F.pad(ones, (left, right)), (1, k), 1)  # valid fraction, as TF 'SAME' averages
+        return F.avg_pool2d(F.pad(x, (left, right)), (1, k), 1) / cnt
+
+    def forward(self, x):
+        return self._same(self._same(x, self.k, 'avg'), 2 * self.k, 'max')
+
+
+class CustomModel(nn.Module):
+    """The CRNN of define_keras_model plus the Keras-style training surface the reference
+    uses: compile(), train_step(data) (sj_train.py:158-188), test_step, fit."""
+
+    def __init__(self, config):
+        super().__init__()
+        fsize = 48 if (config.model_type == 'vad' and config.v == 8) else 32
+        self.config_v, self.model_type = config.v, config.model_type
+        blocks = [ConvMPBlock(config.n_chan, 2, fsize, BN=True)]
+        cin, width = fsize, config.n_frame // 2
+        for i in range(1, 5):
+            if config.model_type == 'vad' and config.v == 6:
+                k = int(round(0.5 / (256 * config.n_frame / 16000 / width)))
+                blocks.append(_SmoothPool(k))
+            if config.model_type == 'vad' and config.v == 7:
+                blocks.append(_Bottleneck(cin))
+            blocks.append(ConvMPBlock(cin, 3, fsize * 2 ** i, BN=True))
+            cin, width = fsize * 2 ** i, -(-width // 2)
+        self.features = nn.Sequential(*blocks)
+        m_out = config.n_mels
+        for _ in range(5):
+            m_out = -(-m_out // 2)
+        v9 = config.model_type == 'vad' and config.v == 9
+        self.td = nn.Linear(m_out * cin, 1024)
+        fcs, d = [], 1024
+        if v9:
+            fcs.append(FullyConnectedLayer(d, 512, BN=True)); d = 512
+        fcs.append(FullyConnectedLayer(d, 256, BN=True))
+        fcs.append(FullyConnectedLayer(256, 128, BN=True))
+        self.fc_pre = nn.Sequential(*fcs)
+        self.lstm = nn.LSTM(128, 128, batch_first=True, bidirectional=True) if v9 else None
+        self.fc_post = FullyConnectedLayer(256 if v9 else 128, 64, BN=True)
+        self.head = FullyConnectedLayer(64, 3, act='sigmoid' if config.model_type == 'vad' else 'relu')
+        self.optimizer = None
+        self.loss_fn: Optional[Callable] = None
+        self.clipvalue: Optional[float] = None
+        self.use_agc = True
+        self._ddp = None
+
+    def forward(self, x):
+        """x: [B, n_mels, n_frame, n_chan] (the reference's channels-last input)."""
+        x = x.permute(0, 3, 1, 2)  # NCHW view of the NHWC tensor (channels_last strides)
+        x = self.features(x)       # [B, C, M', T']
+        x = x.permute(0, 3, 2, 1).flatten(2)  # [B, T', M' * C], m' major as Keras Permute+Reshape
+        x = torch.relu(self.td(x))
+        x = self.fc_pre(x)
+        if self.lstm is not None:
+            x, _ = self.lstm(x)
+        return self.head(self.fc_post(x))
+
+    # ---- Keras-like training surface ------------------------------------
+    def compile(self, optimizer, loss, clipvalue: Optional[float] = None, use_agc: bool = True, ddp=None):
+        self.optimizer, self.loss_fn, self.clipvalue, self.use_agc, self._ddp = optimizer, loss, clipvalue, use_agc, ddp
+
+    def _call(self, x):
+        return self._ddp(x) if self._ddp is not None else self(x)
+
+    def train_step(self, data):
+        """Forward, loss, backward, AGC on the (all-reduced) gradients, element-wise
+        clipvalue, optimiser step (sj_train.py:162-188).  Returns {'loss': tensor}."""
+        x, y = data
+        self.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        y_pred = self._call(x)
+        loss = self.loss_fn(y, y_pred)
+        loss.backward()  # under DDP the bucketed RCCL all-reduce overlaps with this
+        params = [p for p in self.parameters() if p.grad is not None]
+        if self.use_agc:
+            new = adaptive_clip_grad(params, [p.grad for p in params])
+            for p, g in zip(params, new):
+                p.grad = g
+        if self.clipvalue:
+            torch.nn.utils.clip_grad_value_(params, self.clipvalue)
+        self.optimizer.step()
+        return {'loss': loss.detach()}
+
+    @torch.no_grad()
+    def test_step(self, data):
+        x, y = data
+        self.eval()
+        return {'loss': self.loss_fn(y, self(x))}
+
+
+def define_keras_model(config=None):
+    """Name kept for drop-in use; returns the torch CustomModel (sj_train.py:214-255)."""
+    return CustomModel(config)
+
+
+def get_model(config):
+    if config.model_type == 'vad':
+        return define_keras_model(config)
+    raise NotImplementedError(f"model_type '{config.model_type}' is outside the accelerated path "
+                              "(EfficientNet / speech-enhancement branches, sj_train.py:299-401)")
+
+
+def binary_crossentropy(y_true, y_pred):
+    """tf.keras.losses.BinaryCrossentropy(): mean over all elements, probabilities
+    clipped to [1e-7, 1 - 1e-7]."""
+    p = torch.clamp(y_pred, 1e-7, 1 - 1e-7)
+    return torch.mean(-(y_true * torch.log(p) + (1 - y_true) * torch.log(1 - p)))
+
+
+def make_optimizer(config, params):
+    if config.optimizer == 'adam':
+        return torch.optim.Adam(params, lr=config.lr, eps=1e-7)  # Keras Adam epsilon
+    if config.optimizer == 'sgd':
+        return torch.optim.SGD(params, lr=config.lr, momentum=0.9)
+    if config.optimizer == 'rmsprop':
+        return torch.optim.RMSprop(params, lr=config.lr, momentum=0.9, alpha=0.9, eps=1e-7)
+    raise ValueError('adabelief is deprecated')
+
+
+def run_name(config) -> str:
+    """Run name encoding of sj_train.py:416-429."""
+    name = (config.name + '_') if config.name != '' else ''
+    first = {'eff': f'B{config.model}', 'se': 'se', 'vad': 'vad'}[config.model_type]
+    name += '_'.join([first, f'v{config.v}', f'lr{config.lr}', f'batch{config.batch_size}',
+                      f'opt_{config.optimizer}', f'mel{config.n_mels}', f'chan{config.n_chan}',
+                      f'{config.loss.upper()}', f'framelen{config.n_frame}'])
+    return name if name.endswith('.h5') else name + '.h5'
+
+
+def init_distributed():
+    """One process per GPU (torchrun): returns (rank, world, device).  Backend 'nccl' is
+    RCCL on ROCm; 'gloo' on CPU-only hosts (tests)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
+    else:
+        device = torch.device('cpu')
+    if world > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if device.type == 'cuda':
+            torch.distributed.init_process_group('nccl', device_id=device)
+        else:
+            torch.distributed.init_process_group('gloo')
+    return rank, world, device
+
+
+def wrap_ddp(model: CustomModel, device, world: int):
+    if world <= 1:
+        return None
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    return DDP(model, device_ids=[device.index] if device.type == 'cuda' else None,
+               bucket_cap_mb=25, gradient_as_bucket_view=True)
+
+
+def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=None, validation_steps=16,
+        scheduler=None, csv_path=None, checkpoint_path=None, patience=None, rank=0, world=1, verbose=True):
+    """Minimal Keras-fit equivalent for this path: per-epoch LR schedule, CSV log,
+    best-val-loss checkpoint, early stopping, TerminateOnNaN (sj_train.py:489-519)."""
+    best, bad, history = math.inf, 0, []
+    it = iter(train_set)
+    for epoch in range(epochs):
+        if scheduler is not None:
+            lr = scheduler(epoch)
+            for g in model.optimizer.param_groups:
+                g['lr'] = lr
+        t0, losses = time.time(), []
+        for _ in range(steps_per_epoch):
+            losses.append(model.train_step(next(it))['loss'])
+        loss = torch.stack(losses).mean()
+        if world > 1:
+            torch.distributed.all_reduce(loss)  # one scalar per epoch
+            loss = loss / world
+        row = {'epoch': epoch, 'loss': float(loss), 'lr': model.optimizer.param_groups[0]['lr'],
+               'time': time.time() - t0}
+        if not math.isfinite(row['loss']):
+            if verbose and rank == 0:
+                print('NaN loss, terminating')
+            break
+        if validation_data is not None:
+            vit = iter(validation_data)
+            vl = torch.stack([model.test_step(next(vit))['loss'] for _ in range(validation_steps)]).mean()
+            row['val_loss'] = float(vl)
+        history.append(row)
+        if rank == 0:
+            if verbose:
+                print(row)
+            if csv_path:
+                new = not os.path.exists(csv_path)
+                with open(csv_path, 'a', newline='') as f:
+                    w = csv.DictWriter(f, fieldnames=list(row))
+                    if new:
+                        w.writeheader()
+                    w.writerow(row)
+            monitor = row.get('val_loss', row['loss'])
+            if monitor < best:
+                best, bad = monitor, 0
+                if checkpoint_path:
+                    torch.save(model.state_dict(), checkpoint_path)
+            else:
+                bad += 1
+        if patience is not None and bad > patience:
+            break
+    return history
+
+
+def main(argv=None):
+    config = ARGS().get(argv)
+    config.loss = config.loss.upper()
+    if config.loss != 'MSE':
+        config.mse_multiplier = 1
+    rank, world, device = init_distributed()
+    if rank == 0:
+        print(config)
+    NAME = run_name(config)
+    model = get_model(config).to(device).to(memory_format=torch.channels_last)
+    opt = make_optimizer(config, model.parameters())
+    loss = binary_crossentropy if config.loss == 'BCE' else \
+        (lambda yt, yp: sigmoid_focal_crossentropy(yt, yp).mean())
+    model.compile(opt, loss, clipvalue=None if config.no_clipvalue_after_agc else config.clipvalue,
+                  ddp=wrap_ddp(model, device, world))
+    if rank == 0:
+        print(NAME, sum(p.numel() for p in model.parameters()), 'parameters')
+    if config.pretrain and os.path.exists(NAME.replace('.h5', '.pt')):
+        model.load_state_dict(torch.load(NAME.replace('.h5', '.pt'), map_location=device))
+    train_set = make_dataset(config, training=True)
+    test_set = make_dataset(config, training=False)
+    fit(model, train_set, config.epochs, config.steps_per_epoch, test_set, config.validation_steps,
+        scheduler=custom_scheduler(4096, config.epochs / 12, config.lr_div),
+        csv_path=NAME.replace('.h5', '.csv'), checkpoint_path=NAME.replace('.h5', '.pt'),
+        patience=config.patience, rank=rank, world=world)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(NAME.split('.h5')[0])
+
+
+if __name__ == "__main__":
+    main()

@@ -78,10 +78,12 @@ int iris_mel_weight_matrix(int n_mel, int n_bins, float sample_rate,
  * num_spectrogram_bins, sample_rate, **kw) (transforms.py:51-56) and
  * torchaudio.transforms.Spectrogram(n_fft, power=None) (data_utils.py:17) hold.
  *
- *   n_fft       power of two in [256, 2048]; window = periodic Hann(n_fft)
+ *   n_fft       power of two in [256, 2048]; window = periodic Hann(n_fft).
+ *               0 = mel-only plan: any n_bins >= 2, only iris_magmel is available
+ *               (magphase_to_mel on spectra of an arbitrary bin count)
  *   hop         > 0 (Spectrogram default: n_fft / 2)
  *   n_mel       M >= 1
- *   n_bins      must equal n_fft/2 + 1
+ *   n_bins      must equal n_fft/2 + 1 (unless n_fft == 0)
  *   channels    C >= 1 audio channels per clip
  *   max_batch, max_len   capacity of the workspace (clips, samples per channel)
  *   mel_host    optional HOST [n_bins*n_mel] matrix to use instead of the
