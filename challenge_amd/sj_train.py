@@ -362,7 +362,7 @@ class CustomModel(nn.Module):
         self.loss_fn: Optional[Callable] = None
         self.clipvalue: Optional[float] = None
         self.use_agc = True
-        self._ddp = None
+        object.__setattr__(self, '_ddp', None)  # not a submodule: DDP wraps this very module
 
     def forward(self, x):
         """x: [B, n_mels, n_frame, n_chan] (the reference's channels-last input)."""
@@ -377,7 +377,8 @@ class CustomModel(nn.Module):
 
     # ---- Keras-like training surface ------------------------------------
     def compile(self, optimizer, loss, clipvalue: Optional[float] = None, use_agc: bool = True, ddp=None):
-        self.optimizer, self.loss_fn, self.clipvalue, self.use_agc, self._ddp = optimizer, loss, clipvalue, use_agc, ddp
+        self.optimizer, self.loss_fn, self.clipvalue, self.use_agc = optimizer, loss, clipvalue, use_agc
+        object.__setattr__(self, '_ddp', ddp)
 
     def _call(self, x):
         return self._ddp(x) if self._ddp is not None else self(x)

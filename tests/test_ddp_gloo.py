@@ -1,0 +1,67 @@
+"""world_size-2 data-parallel test on CPU (gloo): the N > 1 path of the training step.
+Gradients all-reduced by DDP equal the mean of the per-rank gradients, and after
+AGC + clipvalue + Adam both ranks hold identical parameters."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from challenge_amd import sj_train as S
+    r, w, device = S.init_distributed()
+    assert (r, w, device.type) == (rank, world, "cpu")
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '32', '--n_frame', '64', '--n_chan', '1'])
+    torch.manual_seed(0)                      # identical init on every rank
+    model = S.get_model(cfg)
+    ref = S.get_model(cfg)
+    ref.load_state_dict(model.state_dict())
+    g = torch.Generator().manual_seed(100)    # the same global batch everywhere; each rank takes its shard
+    xs = torch.randn(4, 32, 64, 1, generator=g)
+    ys = (torch.rand(4, 2, 3, generator=g) > 0.8).float()
+    x, y = xs[rank::world], ys[rank::world]
+    model.compile(S.make_optimizer(cfg, model.parameters()), S.binary_crossentropy, clipvalue=cfg.clipvalue,
+                  ddp=S.wrap_ddp(model, device, world))
+    # reference: mean over ranks of single-process gradients (BatchNorm stays per replica)
+    grads = []
+    for rr in range(world):
+        ref.zero_grad()
+        ref.train()
+        S.binary_crossentropy(ys[rr::world], ref(xs[rr::world])).backward()
+        grads.append([p.grad.clone() for p in ref.parameters()])
+    mean_grads = [sum(gs) / world for gs in zip(*grads)]
+    model.train()
+    model.optimizer.zero_grad()
+    S.binary_crossentropy(y, model._call(x)).backward()
+    err = max(float((p.grad - g_).abs().max()) for p, g_ in zip(model.parameters(), mean_grads))
+    assert err < 1e-5, err
+    model.train_step((x, y))                 # full step: AGC + clipvalue + Adam on averaged grads
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(gathered, flat)
+    assert torch.equal(gathered[0], gathered[1])
+    torch.save({"ok": True, "err": err}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_two_ranks_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert torch.load(tmp_path / f"rank{r}.pt")["ok"]
