@@ -79,6 +79,64 @@ def cpu_baseline(wav_cpu: np.ndarray):
     }
 
 
+def side_measurements(dev, rank, world, steps, fence):
+    """BASELINE configs[2] and [3], reported beside the headline (never as `value`):
+    c3 = fused frontend with SpecAugment + CRNN v9 forward, batch 64 x 8.176 s (T = 512);
+    c4 = the full training step (frontend, forward, backward, RCCL gradient all-reduce via
+    DDP when world > 1, AGC, clipvalue, Adam), batch 64 per GPU, synthetic labels."""
+    import torch.distributed as dist
+    from challenge_amd import sj_train as S
+    # MIOpen must benchmark its solvers once per conv shape (NORMAL find): the FAST heuristic picks
+    # a CK backward-weight kernel that is ~60x slower on these fp32 shapes (about 35 s, first run only)
+    os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL")
+    batch, length = 64, 130816
+    audio_s = batch * length / SR
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', str(N_MEL), '--n_frame', '512', '--n_chan', '1',
+                        '--batch_size', str(batch)])
+    torch.manual_seed(0)
+    model = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    model.compile(S.make_optimizer(cfg, model.parameters()), S.binary_crossentropy, clipvalue=cfg.clipvalue,
+                  ddp=S.wrap_ddp(model, dev, world))
+    fe = S.WaveFrontend(N_FFT, HOP, N_MEL, SR, 1, batch, length, dev, training=True, device_draw=True,
+                        seed=99 + rank)
+    gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    wav = torch.randn(batch, 1, length, generator=gen, device=dev) * 0.1
+    y = (torch.rand(batch, 16, 3, generator=gen, device=dev) < 0.1).float()
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / n
+
+    def fwd():
+        model.eval()
+        with torch.no_grad():
+            model(fe(wav))
+
+    def train():
+        model.train_step((fe(wav), y))
+
+    t_fwd = timed(fwd, steps)
+    t_train = timed(train, steps)
+    return {
+        "c3_frontend_specaug_crnn_fwd": {"audio_s_per_s": round(world * audio_s / t_fwd, 1),
+                                         "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch},
+        "c4_train_step": {"audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3),
+                          "batch_per_gpu": batch, "n_gpus": world, "params": sum(p.numel() for p in model.parameters()),
+                          "grad_allreduce": "DDP/RCCL" if world > 1 else "none"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +145,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the dominant kernel with HIP events (roofline.achieved = null)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the c3 (frontend + CRNN forward) and c4 (training step, DDP) side measurements")
+    ap.add_argument("--extra-steps", type=int, default=20)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -149,7 +210,12 @@ def main():
                                "fused STFT+magnitude+mel+min-max+log (frontend only, no collective)",
                    "global_batch": world * BATCH, "parallelism": f"dp{world}"},
     }
+    extras = None
+    if not args.no_extras:
+        extras = side_measurements(dev, rank, world, args.extra_steps, fence)
     if rank == 0:
+        if extras:
+            result["extra"] = extras
         algo_bytes = ALGO_BYTES_PER_AUDIO_S * audio_s_per_step  # per launch
         achieved = (algo_bytes / (kernel_ms * 1e-3) / 1e9) if n_ev and kernel_ms > 0 else None
         result["roofline"] = {

@@ -200,24 +200,44 @@ class WaveFrontend:
     + magphase_to_mel + minmax + log_on_mel without materialising the spectrum."""
 
     def __init__(self, n_fft=1024, hop=256, n_mels=64, sample_rate=16000, n_chan=1, batch=64, length=130816,
-                 device=None, training=True, filter_bins: int = 0, do_minmax: bool = True):
+                 device=None, training=True, filter_bins: int = 0, do_minmax: bool = True,
+                 device_draw: bool = False, seed: int = 0):
         self.plan = _fe.FrontendPlan(n_fft, hop, n_mels, sample_rate, n_chan, batch, length, device)
         self.training, self.filter_bins, self.do_minmax = training, filter_bins, do_minmax
-        self.rng = np.random.default_rng(0)
+        self.device_draw = device_draw
+        self.rng = np.random.default_rng(seed)
+        self._gen = torch.Generator(device=self.plan.device).manual_seed(seed)
 
     def draw_bands(self, batch: int, n_time: int):
+        """Host draw (NumPy Generator): exact integer distributions of transforms.py:25-26."""
         tb = np.stack([_du.augment_draw(n_time, self.plan.n_bins, self.rng)[0] for _ in range(batch)])
         fb = np.stack([_du.augment_draw(n_time, self.plan.n_bins, self.rng)[1] for _ in range(batch)])
         return tb, fb
+
+    def draw_bands_device(self, batch: int, n_time: int):
+        """Device draw, no host round trip: size ~ U{0..max-1}, offset = floor(U[0,1) * (total - size))
+        (same support as the reference's integer draw; probabilities equal up to fp32 rounding)."""
+        dev = self.plan.device
+
+        def draw(total, max_size, n):
+            size = torch.randint(0, max_size, (batch, n), device=dev, generator=self._gen)
+            off = (torch.rand((batch, n), device=dev, generator=self._gen) * (total - size)).floor().to(torch.int64)
+            off = torch.minimum(off, total - size - 1)
+            return torch.stack([off, size], dim=-1).to(torch.int32)
+        return draw(n_time, 24, 6), draw(self.plan.n_bins, 16, 1)
 
     def __call__(self, wav: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         b, n_time = wav.shape[0], self.plan.num_frames(wav.shape[2])
         tb = fb = None
         if self.training:
-            tb, fb = self.draw_bands(b, n_time)
+            tb, fb = self.draw_bands_device(b, n_time) if self.device_draw else self.draw_bands(b, n_time)
         if self.filter_bins:
-            flt = np.tile(np.array([[[1, self.filter_bins]]], np.int32), (b, 1, 1))
-            fb = flt if fb is None else np.concatenate([fb, flt], axis=1)
+            if isinstance(fb, torch.Tensor) or (fb is None and self.device_draw):
+                flt = torch.tensor([[[1, self.filter_bins]]], dtype=torch.int32, device=self.plan.device).expand(b, 1, 2)
+                fb = flt if fb is None else torch.cat([fb, flt], dim=1)
+            else:
+                flt = np.tile(np.array([[[1, self.filter_bins]]], np.int32), (b, 1, 1))
+                fb = flt if fb is None else np.concatenate([fb, flt], axis=1)
         return self.plan.wav_to_logmel(wav, minmax=self.do_minmax, log=True, t_bands=tb, f_bands=fb, out=out)
 
 

@@ -217,3 +217,15 @@ def test_train_step_on_gpu(dev):
     for _ in range(10):
         last = float(model.train_step((x, y))['loss'])
     assert math.isfinite(last) and last < first
+
+
+def test_wave_frontend_device_draw(dev):
+    _, _, S = mods()
+    fe = S.WaveFrontend(1024, 256, 64, 16000, 1, 16, 130816, dev, training=True, device_draw=True, filter_bins=3)
+    tb, fb = fe.draw_bands_device(16, 512)
+    tb, fb = tb.cpu().numpy(), fb.cpu().numpy()
+    assert tb.shape == (16, 6, 2) and fb.shape == (16, 1, 2)
+    assert tb[..., 1].max() < 24 and tb[..., 1].min() >= 0 and np.all(tb[..., 0] + tb[..., 1] < 512 + (tb[..., 1] == 0))
+    assert fb[..., 1].max() < 16 and np.all(fb[..., 0] + fb[..., 1] < 513 + (fb[..., 1] == 0)) and tb[..., 0].min() >= 0
+    x = fe(torch.randn(16, 1, 130816, device=dev) * 0.1)
+    assert tuple(x.shape) == (16, 64, 512, 1) and torch.isfinite(x).all()
