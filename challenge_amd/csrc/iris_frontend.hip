@@ -66,6 +66,8 @@ struct iris_plan {
     int rows, need_hi, mel_mode;
     float* d_ws;  // workspace
     unsigned long long* d_dbg;  // diagnostic stamps
+    unsigned* d_sync;           // [max_batch][kSyncStride] clip lines, then [1] timeout
+    int fuse_epilogue;          // IRIS_FUSE_MINMAX=1: min-max/log inside K1 (default 0: measured slower)
     size_t ws_floats;
     int num_cu;
     int chunk_target;  // 0 = auto; frames per chunk of the fused kernel (IRIS_CHUNK_FRAMES)
@@ -120,6 +122,16 @@ __device__ __forceinline__ void block_minmax(float& mn, float& mx, float* red /*
         mx = fmaxf(mx, red[8 + i]);
     }
 }
+
+// Order-preserving map float -> uint (and back), so that unsigned atomic min/max order floats.
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+constexpr int kSyncStride = 32;  // uint32 words per clip: one 128-byte line {arrive, depart, min key, max key}
 
 // Consecutive logical workgroup ids land on the same XCD (blocks b and b+8 share
 // one; bijective for any grid size).  Placement only affects speed.
@@ -278,6 +290,11 @@ struct FusedArgs {
     int n_fb;
     int B, C, L, T, hop, M;
     int chunk_frames, chunks_per_clip, n_chunks;
+    // fused epilogue (mode 0 = raw mel + min/max partials for k_minmax_log_apply;
+    // 1 = min-max and/or log applied here, clips synchronised through arrive/depart)
+    int fuse, do_minmax, do_log;
+    unsigned* sync;     // [B][kSyncStride]: {arrive, depart, min key, max key} of each clip on its own line
+    unsigned* timeout;  // [1] set when a wait gave up (results for that chunk are not normalised)
     int ablate;  // diagnostic only (IRIS_ABLATE): skip phases, results are wrong when non-zero
     unsigned long long* dbg;  // diagnostic only: [4] shader-clock / 100 MHz stamps of workgroup 0
 };
@@ -516,23 +533,100 @@ __global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_m
         }
         __syncthreads();
 
-        // write the chunk: wave per mel row, a contiguous run of nt*C floats each
+        // chunk epilogue: wave per mel row, a contiguous run of nt*C floats each
         const int run = nt * a.C;
         float mn = INFINITY, mx = -INFINITY;
+        if (!a.fuse) {
+            for (int m = wv; m < a.M; m += kFusedWaves) {
+                float* dst = a.out + (((size_t)b * a.M + m) * a.T + t0) * a.C;
+                const float* srow = tile_out + m * tile_stride;
+                for (int r = lane; r < run; r += kWave) {
+                    const float v = srow[r];
+                    if (!ABL(16)) dst[r] = v;
+                    mn = fminf(mn, v);
+                    mx = fmaxf(mx, v);
+                }
+            }
+            block_minmax(mn, mx, red);  // ends with every thread past the tile reads
+            if (threadIdx.x == 0) {
+                a.partial[(size_t)chunk * 2 + 0] = mn;
+                a.partial[(size_t)chunk * 2 + 1] = mx;
+            }
+            __syncthreads();
+            continue;
+        }
+        // fused min-max / log: publish this chunk's (min, max), wait for the clip's other
+        // chunks, normalise the tile still sitting in LDS and write the final values once.
+        // Placement-independent protocol: 8-byte agent-scope atomics carry the payload
+        // (no tearing), an agent-scope counter signals it; every workgroup publishes BEFORE
+        // it waits and the grid never exceeds what is resident, so the wait always ends;
+        // it is bounded anyway (timeout word).
+        float gmn = 0.f, den = 1.f;
+        if (a.do_minmax) {
+            for (int m = wv; m < a.M; m += kFusedWaves) {
+                const float* srow = tile_out + m * tile_stride;
+                for (int r = lane; r < run; r += kWave) {
+                    const float v = srow[r];
+                    mn = fminf(mn, v);
+                    mx = fmaxf(mx, v);
+                }
+            }
+            block_minmax(mn, mx, red);
+            unsigned* line = a.sync + (size_t)b * kSyncStride;
+            if (threadIdx.x == 0) {
+                // memory-side atomics fold this chunk into the clip's (min, max); once they are
+                // acknowledged the arrival is counted
+                const unsigned need = (unsigned)a.chunks_per_clip;
+                __hip_atomic_fetch_min(&line[2], f2key(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max(&line[3], f2key(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                unsigned seen = __hip_atomic_fetch_add(&line[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                bool ok = true;
+                unsigned spins = 0;
+                while (!ABL(1024) && seen < need) {  // the last arriver never polls
+                    __builtin_amdgcn_s_sleep(16);     // ~0.5 us: keeps the poll rate per line low
+                    seen = __hip_atomic_load(&line[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > (1u << 21)) {       // ~1 s: give up, flag it
+                        ok = false;
+                        __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                float lo = 0.f, hi = 1.f;  // timed out: identity transform for this chunk
+                if (ok) {
+                    const unsigned long long pk = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&line[2]),
+                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    lo = key2f((unsigned)(pk & 0xffffffffull));
+                    hi = key2f((unsigned)(pk >> 32));
+                }
+                red[16] = lo;
+                red[17] = fmaxf(hi - lo, 1e-8f);
+            }
+            __syncthreads();
+            gmn = red[16];
+            den = red[17];
+        }
         for (int m = wv; m < a.M; m += kFusedWaves) {
             float* dst = a.out + (((size_t)b * a.M + m) * a.T + t0) * a.C;
             const float* srow = tile_out + m * tile_stride;
             for (int r = lane; r < run; r += kWave) {
-                const float v = srow[r];
-                if (!ABL(16)) dst[r] = v;
-                mn = fminf(mn, v);
-                mx = fmaxf(mx, v);
+                float v = srow[r];
+                if (a.do_minmax) v = (v - gmn) / den;
+                if (a.do_log) v = logf(v + 1e-8f);
+                dst[r] = v;
             }
         }
-        block_minmax(mn, mx, red);  // ends with every thread past the tile reads
-        if (threadIdx.x == 0) {
-            a.partial[(size_t)chunk * 2 + 0] = mn;
-            a.partial[(size_t)chunk * 2 + 1] = mx;
+        if (a.do_minmax && threadIdx.x == 0) {
+            // done with the clip's line (off the critical path): the clip's last chunk to get
+            // here re-arms it for the next launch
+            unsigned* line = a.sync + (size_t)b * kSyncStride;
+            const unsigned prev = __hip_atomic_fetch_add(&line[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev + 1 == (unsigned)a.chunks_per_clip) {
+                __hip_atomic_store(&line[2], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&line[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&line[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&line[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
     }
@@ -1035,6 +1129,9 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->d_band_lo = p->d_band_len = p->d_fband_lo = nullptr;
     p->d_wband = p->d_mel = p->d_ws = nullptr;
     p->d_dbg = nullptr;
+    p->d_sync = nullptr;
+    p->fuse_epilogue = 0;
+    if (const char* e = getenv("IRIS_FUSE_MINMAX")) p->fuse_epilogue = atoi(e) != 0;
     p->timing = false;
     p->ev_used = 0;
 
@@ -1159,7 +1256,16 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->ws_floats = 2 * (size_t)max_batch * t_max + (size_t)max_batch * ((wav_row + kChunk - 1) / kChunk) + 64;
     (void)hipMalloc((void**)&p->d_dbg, (4 + 3 * 4096) * sizeof(unsigned long long));
     if (p->d_dbg) (void)hipMemset(p->d_dbg, 0, (4 + 3 * 4096) * sizeof(unsigned long long));
-    hipError_t e = hipMalloc((void**)&p->d_ws, p->ws_floats * sizeof(float));
+    std::vector<unsigned> sync_init((size_t)max_batch * kSyncStride + kSyncStride, 0u);
+    for (int b = 0; b < max_batch; ++b) sync_init[(size_t)b * kSyncStride + 2] = 0xffffffffu;  // min key
+    hipError_t e = hipMalloc((void**)&p->d_sync, sync_init.size() * sizeof(unsigned));
+    if (e == hipSuccess)
+        e = hipMemcpy(p->d_sync, sync_init.data(), sync_init.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        iris_plan_destroy(p);
+        return fail((int)e, "hipMalloc/hipMemcpy(sync words) failed: %s", hipGetErrorString(e));
+    }
+    e = hipMalloc((void**)&p->d_ws, p->ws_floats * sizeof(float));
     if (e != hipSuccess) {
         iris_plan_destroy(p);
         return fail((int)e, "hipMalloc(workspace %zu floats) failed: %s", p->ws_floats, hipGetErrorString(e));
@@ -1196,6 +1302,7 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
                     loop / n * 0.01);
     }
     (void)hipFree(p->d_dbg);
+    (void)hipFree(p->d_sync);
     for (hipEvent_t ev : p->ev) (void)hipEventDestroy(ev);
     (void)hipFree(p->d_consts);
     (void)hipFree(p->d_band_lo);
@@ -1371,10 +1478,11 @@ extern "C" int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minm
     return IRIS_OK;
 }
 
-// Chunk geometry of the fused kernel: fused_occ() workgroups per CU, every workgroup one
+// Chunk geometry of the fused kernel for `per_cu` workgroups per CU: every workgroup one
 // chunk when the problem is large enough, chunks never span clips.
-static void fused_geometry(const iris_plan* p, int batch, int T, int* chunk_frames, int* chunks_per_clip) {
-    const int slots = p->num_cu * fused_occ(p->log2n);
+static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int* chunk_frames,
+                           int* chunks_per_clip) {
+    const int slots = p->num_cu * per_cu;
     const long total = (long)batch * T;
     int cap = 128;  // frames; keeps the LDS out tile <= 48 KiB
     while (cap > 1 && (size_t)p->n_mel * (cap * p->channels + 1) * 4 > 48 * 1024) cap /= 2;
@@ -1383,6 +1491,30 @@ static void fused_geometry(const iris_plan* p, int batch, int T, int* chunk_fram
     const int cpc = (T + target - 1) / target;
     *chunks_per_clip = cpc;
     *chunk_frames = (T + cpc - 1) / cpc;
+}
+
+// Geometry + grid with the residency the hardware really grants: the fused epilogue
+// makes workgroups of a clip wait for each other, which is only safe when every
+// workgroup of the grid is resident.  LDS use depends on the chunk size and the chunk
+// size on the number of resident workgroups, so iterate from the register-limited
+// occupancy downwards until the occupancy query agrees.
+static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, int T, int* chunk_frames,
+                        int* chunks_per_clip, int* grid, size_t* lds) {
+    for (int per_cu = fused_occ(p->log2n); per_cu >= 1; --per_cu) {
+        fused_geometry(p, batch, T, per_cu, chunk_frames, chunks_per_clip);
+        *lds = fused_lds_bytes(p, *chunk_frames);
+        if (*lds > 160 * 1024) continue;
+        int resident = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
+                                                                    64 * kFusedWaves, *lds);
+        if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s",
+                                         hipGetErrorString(e));
+        if (resident >= per_cu) {
+            *grid = std::min(batch * *chunks_per_clip, p->num_cu * per_cu);
+            return IRIS_OK;
+        }
+    }
+    return fail(IRIS_E_UNSUPPORTED, "fused kernel does not fit one workgroup per CU (LDS %zu B)", *lds);
 }
 
 extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, int batch, int len, int flags,
@@ -1412,10 +1544,20 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     a.T = 1 + len / p->hop;
     a.hop = p->hop;
     a.M = p->n_mel;
+    const int do_minmax = (flags & IRIS_F_MINMAX) ? 1 : 0, do_log = (flags & IRIS_F_LOG) ? 1 : 0;
+    a.fuse = (p->fuse_epilogue && (do_minmax || do_log)) ? 1 : 0;
+    a.do_minmax = do_minmax;
+    a.do_log = do_log;
+    a.sync = p->d_sync;
+    a.timeout = p->d_sync + (size_t)p->max_batch * kSyncStride;
     a.ablate = 0;
     if (const char* e = getenv("IRIS_ABLATE")) a.ablate = atoi(e);
     a.dbg = p->d_dbg;
-    fused_geometry(p, batch, a.T, &a.chunk_frames, &a.chunks_per_clip);
+    const bool bands = (n_tb > 0) || (n_fb > 0);
+    const fused_kernel_t kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands);
+    int grid = 0;
+    size_t lds = 0;
+    if ((rc = fused_config(p, kernel, batch, a.T, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds))) return rc;
     a.n_chunks = batch * a.chunks_per_clip;
     const size_t n_partial = 2 * (size_t)a.n_chunks;
     a.partial = p->d_ws;
@@ -1431,9 +1573,6 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         a.sumsq = sq;
     }
     if (n_partial > p->ws_floats) return fail(IRIS_E_CAPACITY, "iris_wav_to_logmel: workspace too small");
-    const int grid = std::min(a.n_chunks, p->num_cu * fused_occ(p->log2n));
-    const size_t lds = fused_lds_bytes(p, a.chunk_frames);
-    if (lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_wav_to_logmel: LDS tile too large (%zu B)", lds);
 
     const bool timed = p->timing && p->ev_used < kMaxTimedLaunches;
     if (timed) {
@@ -1444,16 +1583,14 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         }
         HIP_TRY(hipEventRecord(p->ev[2 * p->ev_used], s));
     }
-    const bool bands = (a.t_bands != nullptr) || (a.f_bands != nullptr);
-    fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands)<<<grid, 64 * kFusedWaves, lds, s>>>(a);
+    kernel<<<grid, 64 * kFusedWaves, lds, s>>>(a);
     hipError_t e = hipGetLastError();
     HIP_TRY(e);
     if (timed) {
         HIP_TRY(hipEventRecord(p->ev[2 * p->ev_used + 1], s));
         p->ev_used++;
     }
-    const int do_minmax = (flags & IRIS_F_MINMAX) ? 1 : 0, do_log = (flags & IRIS_F_LOG) ? 1 : 0;
-    if (do_minmax || do_log) {
+    if (!a.fuse && (do_minmax || do_log)) {
         const size_t row_len = (size_t)p->n_mel * a.T * p->channels;
         const unsigned n_chunks = (unsigned)((row_len + kChunk - 1) / kChunk);
         k_minmax_log_apply<<<dim3(n_chunks, batch), 256, 0, s>>>(out, p->d_ws, a.chunks_per_clip, row_len, do_minmax,
