@@ -48,19 +48,25 @@ def cpu_baseline(wav_cpu: np.ndarray):
         R.wav_to_logmel(wav_cpu, N_FFT, HOP, N_MEL, SR)
         ta.append(time.perf_counter() - t0)
     a_rate = audio_s / float(np.median(ta))
-    # B: torch CPU, all threads
-    torch.set_num_threads(cores)
+    # B: torch CPU; small FFTs oversubscribe badly, so try a few thread counts and keep the best
     w = torch.from_numpy(R.linear_to_mel_weight_matrix(N_MEL, N_FFT // 2 + 1, SR))
     x = torch.from_numpy(wav_cpu)
-    for _ in range(2):
-        wav_to_logmel_cpu(x, w, N_FFT, HOP)
-    tb = []
-    t_end = time.perf_counter() + 8.0
-    while len(tb) < 5 or (time.perf_counter() < t_end and len(tb) < 200):
-        t0 = time.perf_counter()
-        wav_to_logmel_cpu(x, w, N_FFT, HOP)
-        tb.append(time.perf_counter() - t0)
-    b_rate = audio_s / float(np.median(tb))
+    b_rate, b_threads, b_runs = 0.0, 1, 0
+    for nt in sorted({1, 8, 16, 32, min(64, cores), cores}):
+        if nt > cores:
+            continue
+        torch.set_num_threads(nt)
+        for _ in range(2):
+            wav_to_logmel_cpu(x, w, N_FFT, HOP)
+        tb = []
+        t_end = time.perf_counter() + 2.0
+        while len(tb) < 5 or (time.perf_counter() < t_end and len(tb) < 100):
+            t0 = time.perf_counter()
+            wav_to_logmel_cpu(x, w, N_FFT, HOP)
+            tb.append(time.perf_counter() - t0)
+        rate = audio_s / float(np.median(tb))
+        if rate > b_rate:
+            b_rate, b_threads, b_runs = rate, nt, len(tb)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -71,11 +77,12 @@ def cpu_baseline(wav_cpu: np.ndarray):
     except OSError:
         pass
     return {
-        "value": round(max(a_rate, b_rate), 1), "unit": "audio-s/s", "cores": cores if b_rate >= a_rate else 1,
+        "value": round(max(a_rate, b_rate), 1), "unit": "audio-s/s", "cores": b_threads if b_rate >= a_rate else 1,
         "kind": "port",
-        "sample": (f"same c2 batch (32 x 10 s); B=torch.stft+torch CPU ops, {cores} threads, median of {len(tb)} "
-                   f"runs = {b_rate:.0f}; A=NumPy oracle, 1 thread, median of {reps_a} = {a_rate:.0f}; CPU: {model}"),
-        "numpy_1thread": round(a_rate, 1), "torch_allthreads": round(b_rate, 1),
+        "sample": (f"same c2 batch (32 x 10 s); B=torch.stft+torch CPU ops, best of 1/8/16/32/64/{cores} threads = "
+                   f"{b_threads} threads, median of {b_runs} runs = {b_rate:.0f}; A=NumPy oracle, 1 thread, median of "
+                   f"{reps_a} = {a_rate:.0f}; host has {cores} hardware threads; CPU: {model}"),
+        "numpy_1thread": round(a_rate, 1), "torch_best": round(b_rate, 1), "torch_best_threads": b_threads,
     }
 
 
