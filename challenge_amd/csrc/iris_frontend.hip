@@ -900,6 +900,60 @@ __global__ void k_mask_apply(T* x, size_t n_outer, size_t axis_len, size_t n_inn
 }
 
 // ---------------------------------------------------------------------------
+// adaptive gradient clipping + clipvalue, one wave per output unit (row)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_agc_clip(const iris_agc_row* rows, size_t n_rows, float clip_factor,
+                                                  float eps, float clipvalue) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * 4;
+    for (size_t r = wave; r < n_rows; r += n_waves) {
+        const float* p = rows[r].param;
+        float* g = rows[r].grad;
+        const long len = rows[r].len;
+        float sp = 0.f, sg = 0.f;
+        const bool vec = ((len & 3) == 0) && (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g)) & 15) == 0);
+        if (vec) {
+            for (long i = 4 * lane; i < len; i += 4 * kWave) {
+                const float4 a = *reinterpret_cast<const float4*>(p + i);
+                const float4 b = *reinterpret_cast<const float4*>(g + i);
+                sp += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+                sg += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+            }
+        } else {
+            for (long i = lane; i < len; i += kWave) {
+                sp += p[i] * p[i];
+                sg += g[i] * g[i];
+            }
+        }
+        const float p_norm = sqrtf(wave_sum(sp)), g_norm = sqrtf(wave_sum(sg));
+        const float max_norm = fmaxf(p_norm, eps) * clip_factor;
+        const float scale = g_norm < max_norm ? 1.0f : max_norm / fmaxf(g_norm, 1e-6f);
+        const bool clamp = clipvalue > 0.f;
+        if (scale == 1.0f && !clamp) continue;  // wave-uniform
+        if (vec) {
+            for (long i = 4 * lane; i < len; i += 4 * kWave) {
+                float4 b = *reinterpret_cast<float4*>(g + i);
+                b.x *= scale; b.y *= scale; b.z *= scale; b.w *= scale;
+                if (clamp) {
+                    b.x = fminf(fmaxf(b.x, -clipvalue), clipvalue);
+                    b.y = fminf(fmaxf(b.y, -clipvalue), clipvalue);
+                    b.z = fminf(fmaxf(b.z, -clipvalue), clipvalue);
+                    b.w = fminf(fmaxf(b.w, -clipvalue), clipvalue);
+                }
+                *reinterpret_cast<float4*>(g + i) = b;
+            }
+        } else {
+            for (long i = lane; i < len; i += kWave) {
+                float v = g[i] * scale;
+                if (clamp) v = fminf(fmaxf(v, -clipvalue), clipvalue);
+                g[i] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host: mel matrix (fp32 recipe of tf.signal.linear_to_mel_weight_matrix)
 // ---------------------------------------------------------------------------
 // All fp32, one rounding per operation (no FMA contraction); the logarithm is the
@@ -1628,6 +1682,16 @@ extern "C" int iris_mask_apply(void* x, size_t n_outer, size_t axis_len, size_t 
     else
         k_mask_apply<uint64_t><<<grid_for(total), 256, 0, s>>>((uint64_t*)x, n_outer, axis_len, n_inner, bands,
                                                               n_bands, outer_per_group);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float clip_factor, float eps,
+                             float clipvalue, void* stream) {
+    if (!rows_dev) return fail(IRIS_E_INVALID, "iris_agc_clip: rows is NULL");
+    if (n_rows == 0) return IRIS_OK;
+    const int grid = (int)std::min<size_t>((n_rows + 3) / 4, 4096);
+    k_agc_clip<<<grid, 256, 0, (hipStream_t)stream>>>(rows_dev, n_rows, clip_factor, eps, clipvalue);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }

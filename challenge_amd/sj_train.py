@@ -273,6 +273,70 @@ def adaptive_clip_grad(parameters, gradients, clip_factor=0.01, eps=1e-3):
     return new_grads
 
 
+class FusedAGC:
+    """adaptive_clip_grad + clipvalue for a whole model in ONE HIP launch (iris_agc_clip): a
+    device table with one record per output unit (row of a Linear/LSTM weight, output
+    channel of a conv kernel, or a whole 1-D tensor).  The table is rebuilt only when a
+    parameter or gradient buffer moves."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        self._sig = None
+        self._table = None
+        self._slow = []
+
+    @staticmethod
+    def _rows_of(p):
+        if p.dim() <= 1:
+            return 1, p.numel()
+        return p.shape[0], p.numel() // p.shape[0]
+
+    def _build(self):
+        import ctypes as C
+        recs, self._slow = [], []
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                continue
+            rows, length = self._rows_of(p)
+            ok = p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_cuda
+            if p.dim() > 1:
+                ok = ok and p.stride(0) == length and g.stride(0) == length
+                dense = sorted(p.stride()[1:], reverse=True), sorted(g.stride()[1:], reverse=True)
+                ok = ok and all(d[-1] == 1 for d in dense)
+            else:
+                ok = ok and p.is_contiguous() and g.is_contiguous()
+            if not ok:
+                self._slow.append(p)
+                continue
+            base_p, base_g = p.data_ptr(), g.data_ptr()
+            idx = np.arange(rows, dtype=np.int64) * (length * 4)
+            rec = np.empty((rows, 3), np.int64)
+            rec[:, 0], rec[:, 1], rec[:, 2] = base_p + idx, base_g + idx, length
+            recs.append(rec)
+        table = np.concatenate(recs) if recs else np.zeros((0, 3), np.int64)
+        self._table = torch.from_numpy(table).to(self.params[0].device)
+        self._sig = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
+
+    def __call__(self, clip_factor=0.01, eps=1e-3, clipvalue=None):
+        import ctypes as C
+        sig = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
+        if sig != self._sig:
+            self._build()
+        dev = self.params[0].device
+        if self._table.shape[0]:
+            from . import _native as N
+            with torch.cuda.device(dev):
+                rc = N.lib().iris_agc_clip(self._table.data_ptr(), int(self._table.shape[0]), float(clip_factor),
+                                           float(eps), float(clipvalue or 0.0),
+                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            N.check(rc, "iris_agc_clip")
+        for p in self._slow:  # odd layouts: torch path
+            p.grad = adaptive_clip_grad([p], [p.grad], clip_factor, eps)[0]
+            if clipvalue:
+                p.grad.clamp_(-clipvalue, clipvalue)
+
+
 # ---------------------------------------------------------------------------
 # model                                                     sj_train.py:191-255
 # ---------------------------------------------------------------------------
@@ -383,6 +447,7 @@ class CustomModel(nn.Module):
         self.clipvalue: Optional[float] = None
         self.use_agc = True
         object.__setattr__(self, '_ddp', None)  # not a submodule: DDP wraps this very module
+        object.__setattr__(self, '_fused_agc', None)
 
     def forward(self, x):
         """x: [B, n_mels, n_frame, n_chan] (the reference's channels-last input)."""
@@ -408,17 +473,23 @@ class CustomModel(nn.Module):
         clipvalue, optimiser step (sj_train.py:162-188).  Returns {'loss': tensor}."""
         x, y = data
         self.train()
-        self.optimizer.zero_grad(set_to_none=True)
+        fused = self.use_agc and x.is_cuda  # one HIP launch for AGC + clipvalue over the whole model
+        self.optimizer.zero_grad(set_to_none=not fused)  # fused: keep the gradient buffers in place
         y_pred = self._call(x)
         loss = self.loss_fn(y, y_pred)
         loss.backward()  # under DDP the bucketed RCCL all-reduce overlaps with this
-        params = [p for p in self.parameters() if p.grad is not None]
-        if self.use_agc:
-            new = adaptive_clip_grad(params, [p.grad for p in params])
-            for p, g in zip(params, new):
-                p.grad = g
-        if self.clipvalue:
-            torch.nn.utils.clip_grad_value_(params, self.clipvalue)
+        if fused:
+            if self._fused_agc is None:
+                object.__setattr__(self, '_fused_agc', FusedAGC(list(self.parameters())))
+            self._fused_agc(0.01, 1e-3, self.clipvalue)
+        else:
+            params = [p for p in self.parameters() if p.grad is not None]
+            if self.use_agc:
+                new = adaptive_clip_grad(params, [p.grad for p in params])
+                for p, g in zip(params, new):
+                    p.grad = g
+            if self.clipvalue:
+                torch.nn.utils.clip_grad_value_(params, self.clipvalue)
         self.optimizer.step()
         return {'loss': loss.detach()}
 

@@ -177,6 +177,24 @@ int iris_mask_apply(void* x, size_t n_outer, size_t axis_len, size_t n_inner, in
                     const int32_t* bands, int n_bands, size_t outer_per_group, void* stream);
 
 /*
+ * adaptive_clip_grad (sj_train.py:145-155 with unitwise_norm, utils.py:350-366) followed by the
+ * optimiser's element-wise clipvalue (sj_train.py:435), in place on the gradients, one launch for
+ * the whole model.  rows: DEVICE array, one record per output unit (a row of a Linear / LSTM
+ * weight, an output channel of a conv kernel, or a whole 1-D tensor): for each row
+ *     max_norm = max(||param||, eps) * clip_factor
+ *     grad    *= max_norm / max(||grad||, 1e-6)      where ||grad|| >= max_norm
+ *     grad     = clamp(grad, -clipvalue, +clipvalue)  when clipvalue > 0
+ * Runs on the current HIP device.
+ */
+typedef struct {
+    const float* param; /* first element of the row, contiguous */
+    float* grad;
+    int64_t len;
+} iris_agc_row;
+int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float clip_factor, float eps,
+                  float clipvalue, void* stream);
+
+/*
  * Per-kernel timing for bench.py: when enabled, the dominant kernel of
  * iris_wav_to_logmel is bracketed by hipEvents on the launch stream.
  * iris_timing_read synchronises those events and returns the number of

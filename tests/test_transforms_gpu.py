@@ -229,3 +229,29 @@ def test_wave_frontend_device_draw(dev):
     assert fb[..., 1].max() < 16 and np.all(fb[..., 0] + fb[..., 1] < 513 + (fb[..., 1] == 0)) and tb[..., 0].min() >= 0
     x = fe(torch.randn(16, 1, 130816, device=dev) * 0.1)
     assert tuple(x.shape) == (16, 64, 512, 1) and torch.isfinite(x).all()
+
+
+def test_fused_agc_matches_torch_reference(dev):
+    """iris_agc_clip (one launch) == adaptive_clip_grad + clip_grad_value_ (sj_train.py:145-155, :435)."""
+    _, _, S = mods()
+    torch.manual_seed(1)
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '32', '--n_frame', '64', '--n_chan', '2'])
+    model = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    params = list(model.parameters())
+    for i, p in enumerate(params):  # a mix of small and large gradients so that both branches run
+        scale = 10.0 if i % 3 == 0 else (1e-4 if i % 3 == 1 else 0.05)
+        p.grad = (torch.randn_like(p) * scale)
+    ref = S.adaptive_clip_grad(params, [p.grad.clone() for p in params])
+    ref = [torch.clamp(g, -0.01, 0.01) for g in ref]
+    ref_noclip = S.adaptive_clip_grad(params, [p.grad.clone() for p in params])
+    keep = [p.grad.clone() for p in params]
+    agc = S.FusedAGC(params)
+    agc(0.01, 1e-3, 0.01)
+    assert not agc._slow
+    for p, r in zip(params, ref):
+        assert torch.allclose(p.grad, r, rtol=2e-5, atol=1e-9), (tuple(p.shape), float((p.grad - r).abs().max()))
+    for p, g in zip(params, keep):
+        p.grad.copy_(g)
+    agc(0.01, 1e-3, None)
+    for p, r in zip(params, ref_noclip):
+        assert torch.allclose(p.grad, r, rtol=2e-5, atol=1e-9)
