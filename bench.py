@@ -225,10 +225,17 @@ def main():
             result["extra"] = extras
         algo_bytes = ALGO_BYTES_PER_AUDIO_S * audio_s_per_step  # per launch
         achieved = (algo_bytes / (kernel_ms * 1e-3) / 1e9) if n_ev and kernel_ms > 0 else None
+        traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["k_wav_to_mel<10,0,false,false,false>"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         result["roofline"] = {
             "bound": "hbm", "kernel": "k_wav_to_mel<10>",
             "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+            "traffic_source": "profiles/r1/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
             "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_ms": round(kernel_ms, 5) if n_ev else None, "launches_timed": n_ev,
         }

@@ -7,7 +7,7 @@ rm -rf $OUT; mkdir -p $OUT
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o pmc -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o pmc -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events --no-extras > $OUT/p$i.log 2>&1
   f=$(find $OUT/p$i -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections
