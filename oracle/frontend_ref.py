@@ -515,3 +515,37 @@ def wav_to_logmel(wav, n_fft, hop, n_mel, sample_rate=16000, do_minmax=True,
     if do_minmax:
         mel = minmax(mel)
     return log_on_mel(mel)
+
+
+# --------------------------------------------------------------------------
+# eval-path helpers (metrics.py:56-81): tf.signal.frame / overlap_and_add / smoothing
+# --------------------------------------------------------------------------
+def tf_frame(x: np.ndarray, frame_length: int, frame_step: int, axis: int = -2) -> np.ndarray:
+    """tf.signal.frame(..., pad_end=True): ceil(len/step) frames, zero padded at the end."""
+    x = np.moveaxis(np.asarray(x), axis, -1)
+    n = x.shape[-1]
+    num = -(-n // frame_step)
+    need = (num - 1) * frame_step + frame_length
+    if need > n:
+        x = np.concatenate([x, np.zeros(x.shape[:-1] + (need - n,), x.dtype)], -1)
+    out = np.stack([x[..., i * frame_step:i * frame_step + frame_length] for i in range(num)], -2)
+    return out  # [..., num, frame_length]: the framed axis is moved to the end
+
+
+def tf_overlap_and_add(frames: np.ndarray, step: int) -> np.ndarray:
+    w, length = frames.shape[-2:]
+    out = np.zeros(frames.shape[:-2] + ((w - 1) * step + length,), frames.dtype)
+    for i in range(w):
+        out[..., i * step:i * step + length] += frames[..., i, :]
+    return out
+
+
+def pool1d_same(x: np.ndarray, k: int, mode: str) -> np.ndarray:
+    """Keras {Average,Max}Pooling1D(k, strides=1, padding='same') on [T, K]."""
+    t = x.shape[0]
+    left = (k - 1) // 2
+    out = np.empty_like(x)
+    for i in range(t):
+        lo, hi = max(0, i - left), min(t, i - left + k)
+        out[i] = x[lo:hi].max(0) if mode == 'max' else x[lo:hi].mean(0)
+    return out

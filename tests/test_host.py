@@ -235,3 +235,26 @@ def test_fit_loop_with_csv_and_checkpoint(tmp_path):
                  checkpoint_path=str(tmp_path / 'm.pt'), patience=3, verbose=False)
     assert len(hist) == 2 and os.path.exists(tmp_path / 'm.pt')
     assert len(open(tmp_path / 'log.csv').read().strip().splitlines()) == 3
+
+
+def test_inference_chain_helpers_match_oracle():
+    from challenge_amd import inference as I
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((5, 37, 2)).astype(np.float32)           # [M, T, C]
+    fr = I.frame(torch.from_numpy(x), 16, 8, pad_end=True, axis=-2).numpy()  # [M, W, 16, C]
+    ref = R.tf_frame(x, 16, 8, axis=-2)                               # [M, C, W, 16]
+    assert fr.shape == (5, 5, 16, 2)
+    assert np.array_equal(fr.transpose(0, 3, 1, 2), ref)
+    assert I.frame(torch.from_numpy(x), 16, 8, pad_end=False, axis=-2).shape[1] == 3
+    p = rng.random((3, 5, 16)).astype(np.float32)
+    assert np.allclose(I.overlap_and_add(torch.from_numpy(p), 8).numpy(), R.tf_overlap_and_add(p, 8), atol=1e-6)
+    q = rng.random((200, 3)).astype(np.float32)
+    sm = I.smooth(torch.from_numpy(q)).numpy()
+    assert np.allclose(sm, R.pool1d_same(R.pool1d_same(q, 31, 'avg'), 124, 'max'), atol=1e-6)
+    # end to end with a tiny model on CPU features (frames -> model -> overlap-add mean -> smoothing)
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '32', '--n_frame', '64', '--n_chan', '1'])
+    torch.manual_seed(0)
+    model = S.get_model(cfg)
+    feats = torch.randn(32, 150, 1)
+    out = I.predict_frames(model, feats, cfg, overlap_hop=32, smoothing=True)
+    assert tuple(out.shape) == (150, 3) and set(np.unique(out.numpy())) <= {0.0, 1.0}

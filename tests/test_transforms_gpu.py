@@ -255,3 +255,23 @@ def test_fused_agc_matches_torch_reference(dev):
     agc(0.01, 1e-3, None)
     for p, r in zip(params, ref_noclip):
         assert torch.allclose(p.grad, r, rtol=2e-5, atol=1e-9)
+
+
+def test_eval_path_on_gpu(dev):
+    """metrics.evaluate's chain (metrics.py:40-81) without the scoring: features match the
+    oracle, predictions are thresholded frames of the clip's length."""
+    from challenge_amd import inference as I
+    _, D, S = mods()
+    rng = np.random.default_rng(21)
+    wav = rng.standard_normal((2, 40000)).astype(np.float32)
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '80', '--n_frame', '64', '--n_chan', '2'])
+    spec = D.load_wav_array(wav, 16000, dev)
+    feats = I.features_for_eval(spec, cfg)
+    r = R.stft_filter(16)(R.load_wav_array(wav, 512))
+    r = R.log_on_mel(R.minmax(R.magphase_to_mel(80)(R.complex_to_magphase(r))))
+    assert tuple(feats.shape) == r.shape == (80, 157, 2)
+    assert np.abs(np.exp(feats.cpu().numpy()) - np.exp(r)).max() <= 1e-5
+    torch.manual_seed(0)
+    model = S.get_model(cfg).to(dev)
+    out = I.evaluate_wav(model, wav, cfg, 16000, overlap_hop=32, device=dev)
+    assert tuple(out.shape) == (157, 3) and set(np.unique(out.cpu().numpy())) <= {0.0, 1.0}
