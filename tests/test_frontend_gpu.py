@@ -288,3 +288,81 @@ def test_fused_minmax_epilogue_option(golden_dir, dev, monkeypatch):
     tb = np.stack([R.mask_draw(rng, 126, 24, 6) for _ in range(3)]).transpose(0, 2, 1)
     out = plan.wav_to_logmel(wav, t_bands=tb).cpu().numpy()
     assert np.abs(np.exp(out) - np.exp(plan2.wav_to_logmel(wav, t_bands=tb).cpu().numpy())).max() <= 2e-6
+
+
+@pytest.mark.parametrize("n_fft,hop,m,c", [(512, 256, 80, 2), (2048, 512, 128, 2), (256, 64, 40, 1), (1024, 256, 64, 2)])
+def test_bands_all_fft_sizes(dev, n_fft, hop, m, c):
+    """SpecAugment / filter bands inside the fused kernel for every FFT size and mel mode."""
+    rng = np.random.default_rng(n_fft)
+    b, length = 3, 9 * n_fft + 5
+    wav = (rng.standard_normal((b, c, length)) * 0.1).astype(np.float32)
+    n_t, n_f = 1 + length // hop, n_fft // 2 + 1
+    tb = np.stack([np.stack(R.mask_draw(rng, n_t, 6, 3), 1) for _ in range(b)])
+    fb = np.stack([np.stack(R.mask_draw(rng, n_f, 16, 2), 1) for _ in range(b)])
+    plan = FE().FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
+    out = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), minmax=False, log=False, t_bands=tb, f_bands=fb)
+    ref = R.wav_to_mel(wav, n_fft, hop, m, 16000, t_bands=tb, f_bands=fb)
+    assert rel_err(out.cpu().numpy(), ref) <= 1e-5
+    full = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), t_bands=tb, f_bands=fb).cpu().numpy()
+    assert np.abs(np.exp(full) - np.exp(R.wav_to_logmel(wav, n_fft, hop, m, 16000, t_bands=tb, f_bands=fb))).max() <= 5e-6
+
+
+def test_minimal_and_odd_shapes(dev):
+    """Shortest legal clip (one frame more than the reflect pad), odd hop (unaligned frames),
+    odd length, one clip, many clips of one frame."""
+    rng = np.random.default_rng(31)
+    for n_fft, hop, length, b in [(256, 64, 129, 2), (512, 77, 1000, 3), (1024, 255, 4097, 1), (256, 256, 300, 40)]:
+        wav = (rng.standard_normal((b, 1, length)) * 0.3).astype(np.float32)
+        plan = FE().FrontendPlan(n_fft, hop, 32, 16000, 1, b, length, dev, upper_edge_hertz=7000.0)
+        out = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), minmax=False, log=False).cpu().numpy()
+        ref = R.wav_to_mel(wav, n_fft, hop, 32, 16000, upper_edge_hertz=7000.0)
+        assert out.shape == ref.shape == (b, 32, 1 + length // hop, 1)
+        assert rel_err(out, ref) <= 1e-5
+        spec = plan.stft(torch.from_numpy(wav).to(dev)).cpu().numpy()
+        full = np.stack([R.to_ref_layout(R.stft(wav[i], n_fft, hop)) for i in range(b)])
+        assert np.abs(spec - full).max() <= 3e-6 * np.abs(full).max()
+
+
+def test_side_stream_and_graph_capture(dev):
+    """The entry points only enqueue on the caller's stream: they work on a side stream and
+    inside hipGraph capture (no allocation, no synchronisation), and the replayed graph
+    reproduces the eager result."""
+    rng = np.random.default_rng(41)
+    wav = torch.from_numpy((rng.standard_normal((4, 1, 20000)) * 0.1).astype(np.float32)).to(dev)
+    plan = FE().FrontendPlan(1024, 256, 64, 16000, 1, 4, 20000, dev)
+    eager = plan.wav_to_logmel(wav).clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        out_side = plan.wav_to_logmel(wav)
+    side.synchronize()
+    assert torch.equal(out_side, eager)
+    static_out = torch.empty_like(eager)
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        plan.wav_to_logmel(wav, out=static_out)      # warm-up on the capture stream
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        plan.wav_to_logmel(wav, out=static_out)
+    static_out.zero_()
+    wav2 = wav * 0.5 + 0.01
+    wav.copy_(wav2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, plan.wav_to_logmel(wav))
+
+
+def test_two_plans_interleaved(dev):
+    """Distinct plans are independent: interleaved launches on one stream do not disturb
+    each other's workspace."""
+    rng = np.random.default_rng(43)
+    a = torch.from_numpy((rng.standard_normal((5, 1, 12000)) * 0.1).astype(np.float32)).to(dev)
+    b = torch.from_numpy((rng.standard_normal((3, 2, 9000)) * 0.1).astype(np.float32)).to(dev)
+    pa = FE().FrontendPlan(1024, 256, 64, 16000, 1, 5, 12000, dev)
+    pb = FE().FrontendPlan(512, 256, 80, 16000, 2, 3, 9000, dev)
+    ra, rb = pa.wav_to_logmel(a).clone(), pb.wav_to_logmel(b).clone()
+    for _ in range(3):
+        oa, ob = pa.wav_to_logmel(a), pb.wav_to_logmel(b)
+        oa2 = pa.wav_to_logmel(a)
+        assert torch.equal(oa, ra) and torch.equal(ob, rb) and torch.equal(oa2, ra)
