@@ -105,22 +105,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Block-wide (256 threads) min/max; result valid in every thread.
-__device__ __forceinline__ void block_minmax(float& mn, float& mx, float* red /*[16]*/) {
+// Block-wide min/max (up to 16 waves); result valid in every thread.  red: 32 floats.
+__device__ __forceinline__ void block_minmax(float& mn, float& mx, float* red /*[32]*/) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     mn = wave_min(mn);
     mx = wave_max(mx);
     __syncthreads();
     if (lane == 0) {
         red[w] = mn;
-        red[8 + w] = mx;
+        red[16 + w] = mx;
     }
     __syncthreads();
     mn = red[0];
-    mx = red[8];
+    mx = red[16];
     for (int i = 1; i < nw; ++i) {
         mn = fminf(mn, red[i]);
-        mx = fmaxf(mx, red[8 + i]);
+        mx = fmaxf(mx, red[16 + i]);
     }
 }
 
@@ -255,7 +255,7 @@ __device__ __forceinline__ void load_consts(const float* consts, int lane, cf (&
 // ---------------------------------------------------------------------------
 // K1: fused wav -> mel magnitudes (+ per-chunk min/max partials)
 //   work unit = chunk: `chunk_frames` consecutive frames of one clip, all C channels
-//   grid      = min(#chunks, fused_occ per CU) workgroups of 4 waves looping over chunks
+//   grid      = min(#chunks, #CUs) workgroups of 12 waves (n_fft 2048: 8) looping over chunks
 //   per wave  = one frame at a time:
 //                 LDS-DMA (global_load_lds) of the NEXT frame into the wave's frame
 //                 buffer -- no VGPRs, reflect padding resolved in the DMA's per-lane
@@ -263,17 +263,19 @@ __device__ __forceinline__ void load_consts(const float* consts, int lane, cf (&
 //                 (registers + private padded LDS exchanges), untangled, |X| written
 //                 to LDS and reduced over the banded mel weights
 //   LDS       = per wave [frame buffer N floats | exchange buffer] | out tile
-//               [M][chunk_frames*C+1] | red[32] | mel table (mode 1)
+//               [M][chunk_frames*C+1] | red[48] | mel table (mode 1)
 //   MELMODE 0 = band weights in registers (M <= 64, band length <= 16): each lane reads
 //               a 16-byte-aligned window of 20 magnitudes with 5 ds_read_b128
 //           1 = band table staged in LDS, 2 = band table read from global (L1/L2)
 //   HI        = some band needs bins above n_fft/4 (both halves of the untangle)
 //   BANDS     = SpecAugment / filter bands present
 // ---------------------------------------------------------------------------
-constexpr int kFusedWaves = 4;   // waves per workgroup
+// waves per workgroup: one workgroup per CU holding every wave of the CU, so that all waves are
+// of one age class for the issue arbiter (which favours older waves) and share one frame queue
 // workgroups per CU (= waves per SIMD): 3 -> <= 168 VGPRs; n_fft 2048 keeps 16 points per
 // lane and needs the 256-VGPR budget of 2
-constexpr int fused_occ(int log2n) { return log2n >= 11 ? 2 : 3; }
+constexpr int fused_occ(int log2n) { return 1; }
+constexpr int fused_waves(int log2n) { return log2n >= 11 ? 8 : 12; }  // 2 resp. 3 waves per SIMD
 
 struct FusedArgs {
     const float* wav;    // [B, C, L]
@@ -381,7 +383,8 @@ __device__ __forceinline__ void dma_frame(const float* clip, int len, int start,
 }
 
 template <int LOG2N, int MELMODE, bool HI, bool BANDS, bool FUSE>
-__global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_mel(const FusedArgs a) {
+__global__ __launch_bounds__(64 * fused_waves(LOG2N), fused_waves(LOG2N) / 4) void k_wav_to_mel(const FusedArgs a) {
+    constexpr int kFusedWaves = fused_waves(LOG2N);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
     constexpr int F = NC + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -397,8 +400,9 @@ __global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_m
     cf* lds = reinterpret_cast<cf*>(smem + wv * kWaveBytes + N * 4);
     float* magbuf = reinterpret_cast<float*>(lds);
     float* tile_out = reinterpret_cast<float*>(smem + kFusedWaves * kWaveBytes);
-    float* red = tile_out + a.M * tile_stride;  // [32]
-    float* wtab = red + 32;                     // MELMODE 1: [rows][M] then int lo[M]
+    float* red = tile_out + a.M * tile_stride;  // [48]: block_minmax [0,32), fused epilogue [32,34), frame queue [40]
+    int* next_frame = reinterpret_cast<int*>(red + 40);  // next unclaimed wave-frame of the current chunk
+    float* wtab = red + 48;                     // MELMODE 1: [rows][M] then int lo[M]
     int* lotab = reinterpret_cast<int*>(wtab + a.rows * a.M);
 
     unsigned long long real_entry = 0;
@@ -411,8 +415,9 @@ __global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_m
     if constexpr (MELMODE == 1) {
         for (int i = threadIdx.x; i < a.rows * a.M; i += blockDim.x) wtab[i] = a.wband[i];
         for (int i = threadIdx.x; i < a.M; i += blockDim.x) lotab[i] = a.band_lo[i];
-        __syncthreads();
     }
+    if (threadIdx.x == 0) *next_frame = kFusedWaves;
+    __syncthreads();
     const float4* mag4 = reinterpret_cast<const float4*>(magbuf + lo0);  // lo0 is a multiple of 4
     float* my_tile = tile_out + lane * tile_stride;
 
@@ -424,8 +429,9 @@ __global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_m
     const int g0 = xcd_remap(blockIdx.x, gridDim.x);
     for (int chunk = g0; chunk < a.n_chunks; chunk += gridDim.x) {
         const int b = chunk / a.chunks_per_clip, ci = chunk - b * a.chunks_per_clip;
-        const int t0 = ci * a.chunk_frames;
-        const int nt = min(a.chunk_frames, a.T - t0);
+        // balanced split of the clip's T frames over its chunks (sizes differ by at most one)
+        const int t0 = (int)(((long)ci * a.T) / a.chunks_per_clip);
+        const int nt = (int)(((long)(ci + 1) * a.T) / a.chunks_per_clip) - t0;
         const int* tb = nullptr;
         const int* fb = nullptr;
         if constexpr (BANDS) {
@@ -443,9 +449,14 @@ __global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_m
         }
 
         const int nwf = nt * a.C;  // wave-frames in this chunk: f = tl * C + c
+        // frame cursor, all wave-uniform and updated incrementally (no multiplies in the loop):
+        //   c, tl       channel and local frame of wave-frame f
+        //   start       first sample of that frame (may be negative / run past the end: reflect)
+        //   clip        first sample of channel c of this clip
         int f = wv, tl = wv / a.C, c = wv - tl * a.C;
-        if (f < nwf && !ABL(8))
-            dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds, lane);
+        int start = (t0 + tl) * a.hop - N / 2;
+        const float* clip = clip0 + (size_t)c * a.L;
+        if (f < nwf && !ABL(8)) dma_frame<LOG2N>(clip, a.L, start, fbuf_lds, lane);
         while (f < nwf) {
             // frame f has landed; pull it into registers, then reuse the buffer for the next one
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -457,14 +468,18 @@ __global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_m
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int fcur = f, tcur = t0 + tl;
-            f += kFusedWaves;
-            c += kFusedWaves;
-            while (c >= a.C) {
-                c -= a.C;
-                ++tl;
+            // claim the next frame of the chunk (waves that run ahead take more frames: the
+            // issue arbiter favours older waves, a static split would leave the others a tail)
+            {
+                int nf = 0;
+                if (lane == 0) nf = atomicAdd(next_frame, 1);
+                f = __builtin_amdgcn_readfirstlane(nf);
             }
-            if (f < nwf && !ABL(8))
-                dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds, lane);
+            tl = (a.C == 1) ? f : f / a.C;
+            c = f - tl * a.C;
+            start = (t0 + tl) * a.hop - N / 2;
+            clip = clip0 + (size_t)c * a.L;
+            if (f < nwf && !ABL(8)) dma_frame<LOG2N>(clip, a.L, start, fbuf_lds, lane);
 
             if constexpr (BANDS) {
                 const bool masked = tb ? in_bands(tb, a.n_tb, tcur) : false;  // wave-uniform
@@ -552,6 +567,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_m
             if (threadIdx.x == 0) {
                 a.partial[(size_t)chunk * 2 + 0] = mn;
                 a.partial[(size_t)chunk * 2 + 1] = mx;
+                *next_frame = kFusedWaves;
             }
             __syncthreads();
         } else {
@@ -599,12 +615,12 @@ __global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_m
                     lo = key2f((unsigned)(pk & 0xffffffffull));
                     hi = key2f((unsigned)(pk >> 32));
                 }
-                red[16] = lo;
-                red[17] = fmaxf(hi - lo, 1e-8f);
+                red[32] = lo;
+                red[33] = fmaxf(hi - lo, 1e-8f);
             }
             __syncthreads();
-            gmn = red[16];
-            den = red[17];
+            gmn = red[32];
+            den = red[33];
         }
         for (int m = wv; m < a.M; m += kFusedWaves) {
             float* dst = a.out + (((size_t)b * a.M + m) * a.T + t0) * a.C;
@@ -616,6 +632,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, fused_occ(LOG2N)) void k_wav_to_m
                 dst[r] = v;
             }
         }
+        if (threadIdx.x == 0) *next_frame = kFusedWaves;
         if (a.do_minmax && threadIdx.x == 0) {
             // done with the clip's line (off the critical path): the clip's last chunk to get
             // here re-arms it for the next launch
@@ -764,7 +781,7 @@ __global__ __launch_bounds__(256) void k_magmel(const MagmelArgs a) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_minmax_partial(const float* x, float* partial, size_t row_len,
                                                         int n_part) {
-    __shared__ float red[16];
+    __shared__ float red[32];
     const int row = blockIdx.y, part = blockIdx.x;
     const float* p = x + (size_t)row * row_len;
     const size_t beg = (size_t)part * kChunk, end = min(beg + (size_t)kChunk, row_len);
@@ -784,7 +801,7 @@ __global__ __launch_bounds__(256) void k_minmax_partial(const float* x, float* p
 __global__ __launch_bounds__(256) void k_minmax_log_apply(float* x, const float* partial, int n_part,
                                                           size_t row_len, int do_minmax, int do_log,
                                                           float eps_div, float eps_log) {
-    __shared__ float red[16];
+    __shared__ float red[32];
     const int row = blockIdx.y;
     float mn = 0.f, den = 1.f;
     if (do_minmax) {
@@ -1089,8 +1106,8 @@ static int upload(T** dst, const std::vector<T>& src) {
 
 static size_t fused_lds_bytes(const iris_plan* p, int chunk_frames) {
     const size_t xbuf = (wave_buf_bytes(p->log2n) + 15) & ~(size_t)15;
-    size_t bytes = (size_t)kFusedWaves * ((size_t)p->n_fft * 4 + xbuf);
-    bytes += ((size_t)p->n_mel * (chunk_frames * p->channels + 1) + 32) * 4;
+    size_t bytes = (size_t)fused_waves(p->log2n) * ((size_t)p->n_fft * 4 + xbuf);
+    bytes += ((size_t)p->n_mel * (chunk_frames * p->channels + 1) + 48) * 4;
     if (p->mel_mode == 1) bytes += ((size_t)p->rows * p->n_mel + p->n_mel) * 4;
     return bytes;
 }
@@ -1231,7 +1248,8 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->need_hi = p->k_need > NC / 2 ? 1 : 0;
     // bins the kernel writes to its magnitude buffer: [0, limit)
     const int limit = p->need_hi ? ((n_bins + 3) & ~3) : NC / 2;
-    if (n_mel <= 64 && p->max_band_len + 3 <= kMelRegs && limit >= kMelRegs) {
+    // (n_fft 2048 keeps 16 points per lane: no registers to spare for the weights -> table modes)
+    if (log2n <= 10 && n_mel <= 64 && p->max_band_len + 3 <= kMelRegs && limit >= kMelRegs) {
         p->mel_mode = 0;  // 16-byte aligned register window of kMelRegs bins per band
         p->rows = kMelRegs;
     } else {
@@ -1356,6 +1374,15 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
             l0 = std::min(l0, r[1]); l1 = std::max(l1, r[1]);
             x0 = std::min(x0, r[2]); x1 = std::max(x1, r[2]);
             pro += (double)(r[1] - r[0]); loop += (double)(r[2] - r[1]);
+        }
+        if (const char* path = getenv("IRIS_DBG_DUMP")) {
+            if (FILE* fp = fopen(path, "w")) {
+                for (int i = 0; i < 4096; ++i) {
+                    const unsigned long long* r = &h[4 + 3 * i];
+                    if (r[0]) fprintf(fp, "%d %llu %llu %llu\n", i, r[0] - e0, r[1] - e0, r[2] - e0);
+                }
+                fclose(fp);
+            }
         }
         if (n)
             fprintf(stderr, "[iris dbg] %d workgroups (last launch): entry spread %.2f us, loop-start spread %.2f us, "
@@ -1546,11 +1573,21 @@ static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int
                            int* chunks_per_clip) {
     const int slots = p->num_cu * per_cu;
     const long total = (long)batch * T;
-    int cap = 128;  // frames; keeps the LDS out tile <= 48 KiB
-    while (cap > 1 && (size_t)p->n_mel * (cap * p->channels + 1) * 4 > 48 * 1024) cap /= 2;
+    // frames per chunk are capped by the LDS left for the out tile (one workgroup per CU owns
+    // the whole 160 KiB)
+    const size_t fixed = fused_lds_bytes(p, 0) + 1024;
+    const size_t room = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
+    int cap = 512;
+    while (cap > 1 && (size_t)p->n_mel * (cap * p->channels) * 4 > room) --cap;
     int target = p->chunk_target > 0 ? p->chunk_target : (int)((total + slots - 1) / slots);
     target = std::max(std::min(target, cap), std::min(8, cap));
-    const int cpc = (T + target - 1) / target;
+    int cpc = (T + target - 1) / target;
+    // rounding up per clip can overshoot the slots by a few chunks, which would cost a whole
+    // second round: prefer slightly larger chunks that fit one round
+    if ((long)batch * cpc > slots && batch <= slots) {
+        const int fit = slots / batch;
+        if (fit >= 1 && (T + fit - 1) / fit <= cap) cpc = fit;
+    }
     *chunks_per_clip = cpc;
     *chunk_frames = (T + cpc - 1) / cpc;
 }
@@ -1568,7 +1605,7 @@ static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, in
         if (*lds > 160 * 1024) continue;
         int resident = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
-                                                                    64 * kFusedWaves, *lds);
+                                                                    64 * fused_waves(p->log2n), *lds);
         if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s",
                                          hipGetErrorString(e));
         if (resident >= per_cu) {
@@ -1648,11 +1685,11 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         }
         FusedArgs args = a;
         void* kargs[] = {&args};
-        e = hipExtLaunchKernel((const void*)kernel, dim3(grid), dim3(64 * kFusedWaves), kargs, lds, s,
+        e = hipExtLaunchKernel((const void*)kernel, dim3(grid), dim3(64 * fused_waves(p->log2n)), kargs, lds, s,
                                p->ev[2 * p->ev_used], p->ev[2 * p->ev_used + 1], 0);
         if (e == hipSuccess) p->ev_used++;
     } else {
-        kernel<<<grid, 64 * kFusedWaves, lds, s>>>(a);
+        kernel<<<grid, 64 * fused_waves(p->log2n), lds, s>>>(a);
         e = hipGetLastError();
     }
     HIP_TRY(e);
