@@ -806,11 +806,18 @@ __global__ __launch_bounds__(256) void k_minmax_log_apply(float* x, const float*
     float mn = 0.f, den = 1.f;
     if (do_minmax) {
         float lo = INFINITY, hi = -INFINITY;
-        for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
-            lo = fminf(lo, partial[((size_t)row * n_part + i) * 2 + 0]);
-            hi = fmaxf(hi, partial[((size_t)row * n_part + i) * 2 + 1]);
+        if (n_part <= 64) {  // few partials: every thread folds them itself (uniform loads, no barrier)
+            for (int i = 0; i < n_part; ++i) {
+                lo = fminf(lo, partial[((size_t)row * n_part + i) * 2 + 0]);
+                hi = fmaxf(hi, partial[((size_t)row * n_part + i) * 2 + 1]);
+            }
+        } else {
+            for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
+                lo = fminf(lo, partial[((size_t)row * n_part + i) * 2 + 0]);
+                hi = fmaxf(hi, partial[((size_t)row * n_part + i) * 2 + 1]);
+            }
+            block_minmax(lo, hi, red);
         }
-        block_minmax(lo, hi, red);
         mn = lo;
         den = fmaxf(hi - lo, eps_div);
     }
