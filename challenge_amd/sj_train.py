@@ -569,7 +569,8 @@ def wrap_ddp(model: CustomModel, device, world: int):
 
 
 def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=None, validation_steps=16,
-        scheduler=None, csv_path=None, checkpoint_path=None, patience=None, rank=0, world=1, verbose=True):
+        scheduler=None, csv_path=None, checkpoint_path=None, patience=None, rank=0, world=1, verbose=True,
+        swa=None):
     """Minimal Keras-fit equivalent for this path: per-epoch LR schedule, CSV log,
     best-val-loss checkpoint, early stopping, TerminateOnNaN (sj_train.py:489-519)."""
     best, bad, history = math.inf, 0, []
@@ -597,6 +598,8 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
             vl = torch.stack([model.test_step(next(vit))['loss'] for _ in range(validation_steps)]).mean()
             row['val_loss'] = float(vl)
         history.append(row)
+        if swa is not None:
+            swa.on_epoch_end(epoch, model)
         if rank == 0:
             if verbose:
                 print(row)
@@ -640,10 +643,19 @@ def main(argv=None):
         model.load_state_dict(torch.load(NAME.replace('.h5', '.pt'), map_location=device))
     train_set = make_dataset(config, training=True)
     test_set = make_dataset(config, training=False)
+    from .swa import NO_SWA_ERROR, SWA
+    swa = SWA(start_epoch=config.epochs // 4, swa_freq=2)  # sj_train.py:491
     fit(model, train_set, config.epochs, config.steps_per_epoch, test_set, config.validation_steps,
         scheduler=custom_scheduler(4096, config.epochs / 12, config.lr_div),
         csv_path=NAME.replace('.h5', '.csv'), checkpoint_path=NAME.replace('.h5', '.pt'),
-        patience=config.patience, rank=rank, world=world)
+        patience=config.patience, rank=rank, world=world, swa=swa)
+    try:
+        swa.finalize(model)
+        if rank == 0:
+            torch.save(model.state_dict(), NAME.replace('.h5', '_SWA.pt'))
+            print('best model:', NAME.replace('.h5', '_SWA.pt'))
+    except NO_SWA_ERROR:
+        pass
     if world > 1:
         torch.distributed.destroy_process_group()
     if rank == 0:

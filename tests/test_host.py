@@ -258,3 +258,21 @@ def test_inference_chain_helpers_match_oracle():
     feats = torch.randn(32, 150, 1)
     out = I.predict_frames(model, feats, cfg, overlap_hop=32, smoothing=True)
     assert tuple(out.shape) == (150, 3) and set(np.unique(out.numpy())) <= {0.0, 1.0}
+
+
+def test_swa_running_average():
+    from challenge_amd.swa import NO_SWA_ERROR, SWA
+    lin = torch.nn.Linear(2, 1)
+    swa = SWA(start_epoch=2, swa_freq=2)
+    with pytest.raises(NO_SWA_ERROR):
+        swa.finalize(lin)
+    vals = []
+    for epoch in range(6):
+        with torch.no_grad():
+            lin.weight.fill_(float(epoch))
+        swa.on_epoch_end(epoch, lin)
+        if epoch >= 1 and (epoch - 1) % 2 == 0:
+            vals.append(float(epoch))
+    swa.finalize(lin)
+    assert swa.n_models == len(vals) == 3
+    assert torch.allclose(lin.weight, torch.full_like(lin.weight, sum(vals) / len(vals)))
