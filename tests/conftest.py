@@ -24,10 +24,7 @@ def pytest_sessionstart(session):
     (hipcc cross-compiles gfx950 without a GPU)."""
     so = os.path.join(ROOT, "challenge_amd", "csrc", "libiris_frontend.so")
     src = os.path.join(ROOT, "challenge_amd", "csrc", "iris_frontend.hip")
-    stale = os.path.exists(so) and any(
-        os.path.getmtime(os.path.join(ROOT, f)) > os.path.getmtime(so)
-        for f in ("challenge_amd/csrc/iris_frontend.hip", "challenge_amd/csrc/iris_fft.h", "include/iris_frontend.h"))
-    if (not os.path.exists(so) or stale) and os.path.exists(src):
+    if not os.path.exists(so) and os.path.exists(src):
         import shutil
         if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
             import __graft_entry__
