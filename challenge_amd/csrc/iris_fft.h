@@ -123,11 +123,13 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One Stockham stage.  x[q] = data[lane + 64 q] on entry and on exit.
-// NS = product of the radices of the earlier stages.  tw: (P/R)*(R-1) per-lane
-// twiddles exp(-2 pi i ((lane + 64u) mod NS) t / (NS R)), index u*(R-1) + t-1.
+// One Stockham stage, split so that several independent frames ("streams") of one wave can be
+// interleaved: stage_fwd = twiddles + butterflies (+ the strided LDS writes unless LAST),
+// stage_load = the unit-stride reads that bring the data back to x[q] = data[lane + 64 q].
+// NS = product of the radices of the earlier stages.  tw: (P/R)*(R-1) per-lane twiddles
+// exp(-2 pi i ((lane + 64u) mod NS) t / (NS R)), index u*(R-1) + t-1.
 template <int P, int R, int NS, bool LAST>
-__device__ __forceinline__ void fft_stage(cf (&x)[P], const cf* tw, cf* lds, int lane) {
+__device__ __forceinline__ void stage_fwd(cf (&x)[P], const cf* tw, cf* lds, int lane) {
     constexpr int U = P / R, PM = stage_pm(NS, R);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -149,11 +151,25 @@ __device__ __forceinline__ void fft_stage(cf (&x)[P], const cf* tw, cf* lds, int
             for (int t = 0; t < R; ++t) wp[lds_pad<PM>(t * NS)] = v[t];
         }
     }
+}
+
+template <int P, int R, int NS>
+__device__ __forceinline__ void stage_load(cf (&x)[P], const cf* lds, int lane) {
+    constexpr int PM = stage_pm(NS, R);
+    const cf* rp = lds + lds_pad<PM>(lane);
+#pragma unroll
+    for (int q = 0; q < P; ++q) x[q] = rp[lds_pad<PM>(kWave * q)];
+}
+
+// The same stage for S streams: all butterflies and writes, one ordering point, all reads.
+template <int S, int P, int R, int NS, bool LAST>
+__device__ __forceinline__ void stage_multi(cf (&x)[S][P], const cf* tw, cf* const (&lds)[S], int lane) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) stage_fwd<P, R, NS, LAST>(x[s], tw, lds[s], lane);
     if constexpr (!LAST) {
         wave_sync_lds();
-        const cf* rp = lds + lds_pad<PM>(lane);
 #pragma unroll
-        for (int q = 0; q < P; ++q) x[q] = rp[lds_pad<PM>(kWave * q)];
+        for (int s = 0; s < S; ++s) stage_load<P, R, NS>(x[s], lds[s], lane);
         wave_sync_lds();
     }
 }
@@ -179,30 +195,39 @@ struct FftCfg<8> {  // n_fft 256: NC 128 = 2^7
     static constexpr int P = 2, NSTAGE = 7, NTW = 6, PMMAX = 8;
 };
 
+// Complex FFT of S frames held by one wave (S = 1: one frame; S = 2: two frames in flight, so
+// that the LDS round trip of one hides behind the butterflies of the other).
+template <int LOG2N, int S>
+__device__ __forceinline__ void fft_frames(cf (&x)[S][FftCfg<LOG2N>::P], const cf* tw, cf* const (&lds)[S],
+                                           int lane) {
+    if constexpr (LOG2N == 11) {
+        stage_multi<S, 16, 16, 1, false>(x, nullptr, lds, lane);
+        stage_multi<S, 16, 16, 16, false>(x, tw, lds, lane);
+        stage_multi<S, 16, 4, 256, true>(x, tw + 15, lds, lane);
+    } else if constexpr (LOG2N == 10) {
+        stage_multi<S, 8, 8, 1, false>(x, nullptr, lds, lane);
+        stage_multi<S, 8, 8, 8, false>(x, tw, lds, lane);
+        stage_multi<S, 8, 8, 64, true>(x, tw + 7, lds, lane);
+    } else if constexpr (LOG2N == 9) {
+        stage_multi<S, 4, 4, 1, false>(x, nullptr, lds, lane);
+        stage_multi<S, 4, 4, 4, false>(x, tw, lds, lane);
+        stage_multi<S, 4, 4, 16, false>(x, tw + 3, lds, lane);
+        stage_multi<S, 4, 4, 64, true>(x, tw + 6, lds, lane);
+    } else {
+        stage_multi<S, 2, 2, 1, false>(x, nullptr, lds, lane);
+        stage_multi<S, 2, 2, 2, false>(x, tw + 0, lds, lane);
+        stage_multi<S, 2, 2, 4, false>(x, tw + 1, lds, lane);
+        stage_multi<S, 2, 2, 8, false>(x, tw + 2, lds, lane);
+        stage_multi<S, 2, 2, 16, false>(x, tw + 3, lds, lane);
+        stage_multi<S, 2, 2, 32, false>(x, tw + 4, lds, lane);
+        stage_multi<S, 2, 2, 64, true>(x, tw + 5, lds, lane);
+    }
+}
+
 template <int LOG2N>
 __device__ __forceinline__ void fft_frame(cf (&x)[FftCfg<LOG2N>::P], const cf* tw, cf* lds, int lane) {
-    if constexpr (LOG2N == 11) {
-        fft_stage<16, 16, 1, false>(x, nullptr, lds, lane);
-        fft_stage<16, 16, 16, false>(x, tw, lds, lane);
-        fft_stage<16, 4, 256, true>(x, tw + 15, lds, lane);
-    } else if constexpr (LOG2N == 10) {
-        fft_stage<8, 8, 1, false>(x, nullptr, lds, lane);
-        fft_stage<8, 8, 8, false>(x, tw, lds, lane);
-        fft_stage<8, 8, 64, true>(x, tw + 7, lds, lane);
-    } else if constexpr (LOG2N == 9) {
-        fft_stage<4, 4, 1, false>(x, nullptr, lds, lane);
-        fft_stage<4, 4, 4, false>(x, tw, lds, lane);
-        fft_stage<4, 4, 16, false>(x, tw + 3, lds, lane);
-        fft_stage<4, 4, 64, true>(x, tw + 6, lds, lane);
-    } else {
-        fft_stage<2, 2, 1, false>(x, nullptr, lds, lane);
-        fft_stage<2, 2, 2, false>(x, tw + 0, lds, lane);
-        fft_stage<2, 2, 4, false>(x, tw + 1, lds, lane);
-        fft_stage<2, 2, 8, false>(x, tw + 2, lds, lane);
-        fft_stage<2, 2, 16, false>(x, tw + 3, lds, lane);
-        fft_stage<2, 2, 32, false>(x, tw + 4, lds, lane);
-        fft_stage<2, 2, 64, true>(x, tw + 5, lds, lane);
-    }
+    cf* const one[1] = {lds};
+    fft_frames<LOG2N, 1>(reinterpret_cast<cf(&)[1][FftCfg<LOG2N>::P]>(x), tw, one, lane);
 }
 
 }  // namespace iris

@@ -68,6 +68,7 @@ struct iris_plan {
     float* d_ws;  // workspace
     unsigned long long* d_dbg;  // diagnostic stamps
     unsigned* d_sync;           // [max_batch][kSyncStride] clip lines, then [1] timeout
+    int streams;                // IRIS_STREAMS: frames in flight per wave (1 or 2)
     int fuse_epilogue;          // IRIS_FUSE_MINMAX=1: min-max/log inside K1 (default 0: measured slower)
     size_t ws_floats;
     int num_cu;
@@ -175,39 +176,55 @@ __device__ __forceinline__ void load_frame(cf (&x)[FftCfg<LOG2N>::P], const floa
 // x[q] = Z[lane + 64 q] -> Xlo[q] = X[k], Xhi[q] = X[NC - k], k = lane + 64 q, q < P/2.
 // HALF = false leaves out the factor 0.5 (outputs are 2 X).  Uses the wave's LDS
 // buffer; ends with the buffer free for reuse.
+template <int LOG2N, bool HI, bool HALF, int S>
+__device__ __forceinline__ void untangle_multi(const cf (&x)[S][FftCfg<LOG2N>::P], const cf* post, cf* const (&lds)[S],
+                                               int lane, cf (&xlo)[S][FftCfg<LOG2N>::P / 2],
+                                               cf (&xhi)[S][FftCfg<LOG2N>::P / 2]) {
+    constexpr int P = FftCfg<LOG2N>::P;
+    // partners of k = lane + 64 q (q < P/2) are NC - k = (64 - lane) + 64 (P - 1 - q), i.e.
+    // rows P/2 .. P-1 (lane 0 reads row P - q, lane 0): only the upper half is ever fetched
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        cf* wp = lds[s] + lds_pad<1>(lane);
+#pragma unroll
+        for (int q = P / 2; q < P; ++q) wp[lds_pad<1>(kWave * q)] = x[s][q];
+    }
+    wave_sync_lds();
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        // lane 0, q 0 pairs with itself (slot NC is addressable but unused)
+        const cf* rp = lds[s] + lds_pad<1>(kWave - lane);
+#pragma unroll
+        for (int q = 0; q < P / 2; ++q) {
+            const cf zk = x[s][q];
+            cf zp = rp[lds_pad<1>(kWave * (P - 1 - q))];
+            if (q == 0 && lane == 0) zp = zk;
+            const cf zc = mk(zp.x, -zp.y);  // conj(Z[NC-k])
+            cf e = zk + zc;                 // 2 E
+            const cf d = zk - zc;           // 2 i O
+            cf o = mk(d.y, -d.x);           // 2 O
+            if constexpr (HALF) {
+                e *= 0.5f;
+                o *= 0.5f;
+            }
+            const cf wo = cmul(o, post[q]);
+            xlo[s][q] = e + wo;
+            if constexpr (HI) {
+                const cf t = e - wo;
+                xhi[s][q] = mk(t.x, -t.y);
+            }
+        }
+    }
+    wave_sync_lds();
+}
+
 template <int LOG2N, bool HI, bool HALF>
 __device__ __forceinline__ void untangle(const cf (&x)[FftCfg<LOG2N>::P], const cf* post, cf* lds, int lane,
                                          cf (&xlo)[FftCfg<LOG2N>::P / 2], cf (&xhi)[FftCfg<LOG2N>::P / 2]) {
     constexpr int P = FftCfg<LOG2N>::P;
-    // partners of k = lane + 64 q (q < P/2) are NC - k = (64 - lane) + 64 (P - 1 - q), i.e.
-    // rows P/2 .. P-1 (lane 0 reads row P - q, lane 0): only the upper half is ever fetched
-    cf* wp = lds + lds_pad<1>(lane);
-#pragma unroll
-    for (int q = P / 2; q < P; ++q) wp[lds_pad<1>(kWave * q)] = x[q];
-    wave_sync_lds();
-    // lane 0, q 0 pairs with itself (slot NC is addressable but unused)
-    const cf* rp = lds + lds_pad<1>(kWave - lane);
-#pragma unroll
-    for (int q = 0; q < P / 2; ++q) {
-        const cf zk = x[q];
-        cf zp = rp[lds_pad<1>(kWave * (P - 1 - q))];
-        if (q == 0 && lane == 0) zp = zk;
-        const cf zc = mk(zp.x, -zp.y);  // conj(Z[NC-k])
-        cf e = zk + zc;                 // 2 E
-        const cf d = zk - zc;           // 2 i O
-        cf o = mk(d.y, -d.x);           // 2 O
-        if constexpr (HALF) {
-            e *= 0.5f;
-            o *= 0.5f;
-        }
-        const cf wo = cmul(o, post[q]);
-        xlo[q] = e + wo;
-        if constexpr (HI) {
-            const cf t = e - wo;
-            xhi[q] = mk(t.x, -t.y);
-        }
-    }
-    wave_sync_lds();
+    cf* const one[1] = {lds};
+    untangle_multi<LOG2N, HI, HALF, 1>(reinterpret_cast<const cf(&)[1][P]>(x), post, one, lane,
+                                       reinterpret_cast<cf(&)[1][P / 2]>(xlo), reinterpret_cast<cf(&)[1][P / 2]>(xhi));
 }
 
 __device__ __forceinline__ float cabs_rn(cf v) { return __builtin_amdgcn_sqrtf(fmaf(v.x, v.x, v.y * v.y)); }
@@ -275,7 +292,9 @@ __device__ __forceinline__ void load_consts(const float* consts, int lane, cf (&
 // workgroups per CU (= waves per SIMD): 3 -> <= 168 VGPRs; n_fft 2048 keeps 16 points per
 // lane and needs the 256-VGPR budget of 2
 constexpr int fused_occ(int log2n) { return 1; }
-constexpr int fused_waves(int log2n) { return log2n >= 11 ? 8 : 12; }  // 2 resp. 3 waves per SIMD
+// waves per workgroup: 3 per SIMD with one frame per wave (168 VGPRs); 2 per SIMD when a wave keeps
+// two frames in flight or at n_fft 2048 (256 VGPRs)
+constexpr int fused_waves(int log2n, int streams = 1) { return (log2n >= 11 || streams > 1) ? 8 : 12; }
 
 struct FusedArgs {
     const float* wav;    // [B, C, L]
@@ -382,9 +401,9 @@ __device__ __forceinline__ void dma_frame(const float* clip, int len, int start,
         dma_frame_x1<LOG2N>(clip, len, start, fbuf_lds, lane);
 }
 
-template <int LOG2N, int MELMODE, bool HI, bool BANDS, bool FUSE>
-__global__ __launch_bounds__(64 * fused_waves(LOG2N), fused_waves(LOG2N) / 4) void k_wav_to_mel(const FusedArgs a) {
-    constexpr int kFusedWaves = fused_waves(LOG2N);
+template <int LOG2N, int MELMODE, bool HI, bool BANDS, bool FUSE, int S>
+__global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) / 4) void k_wav_to_mel(const FusedArgs a) {
+    constexpr int kFusedWaves = fused_waves(LOG2N, S);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
     constexpr int F = NC + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -392,13 +411,22 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N), fused_waves(LOG2N) / 4) vo
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile_stride = a.chunk_frames * a.C + 1;
 
+    // per wave and stream: frame buffer (LDS-DMA target, N floats) | exchange buffer (also |X|)
     constexpr int kXBufBytes = (lds_padded(NC, FftCfg<LOG2N>::PMMAX) * 8 + 15) & ~15;
-    constexpr int kWaveBytes = N * 4 + kXBufBytes;
-    const float* fbuf = reinterpret_cast<const float*>(smem + wv * kWaveBytes);
-    const unsigned fbuf_lds = __builtin_amdgcn_readfirstlane(
-        (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + wv * kWaveBytes));
-    cf* lds = reinterpret_cast<cf*>(smem + wv * kWaveBytes + N * 4);
-    float* magbuf = reinterpret_cast<float*>(lds);
+    constexpr int kStreamBytes = N * 4 + kXBufBytes;
+    constexpr int kWaveBytes = S * kStreamBytes;
+    const float* fbuf[S];
+    unsigned fbuf_lds[S];
+    cf* lds[S];
+    float* magbuf[S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+        char* base = smem + wv * kWaveBytes + st * kStreamBytes;
+        fbuf[st] = reinterpret_cast<const float*>(base);
+        fbuf_lds[st] = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)base);
+        lds[st] = reinterpret_cast<cf*>(base + N * 4);
+        magbuf[st] = reinterpret_cast<float*>(base + N * 4);
+    }
     float* tile_out = reinterpret_cast<float*>(smem + kFusedWaves * kWaveBytes);
     float* red = tile_out + a.M * tile_stride;  // [48]: block_minmax [0,32), fused epilogue [32,34), frame queue [40]
     int* next_frame = reinterpret_cast<int*>(red + 40);  // next unclaimed wave-frame of the current chunk
@@ -416,9 +444,8 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N), fused_waves(LOG2N) / 4) vo
         for (int i = threadIdx.x; i < a.rows * a.M; i += blockDim.x) wtab[i] = a.wband[i];
         for (int i = threadIdx.x; i < a.M; i += blockDim.x) lotab[i] = a.band_lo[i];
     }
-    if (threadIdx.x == 0) *next_frame = kFusedWaves;
+    if (threadIdx.x == 0) *next_frame = kFusedWaves * S;
     __syncthreads();
-    const float4* mag4 = reinterpret_cast<const float4*>(magbuf + lo0);  // lo0 is a multiple of 4
     float* my_tile = tile_out + lane * tile_stride;
 
     unsigned long long stamp0 = 0, real0 = 0;
@@ -449,77 +476,108 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N), fused_waves(LOG2N) / 4) vo
         }
 
         const int nwf = nt * a.C;  // wave-frames in this chunk: f = tl * C + c
-        // frame cursor, all wave-uniform and updated incrementally (no multiplies in the loop):
-        //   c, tl       channel and local frame of wave-frame f
-        //   start       first sample of that frame (may be negative / run past the end: reflect)
-        //   clip        first sample of channel c of this clip
-        int f = wv, tl = wv / a.C, c = wv - tl * a.C;
-        int start = (t0 + tl) * a.hop - N / 2;
-        const float* clip = clip0 + (size_t)c * a.L;
-        if (f < nwf && !ABL(8)) dma_frame<LOG2N>(clip, a.L, start, fbuf_lds, lane);
-        while (f < nwf) {
-            // frame f has landed; pull it into registers, then reuse the buffer for the next one
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            cf x[P];
-            {
-                const cf* fb2 = reinterpret_cast<const cf*>(fbuf) + lane;
+        // Each wave keeps S frames in flight ("streams"): their butterflies, LDS exchanges and
+        // reductions are issued back to back, so the LDS round trip of one stream hides behind
+        // the arithmetic of the other.  Frames are claimed S at a time from an LDS counter
+        // (waves that run ahead take more: the issue arbiter favours older waves, a static split
+        // leaves the younger ones a tail).  All cursor state is wave-uniform (SGPRs).
+        int f[S];
 #pragma unroll
-                for (int q = 0; q < P; ++q) x[q] = fb2[kWave * q];
+        for (int st = 0; st < S; ++st) {
+            f[st] = wv * S + st;
+            if (f[st] < nwf && !ABL(8)) {
+                const int tl = (a.C == 1) ? f[st] : f[st] / a.C, c = f[st] - tl * a.C;
+                dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
+            }
+        }
+        while (f[0] < nwf) {
+            // the claimed frames have landed; pull them into registers, then reuse the buffers
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            cf x[S][P];
+#pragma unroll
+            for (int st = 0; st < S; ++st) {
+                const cf* fb2 = reinterpret_cast<const cf*>(fbuf[st]) + lane;
+#pragma unroll
+                for (int q = 0; q < P; ++q) x[st][q] = fb2[kWave * q];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int fcur = f, tcur = t0 + tl;
-            // claim the next frame of the chunk (waves that run ahead take more frames: the
-            // issue arbiter favours older waves, a static split would leave the others a tail)
+            int fcur[S];
+            bool live[S];  // stream holds a real, unmasked frame (otherwise its results are dropped)
+#pragma unroll
+            for (int st = 0; st < S; ++st) {
+                fcur[st] = f[st];
+                live[st] = f[st] < nwf;
+            }
             {
                 int nf = 0;
-                if (lane == 0) nf = atomicAdd(next_frame, 1);
-                f = __builtin_amdgcn_readfirstlane(nf);
+                if (lane == 0) nf = atomicAdd(next_frame, S);
+                nf = __builtin_amdgcn_readfirstlane(nf);
+#pragma unroll
+                for (int st = 0; st < S; ++st) {
+                    f[st] = nf + st;
+                    if (f[st] < nwf && !ABL(8)) {
+                        const int tl = (a.C == 1) ? f[st] : f[st] / a.C, c = f[st] - tl * a.C;
+                        dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
+                    }
+                }
             }
-            tl = (a.C == 1) ? f : f / a.C;
-            c = f - tl * a.C;
-            start = (t0 + tl) * a.hop - N / 2;
-            clip = clip0 + (size_t)c * a.L;
-            if (f < nwf && !ABL(8)) dma_frame<LOG2N>(clip, a.L, start, fbuf_lds, lane);
-
+            bool masked[S];
+#pragma unroll
+            for (int st = 0; st < S; ++st) masked[st] = false;
             if constexpr (BANDS) {
-                const bool masked = tb ? in_bands(tb, a.n_tb, tcur) : false;  // wave-uniform
-                if (masked) {
-                    for (int m = lane; m < a.M; m += kWave) tile_out[m * tile_stride + fcur] = 0.f;
+                if (tb) {
+#pragma unroll
+                    for (int st = 0; st < S; ++st)
+                        masked[st] = live[st] && in_bands(tb, a.n_tb, t0 + ((a.C == 1) ? fcur[st] : fcur[st] / a.C));
+                }
+                bool all_masked = true;
+#pragma unroll
+                for (int st = 0; st < S; ++st) all_masked = all_masked && (masked[st] || !live[st]);
+                if (all_masked) {  // wave-uniform: nothing to transform
+#pragma unroll
+                    for (int st = 0; st < S; ++st)
+                        if (live[st])
+                            for (int m = lane; m < a.M; m += kWave) tile_out[m * tile_stride + fcur[st]] = 0.f;
                     continue;
                 }
             }
 #pragma unroll
-            for (int q = 0; q < P; ++q) x[q] *= win[q];
-            if (!ABL(1)) fft_frame<LOG2N>(x, tw, lds, lane);
-            cf xlo[P / 2], xhi[P / 2];
+            for (int st = 0; st < S; ++st)
+#pragma unroll
+                for (int q = 0; q < P; ++q) x[st][q] *= win[q];
+            if (!ABL(1)) fft_frames<LOG2N, S>(x, tw, lds, lane);
+            cf xlo[S][P / 2], xhi[S][P / 2];
             // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)
-            if (!ABL(2)) {
-                untangle<LOG2N, HI, false>(x, post, lds, lane, xlo, xhi);
-            } else {
+            untangle_multi<LOG2N, HI, false, S>(x, post, lds, lane, xlo, xhi);
 #pragma unroll
-                for (int q = 0; q < P / 2; ++q) xlo[q] = xhi[q] = x[q];
-            }
+            for (int st = 0; st < S; ++st) {
 #pragma unroll
-            for (int q = 0; q < P / 2; ++q) magbuf[lane + kWave * q] = cabs_rn(xlo[q]);
-            if constexpr (HI) {
-                float* mhi = magbuf + NC - lane;
+                for (int q = 0; q < P / 2; ++q) magbuf[st][lane + kWave * q] = cabs_rn(xlo[st][q]);
+                if constexpr (HI) {
+                    float* mhi = magbuf[st] + NC - lane;
 #pragma unroll
-                for (int q = 0; q < P / 2; ++q) mhi[-kWave * q] = cabs_rn(xhi[q]);
-                if (lane == 0) magbuf[NC / 2] = 2.0f * cabs_rn(x[P / 2]);
+                    for (int q = 0; q < P / 2; ++q) mhi[-kWave * q] = cabs_rn(xhi[st][q]);
+                    if (lane == 0) magbuf[st][NC / 2] = 2.0f * cabs_rn(x[st][P / 2]);
+                }
             }
             wave_sync_lds();
             if constexpr (BANDS) {
                 if (fb) {
-                    for (int i = 0; i < a.n_fb; ++i) {
-                        const int off = fb[2 * i], end = min(off + fb[2 * i + 1], F);
-                        for (int k = off + lane; k < end; k += kWave) magbuf[k] = 0.f;
-                    }
+#pragma unroll
+                    for (int st = 0; st < S; ++st)
+                        for (int i = 0; i < a.n_fb; ++i) {
+                            const int off = fb[2 * i], end = min(off + fb[2 * i + 1], F);
+                            for (int k = off + lane; k < end; k += kWave) magbuf[st][k] = 0.f;
+                        }
                     wave_sync_lds();
                 }
             }
-            if constexpr (MELMODE == 0) {
-                float acc = 0.f;
-                if (!ABL(4)) {
+#pragma unroll
+            for (int st = 0; st < S; ++st) {
+                const float keep = masked[st] ? 0.f : scale;
+                if constexpr (MELMODE == 0) {
+                    const float4* mag4 = reinterpret_cast<const float4*>(magbuf[st] + lo0);  // lo0 % 4 == 0
+                    float acc = 0.f;
 #pragma unroll
                     for (int i = 0; i < kMelRegs / 4; ++i) {
                         const float4 m4 = mag4[i];
@@ -528,21 +586,22 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N), fused_waves(LOG2N) / 4) vo
                         acc = fmaf(wreg[4 * i + 2], m4.z, acc);
                         acc = fmaf(wreg[4 * i + 3], m4.w, acc);
                     }
+                    if (live[st] && lane < a.M) my_tile[fcur[st]] = acc * keep;
                 } else {
-                    acc = magbuf[lane];
-                }
-                if (lane < a.M) my_tile[fcur] = acc * scale;
-            } else {
-                for (int m = lane; m < a.M; m += kWave) {
-                    float acc = 0.f;
-                    if constexpr (MELMODE == 1) {
-                        const int lo = lotab[m];
-                        for (int i = 0; i < a.rows; ++i) acc = fmaf(wtab[i * a.M + m], magbuf[lo + i], acc);
-                    } else {
-                        const int lo = a.band_lo[m];
-                        for (int i = 0; i < a.rows; ++i) acc = fmaf(a.wband[i * a.M + m], magbuf[lo + i], acc);
+                    if (live[st]) {
+                        for (int m = lane; m < a.M; m += kWave) {
+                            float acc = 0.f;
+                            if constexpr (MELMODE == 1) {
+                                const int lo = lotab[m];
+                                for (int i = 0; i < a.rows; ++i) acc = fmaf(wtab[i * a.M + m], magbuf[st][lo + i], acc);
+                            } else {
+                                const int lo = a.band_lo[m];
+                                for (int i = 0; i < a.rows; ++i)
+                                    acc = fmaf(a.wband[i * a.M + m], magbuf[st][lo + i], acc);
+                            }
+                            tile_out[m * tile_stride + fcur[st]] = acc * keep;
+                        }
                     }
-                    tile_out[m * tile_stride + fcur] = acc * scale;
                 }
             }
             wave_sync_lds();
@@ -567,7 +626,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N), fused_waves(LOG2N) / 4) vo
             if (threadIdx.x == 0) {
                 a.partial[(size_t)chunk * 2 + 0] = mn;
                 a.partial[(size_t)chunk * 2 + 1] = mx;
-                *next_frame = kFusedWaves;
+                *next_frame = kFusedWaves * S;
             }
             __syncthreads();
         } else {
@@ -632,7 +691,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N), fused_waves(LOG2N) / 4) vo
                 dst[r] = v;
             }
         }
-        if (threadIdx.x == 0) *next_frame = kFusedWaves;
+        if (threadIdx.x == 0) *next_frame = kFusedWaves * S;
         if (a.do_minmax && threadIdx.x == 0) {
             // done with the clip's line (off the critical path): the clip's last chunk to get
             // here re-arms it for the next launch
@@ -1111,9 +1170,13 @@ static int upload(T** dst, const std::vector<T>& src) {
     return IRIS_OK;
 }
 
-static size_t fused_lds_bytes(const iris_plan* p, int chunk_frames) {
+static int plan_streams(const iris_plan* p, bool fuse) {
+    return (p->streams == 2 && !fuse && (p->log2n == 9 || p->log2n == 10)) ? 2 : 1;
+}
+
+static size_t fused_lds_bytes(const iris_plan* p, int chunk_frames, int streams) {
     const size_t xbuf = (wave_buf_bytes(p->log2n) + 15) & ~(size_t)15;
-    size_t bytes = (size_t)fused_waves(p->log2n) * ((size_t)p->n_fft * 4 + xbuf);
+    size_t bytes = (size_t)fused_waves(p->log2n, streams) * streams * ((size_t)p->n_fft * 4 + xbuf);
     bytes += ((size_t)p->n_mel * (chunk_frames * p->channels + 1) + 48) * 4;
     if (p->mel_mode == 1) bytes += ((size_t)p->rows * p->n_mel + p->n_mel) * 4;
     return bytes;
@@ -1121,29 +1184,37 @@ static size_t fused_lds_bytes(const iris_plan* p, int chunk_frames) {
 
 typedef void (*fused_kernel_t)(const FusedArgs);
 
-template <int LOG2N, int MELMODE, bool FUSE>
+template <int LOG2N, int MELMODE, bool FUSE, int S>
 static fused_kernel_t fused_kernel_hb(bool hi, bool bands) {
     if (hi)
-        return bands ? k_wav_to_mel<LOG2N, MELMODE, true, true, FUSE> : k_wav_to_mel<LOG2N, MELMODE, true, false, FUSE>;
-    return bands ? k_wav_to_mel<LOG2N, MELMODE, false, true, FUSE> : k_wav_to_mel<LOG2N, MELMODE, false, false, FUSE>;
+        return bands ? k_wav_to_mel<LOG2N, MELMODE, true, true, FUSE, S>
+                     : k_wav_to_mel<LOG2N, MELMODE, true, false, FUSE, S>;
+    return bands ? k_wav_to_mel<LOG2N, MELMODE, false, true, FUSE, S>
+                 : k_wav_to_mel<LOG2N, MELMODE, false, false, FUSE, S>;
 }
+template <int LOG2N, bool FUSE, int S>
+static fused_kernel_t fused_kernel_mm(int mel_mode, bool hi, bool bands) {
+    if (mel_mode == 0) return fused_kernel_hb<LOG2N, 0, FUSE, S>(hi, bands);
+    if (mel_mode == 1) return fused_kernel_hb<LOG2N, 1, FUSE, S>(hi, bands);
+    return fused_kernel_hb<LOG2N, 2, FUSE, S>(hi, bands);
+}
+// two frame streams per wave exist for n_fft 512 / 1024 without the fused epilogue
+static bool streams2_available(int log2n, bool fuse) { return !fuse && (log2n == 9 || log2n == 10); }
+
 template <int LOG2N>
-static fused_kernel_t fused_kernel_m(int mel_mode, bool hi, bool bands, bool fuse) {
-    if (fuse) {
-        if (mel_mode == 0) return fused_kernel_hb<LOG2N, 0, true>(hi, bands);
-        if (mel_mode == 1) return fused_kernel_hb<LOG2N, 1, true>(hi, bands);
-        return fused_kernel_hb<LOG2N, 2, true>(hi, bands);
+static fused_kernel_t fused_kernel_m(int mel_mode, bool hi, bool bands, bool fuse, int streams) {
+    if constexpr (LOG2N == 9 || LOG2N == 10) {
+        if (streams == 2 && !fuse) return fused_kernel_mm<LOG2N, false, 2>(mel_mode, hi, bands);
     }
-    if (mel_mode == 0) return fused_kernel_hb<LOG2N, 0, false>(hi, bands);
-    if (mel_mode == 1) return fused_kernel_hb<LOG2N, 1, false>(hi, bands);
-    return fused_kernel_hb<LOG2N, 2, false>(hi, bands);
+    if (fuse) return fused_kernel_mm<LOG2N, true, 1>(mel_mode, hi, bands);
+    return fused_kernel_mm<LOG2N, false, 1>(mel_mode, hi, bands);
 }
-static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands, bool fuse) {
+static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands, bool fuse, int streams) {
     switch (log2n) {
-        case 11: return fused_kernel_m<11>(mel_mode, hi, bands, fuse);
-        case 10: return fused_kernel_m<10>(mel_mode, hi, bands, fuse);
-        case 9: return fused_kernel_m<9>(mel_mode, hi, bands, fuse);
-        default: return fused_kernel_m<8>(mel_mode, hi, bands, fuse);
+        case 11: return fused_kernel_m<11>(mel_mode, hi, bands, fuse, streams);
+        case 10: return fused_kernel_m<10>(mel_mode, hi, bands, fuse, streams);
+        case 9: return fused_kernel_m<9>(mel_mode, hi, bands, fuse, streams);
+        default: return fused_kernel_m<8>(mel_mode, hi, bands, fuse, streams);
     }
 }
 static const void* stft_kernel(int log2n) {
@@ -1159,9 +1230,12 @@ static const void* stft_kernel(int log2n) {
 static hipError_t allow_big_lds(const iris_plan* p) {
     constexpr int kMaxLds = 160 * 1024;
     hipError_t e;
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 8; ++v) {
+        const bool fuse = (v & 2) != 0;
+        const int streams = (v & 4) ? 2 : 1;
+        if (streams == 2 && !streams2_available(p->log2n, fuse)) continue;
         e = hipFuncSetAttribute(
-            (const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, (v & 1) != 0, (v & 2) != 0),
+            (const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, (v & 1) != 0, fuse, streams),
             hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
         if (e != hipSuccess) return e;
     }
@@ -1217,6 +1291,8 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->d_dbg = nullptr;
     p->d_sync = nullptr;
     p->fuse_epilogue = 0;
+    p->streams = 1;
+    if (const char* e = getenv("IRIS_STREAMS")) p->streams = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("IRIS_FUSE_MINMAX")) p->fuse_epilogue = atoi(e) != 0;
     p->timing = false;
     p->ev_used = 0;
@@ -1331,7 +1407,7 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     }
     p->chunk_target = 0;
     if (const char* e = getenv("IRIS_CHUNK_FRAMES")) p->chunk_target = std::max(0, atoi(e));
-    if (!mel_only && fused_lds_bytes(p, 1) > 160 * 1024) {
+    if (!mel_only && fused_lds_bytes(p, 1, 1) > 160 * 1024) {
         iris_plan_destroy(p);
         return fail(IRIS_E_UNSUPPORTED, "n_mel=%d x channels=%d does not fit the LDS out tile", n_mel, channels);
     }
@@ -1576,13 +1652,13 @@ extern "C" int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minm
 
 // Chunk geometry of the fused kernel for `per_cu` workgroups per CU: every workgroup one
 // chunk when the problem is large enough, chunks never span clips.
-static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int* chunk_frames,
+static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int streams, int* chunk_frames,
                            int* chunks_per_clip) {
     const int slots = p->num_cu * per_cu;
     const long total = (long)batch * T;
     // frames per chunk are capped by the LDS left for the out tile (one workgroup per CU owns
     // the whole 160 KiB)
-    const size_t fixed = fused_lds_bytes(p, 0) + 1024;
+    const size_t fixed = fused_lds_bytes(p, 0, streams) + 1024;
     const size_t room = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
     int cap = 512;
     while (cap > 1 && (size_t)p->n_mel * (cap * p->channels) * 4 > room) --cap;
@@ -1604,15 +1680,15 @@ static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int
 // workgroup of the grid is resident.  LDS use depends on the chunk size and the chunk
 // size on the number of resident workgroups, so iterate from the register-limited
 // occupancy downwards until the occupancy query agrees.
-static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, int T, int* chunk_frames,
+static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, int* chunk_frames,
                         int* chunks_per_clip, int* grid, size_t* lds) {
     for (int per_cu = fused_occ(p->log2n); per_cu >= 1; --per_cu) {
-        fused_geometry(p, batch, T, per_cu, chunk_frames, chunks_per_clip);
-        *lds = fused_lds_bytes(p, *chunk_frames);
+        fused_geometry(p, batch, T, per_cu, streams, chunk_frames, chunks_per_clip);
+        *lds = fused_lds_bytes(p, *chunk_frames, streams);
         if (*lds > 160 * 1024) continue;
         int resident = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
-                                                                    64 * fused_waves(p->log2n), *lds);
+                                                                    64 * fused_waves(p->log2n, streams), *lds);
         if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s",
                                          hipGetErrorString(e));
         if (resident >= per_cu) {
@@ -1660,10 +1736,12 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     if (const char* e = getenv("IRIS_ABLATE")) a.ablate = atoi(e);
     a.dbg = p->d_dbg;
     const bool bands = (n_tb > 0) || (n_fb > 0);
-    const fused_kernel_t kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, a.fuse != 0);
+    const int streams = plan_streams(p, a.fuse != 0);
+    const fused_kernel_t kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, a.fuse != 0, streams);
     int grid = 0;
     size_t lds = 0;
-    if ((rc = fused_config(p, kernel, batch, a.T, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds))) return rc;
+    if ((rc = fused_config(p, kernel, batch, a.T, streams, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
+        return rc;
     a.n_chunks = batch * a.chunks_per_clip;
     const size_t n_partial = 2 * (size_t)a.n_chunks;
     a.partial = p->d_ws;
@@ -1692,11 +1770,11 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         }
         FusedArgs args = a;
         void* kargs[] = {&args};
-        e = hipExtLaunchKernel((const void*)kernel, dim3(grid), dim3(64 * fused_waves(p->log2n)), kargs, lds, s,
+        e = hipExtLaunchKernel((const void*)kernel, dim3(grid), dim3(64 * fused_waves(p->log2n, streams)), kargs, lds, s,
                                p->ev[2 * p->ev_used], p->ev[2 * p->ev_used + 1], 0);
         if (e == hipSuccess) p->ev_used++;
     } else {
-        kernel<<<grid, 64 * fused_waves(p->log2n), lds, s>>>(a);
+        kernel<<<grid, 64 * fused_waves(p->log2n, streams), lds, s>>>(a);
         e = hipGetLastError();
     }
     HIP_TRY(e);
