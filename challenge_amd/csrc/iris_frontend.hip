@@ -439,7 +439,16 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
     cf tw[NTW], post[P / 2], win[P];
     float wreg[kMelRegs];
     int lo0;
-    load_consts<LOG2N>(a.consts, lane, tw, post, win, wreg, lo0);
+    {
+        // the block is the same for every wave: fetch it from global once per workgroup (through
+        // the not-yet-used wave buffers) instead of once per wave
+        float4* stage = reinterpret_cast<float4*>(smem);
+        const float4* g = reinterpret_cast<const float4*>(a.consts);
+        for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
+        __syncthreads();
+        load_consts<LOG2N>(reinterpret_cast<const float*>(stage), lane, tw, post, win, wreg, lo0);
+        __syncthreads();
+    }
     if constexpr (MELMODE == 1) {
         for (int i = threadIdx.x; i < a.rows * a.M; i += blockDim.x) wtab[i] = a.wband[i];
         for (int i = threadIdx.x; i < a.M; i += blockDim.x) lotab[i] = a.band_lo[i];
