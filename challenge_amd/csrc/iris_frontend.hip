@@ -62,6 +62,9 @@ struct iris_plan {
     int* d_band_lo;   // [M] first non-zero bin of each band (magmel)
     int* d_band_len;  // [M]
     float* d_mel;     // [F][M] dense (magmel)
+    int* d_bin_band;  // [F] magmel streaming kernel: first band fed by each bin (-1 none)
+    float* d_bin_w;   // [F][2] its two weights
+    int tri_ok, tri_f_lo, tri_f_hi;  // filterbank is triangular-sparse (<= 2 adjacent bands per bin)
     int* d_fband_lo;  // [M] fused kernel: first bin read, clamped so lo + rows <= limit
     float* d_wband;   // [rows][M] fused kernel: 0.5 * W[lo + i][m]
     int rows, need_hi, mel_mode;
@@ -844,6 +847,112 @@ __global__ __launch_bounds__(256) void k_magmel(const MagmelArgs a) {
     }
 }
 
+// K3b: streaming variant for triangular filterbanks (every bin feeds at most two adjacent
+// bands, which is what linear_to_mel_weight_matrix produces): one thread per frame t walks the
+// bins once with two open accumulators per channel; a band is written as soon as the walk
+// has passed its last bin.  Every spectrum element is read exactly once, with one 8/16-byte
+// load per bin (all 2C components), coalesced along t.
+struct MagmelTriArgs {
+    const float* spec;   // [B, F, T, 2C]
+    float* mel;          // [B, M, T, C]
+    const int* bin_band; // [F] first band fed by bin f (-1: none)
+    const float* bin_w;  // [F][2] weights for bands bin_band[f] and bin_band[f] + 1
+    const int* t_bands;
+    int n_tb;
+    const int* f_bands;
+    int n_fb;
+    int B, F, T, M, is_magphase, f_lo, f_hi;  // bins outside [f_lo, f_hi) feed nothing
+};
+
+template <int C>
+__global__ __launch_bounds__(512) void k_magmel_tri(const MagmelTriArgs a) {
+    typedef float vecT __attribute__((ext_vector_type(2 * C)));
+    constexpr int U = 8;                // bins in flight per wave
+    extern __shared__ float sm_mel[];   // [M][64][C] band sums of this block's 64 frames
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nslice = blockDim.x >> 6;
+    const int t0 = blockIdx.x * 64;
+    const int t = t0 + lane;
+    const bool valid = t < a.T;
+    const int* tb = a.t_bands ? a.t_bands + (size_t)b * a.n_tb * 2 : nullptr;
+    const int* fb = a.f_bands ? a.f_bands + (size_t)b * a.n_fb * 2 : nullptr;
+    for (int i = threadIdx.x; i < a.M * 64 * C; i += blockDim.x) sm_mel[i] = 0.f;
+    __syncthreads();
+
+    // this wave's slice of the bins that feed anything
+    const int nb = a.f_hi - a.f_lo;
+    const int per = (nb + nslice - 1) / nslice;
+    const int f0 = a.f_lo + wave * per;
+    const int f1 = min(f0 + per, a.f_hi);
+    const vecT* sp = reinterpret_cast<const vecT*>(a.spec) + (size_t)b * a.F * a.T + (valid ? t : 0);
+    float acc0[C], acc1[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc0[c] = acc1[c] = 0.f;
+    int cur = -1;  // band held in acc0 (acc1 holds cur + 1); wave-uniform
+    auto retire = [&]() {  // add acc0 into the block sums, shift the window up by one band
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            atomicAdd(&sm_mel[((size_t)cur * 64 + lane) * C + c], acc0[c]);
+            acc0[c] = acc1[c];
+            acc1[c] = 0.f;
+        }
+        ++cur;
+    };
+    for (int fc = f0; fc < f1; fc += U) {
+        vecT v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int f = min(fc + u, f1 - 1);
+            v[u] = valid ? __builtin_nontemporal_load(&sp[(size_t)f * a.T]) : vecT(0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int f = fc + u;
+            if (f >= f1) break;
+            const int m = a.bin_band[f];  // uniform
+            if (m < 0) continue;
+            if (cur < 0) cur = m;
+            while (cur < m) {
+                if (cur + 1 < m && cur + 1 < a.M) {  // gap of more than one band: acc1 is retired too
+                    retire();
+                    retire();
+                    cur = m;
+                } else {
+                    retire();
+                }
+            }
+            float w0 = a.bin_w[2 * f], w1 = a.bin_w[2 * f + 1];
+            if (fb && in_bands(fb, a.n_fb, f)) w0 = w1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float re = v[u][c];
+                const float im = v[u][C + c];
+                const float mag = a.is_magphase ? re : __builtin_amdgcn_sqrtf(fmaf(re, re, im * im));
+                acc0[c] = fmaf(w0, mag, acc0[c]);
+                acc1[c] = fmaf(w1, mag, acc1[c]);
+            }
+        }
+    }
+    if (cur >= 0) {
+        retire();
+        if (cur < a.M) retire();
+    }
+    __syncthreads();
+
+    // write the block's [M][64][C] sums, coalesced along t
+    float* out = a.mel + (size_t)b * a.M * a.T * C;
+    const int row = 64 * C;
+    for (int i = threadIdx.x; i < a.M * row; i += blockDim.x) {
+        const int m = i / row, r = i - m * row;
+        const int tt = t0 + r / C;
+        if (tt >= a.T) continue;
+        const bool tm = tb ? in_bands(tb, a.n_tb, tt) : false;
+        out[(size_t)m * a.T * C + (size_t)t0 * C + r] = tm ? 0.f : sm_mel[i];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K4/K5: min-max (+ log): partial reduce, then apply
 // ---------------------------------------------------------------------------
@@ -1296,6 +1405,8 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->upper_hz = upper_hz;
     p->d_consts = nullptr;
     p->d_band_lo = p->d_band_len = p->d_fband_lo = nullptr;
+    p->d_bin_band = nullptr;
+    p->d_bin_w = nullptr;
     p->d_wband = p->d_mel = p->d_ws = nullptr;
     p->d_dbg = nullptr;
     p->d_sync = nullptr;
@@ -1333,6 +1444,35 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
         }
         p->max_band_len = std::max(p->max_band_len, len[m]);
         p->k_need = std::max(p->k_need, lo[m] + len[m]);
+    }
+    // streaming magmel tables: valid when every bin's non-zeros sit in <= 2 adjacent bands and
+    // the first band index never decreases with the bin (true for triangular filterbanks)
+    std::vector<int> bin_band(n_bins, -1);
+    std::vector<float> bin_w((size_t)n_bins * 2, 0.f);
+    p->tri_ok = 1;
+    p->tri_f_lo = n_bins;
+    p->tri_f_hi = 0;
+    {
+        int prev = -1;
+        for (int f = 0; f < n_bins && p->tri_ok; ++f) {
+            int first = -1, last = -1;
+            for (int m = 0; m < n_mel; ++m)
+                if (p->mel[(size_t)f * n_mel + m] != 0.f) {
+                    if (first < 0) first = m;
+                    last = m;
+                }
+            if (first < 0) continue;
+            if (last - first > 1 || first < prev) {
+                p->tri_ok = 0;
+                break;
+            }
+            prev = first;
+            bin_band[f] = first;
+            bin_w[2 * (size_t)f] = p->mel[(size_t)f * n_mel + first];
+            bin_w[2 * (size_t)f + 1] = last > first ? p->mel[(size_t)f * n_mel + last] : 0.f;
+            p->tri_f_lo = std::min(p->tri_f_lo, f);
+            p->tri_f_hi = std::max(p->tri_f_hi, f + 1);
+        }
     }
     // fused kernel tables: which half of the spectrum it must produce, and per band a
     // window of `rows` bins [flo, flo + rows) inside the bins the kernel writes
@@ -1396,6 +1536,7 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     if ((rc = upload(&p->d_consts, consts)) ||
         (rc = upload(&p->d_band_lo, lo)) || (rc = upload(&p->d_band_len, len)) ||
         (rc = upload(&p->d_fband_lo, flo)) || (rc = upload(&p->d_wband, wband)) ||
+        (rc = upload(&p->d_bin_band, bin_band)) || (rc = upload(&p->d_bin_w, bin_w)) ||
         (rc = upload(&p->d_mel, p->mel))) {
         iris_plan_destroy(p);
         return rc;
@@ -1489,6 +1630,8 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
     (void)hipFree(p->d_band_lo);
     (void)hipFree(p->d_band_len);
     (void)hipFree(p->d_fband_lo);
+    (void)hipFree(p->d_bin_band);
+    (void)hipFree(p->d_bin_w);
     (void)hipFree(p->d_wband);
     (void)hipFree(p->d_mel);
     (void)hipFree(p->d_ws);
@@ -1630,8 +1773,35 @@ extern "C" int iris_magmel(iris_plan* p, const float* spec, float* mel, int batc
     a.T = n_frames;
     a.M = p->n_mel;
     a.is_magphase = is_magphase;
-    const int tc = n_frames * p->channels;
-    k_magmel<<<dim3((tc + 63) / 64, batch), 256, 0, (hipStream_t)stream>>>(a);
+    const bool aligned = (reinterpret_cast<uintptr_t>(spec) & (8 * p->channels - 1)) == 0;
+    if (p->tri_ok && (p->channels == 1 || p->channels == 2) && aligned &&
+        (size_t)p->n_mel * 64 * p->channels * sizeof(float) <= 64 * 1024 && getenv("IRIS_MAGMEL_GENERIC") == nullptr) {
+        MagmelTriArgs t;
+        t.spec = spec;
+        t.mel = mel;
+        t.bin_band = p->d_bin_band;
+        t.bin_w = p->d_bin_w;
+        t.t_bands = a.t_bands;
+        t.n_tb = n_tb;
+        t.f_bands = a.f_bands;
+        t.n_fb = n_fb;
+        t.B = batch;
+        t.F = p->n_bins;
+        t.T = n_frames;
+        t.M = p->n_mel;
+        t.is_magphase = is_magphase;
+        t.f_lo = p->tri_f_lo;
+        t.f_hi = p->tri_f_hi;
+        const dim3 grid((n_frames + 63) / 64, batch);
+        // split the bins over 8 waves when the grid alone cannot fill the chip
+        const int threads = (size_t)grid.x * grid.y * 4 < (size_t)p->num_cu * 8 ? 512 : 256;
+        const size_t lds = (size_t)p->n_mel * 64 * p->channels * sizeof(float);
+        if (p->channels == 1) k_magmel_tri<1><<<grid, threads, lds, (hipStream_t)stream>>>(t);
+        else k_magmel_tri<2><<<grid, threads, lds, (hipStream_t)stream>>>(t);
+    } else {
+        const int tc = n_frames * p->channels;
+        k_magmel<<<dim3((tc + 63) / 64, batch), 256, 0, (hipStream_t)stream>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
