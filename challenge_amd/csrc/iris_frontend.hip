@@ -24,6 +24,15 @@ using namespace iris;
 #define IRIS_DIAG 0
 #endif
 #define ABL(bit) (IRIS_DIAG && (a.ablate & (bit)))
+// diagnostic buffer: [4] header, [3 * 4096] per-workgroup stamps, [4096 * 16 * 16] per-wave phase cycles
+static constexpr int kDbgPhase0 = 4 + 3 * 4096, kDbgWords = kDbgPhase0 + 4096 * 16 * 16;
+#if IRIS_DIAG
+#define PH_BEGIN() do { if (ABL(4096)) ph_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define PH_MARK(i) do { if (ABL(4096)) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph[i] += n_ - ph_t; ph_t = n_; } } while (0)
+#else
+#define PH_BEGIN() do {} while (0)
+#define PH_MARK(i) do {} while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -93,20 +102,45 @@ __device__ __forceinline__ int reflect_idx(int i, int len) {
     return i >= len ? 2 * (len - 1) - i : i;
 }
 
+// Wave-wide reductions on the DPP network (no LDS traffic): four row_shr steps leave each
+// 16-lane row's result in its last lane, row_bcast:15 / row_bcast:31 carry it across rows, lane 63
+// ends up with the whole wave's value, which is returned to every lane.  Lanes/rows a step does not
+// reach keep their own value (the `old` operand), which is harmless for min, max and - with a
+// zero `old` - for sums.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float lane63(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+    v = fminf(v, dpp_take<0x111, 0xf>(v, v));  // row_shr:1
+    v = fminf(v, dpp_take<0x112, 0xf>(v, v));  // row_shr:2
+    v = fminf(v, dpp_take<0x114, 0xf>(v, v));  // row_shr:4
+    v = fminf(v, dpp_take<0x118, 0xf>(v, v));  // row_shr:8
+    v = fminf(v, dpp_take<0x142, 0xa>(v, v));  // row_bcast:15 into rows 1 and 3
+    v = fminf(v, dpp_take<0x143, 0xc>(v, v));  // row_bcast:31 into rows 2 and 3
+    return lane63(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_take<0x111, 0xf>(v, v));
+    v = fmaxf(v, dpp_take<0x112, 0xf>(v, v));
+    v = fmaxf(v, dpp_take<0x114, 0xf>(v, v));
+    v = fmaxf(v, dpp_take<0x118, 0xf>(v, v));
+    v = fmaxf(v, dpp_take<0x142, 0xa>(v, v));
+    v = fmaxf(v, dpp_take<0x143, 0xc>(v, v));
+    return lane63(v);
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_take<0x111, 0xf>(0.f, v);
+    v += dpp_take<0x112, 0xf>(0.f, v);
+    v += dpp_take<0x114, 0xf>(0.f, v);
+    v += dpp_take<0x118, 0xf>(0.f, v);
+    v += dpp_take<0x142, 0xa>(0.f, v);
+    v += dpp_take<0x143, 0xc>(0.f, v);
+    return lane63(v);
 }
 
 // Block-wide min/max (up to 16 waves); result valid in every thread.  red: 32 floats.
@@ -302,7 +336,7 @@ constexpr int fused_waves(int log2n, int streams = 1) { return (log2n >= 11 || s
 struct FusedArgs {
     const float* wav;    // [B, C, L]
     float* out;          // [B, M, T, C]
-    float* partial;      // [B, chunks_per_clip, 2] min, max
+    float* partial;      // [B, chunks_per_clip * waves, 2] (min, max) per wave of each chunk (fused epilogue: per chunk)
     const float* sumsq;  // nullable [B, n_sq] partial sums of squares (normalize)
     int n_sq;
     const float* consts;  // per-lane constant block (ConstLayout)
@@ -315,6 +349,7 @@ struct FusedArgs {
     int n_fb;
     int B, C, L, T, hop, M;
     int chunk_frames, chunks_per_clip, n_chunks;
+    int chunk_base, chunk_rem;  // T = chunks_per_clip * chunk_base + chunk_rem; the first chunk_rem chunks take one more
     // fused epilogue (mode 0 = raw mel + min/max partials for k_minmax_log_apply;
     // 1 = min-max and/or log applied here, clips synchronised through arrive/depart)
     int fuse, do_minmax, do_log;
@@ -460,17 +495,25 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
     __syncthreads();
     float* my_tile = tile_out + lane * tile_stride;
 
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // diag: cycles per loop phase
+    (void)ph;
+    (void)ph_t;
     unsigned long long stamp0 = 0, real0 = 0;
     if ABL(512) {
         stamp0 = __builtin_amdgcn_s_memtime();
         real0 = __builtin_amdgcn_s_memrealtime();
     }
     const int g0 = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned long long pass_t = 0;
+    (void)pass_t;
+    for (int pass = 0; pass < (ABL(16384) ? 2 : 1); ++pass)
     for (int chunk = g0; chunk < a.n_chunks; chunk += gridDim.x) {
+        if ABL(16384) pass_t = __builtin_amdgcn_s_memtime();
+        PH_BEGIN();
         const int b = chunk / a.chunks_per_clip, ci = chunk - b * a.chunks_per_clip;
         // balanced split of the clip's T frames over its chunks (sizes differ by at most one)
-        const int t0 = (int)(((long)ci * a.T) / a.chunks_per_clip);
-        const int nt = (int)(((long)(ci + 1) * a.T) / a.chunks_per_clip) - t0;
+        const int t0 = ci * a.chunk_base + min(ci, a.chunk_rem);
+        const int nt = a.chunk_base + (ci < a.chunk_rem ? 1 : 0);
         const int* tb = nullptr;
         const int* fb = nullptr;
         if constexpr (BANDS) {
@@ -493,154 +536,248 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
         // the arithmetic of the other.  Frames are claimed S at a time from an LDS counter
         // (waves that run ahead take more: the issue arbiter favours older waves, a static split
         // leaves the younger ones a tail).  All cursor state is wave-uniform (SGPRs).
-        int f[S];
+        //
+        // The loop is software-pipelined: while frame i is in its mel phase (its samples are no
+        // longer needed in registers) the wave already reads frame i+1 from its landing buffer and
+        // claims frame i+2, whose DMA is issued once those reads have returned - so neither the
+        // LDS round trip of the frame read nor the queue atomic sits on the critical path.
+        auto issue_dma = [&](const int (&ff)[S]) {
 #pragma unroll
-        for (int st = 0; st < S; ++st) {
-            f[st] = wv * S + st;
-            if (f[st] < nwf && !ABL(8)) {
-                const int tl = (a.C == 1) ? f[st] : f[st] / a.C, c = f[st] - tl * a.C;
-                dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
-            }
-        }
-        while (f[0] < nwf) {
-            // the claimed frames have landed; pull them into registers, then reuse the buffers
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            cf x[S][P];
+            for (int st = 0; st < S; ++st)
+                if (ff[st] < nwf && !ABL(8)) {
+                    const int tl = (a.C == 1) ? ff[st] : ff[st] / a.C, c = ff[st] - tl * a.C;
+                    dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
+                }
+        };
+        cf x[S][P];
+        auto read_frames = [&]() {  // landing buffers -> registers (asynchronous: lgkmcnt)
 #pragma unroll
             for (int st = 0; st < S; ++st) {
                 const cf* fb2 = reinterpret_cast<const cf*>(fbuf[st]) + lane;
 #pragma unroll
                 for (int q = 0; q < P; ++q) x[st][q] = fb2[kWave * q];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        int f[S], fn[S];  // frames in registers / frames in flight to the landing buffers
+#pragma unroll
+        for (int st = 0; st < S; ++st) f[st] = wv * S + st;
+        issue_dma(f);
+        {
+            int nf = 0;
+            if (lane == 0) nf = atomicAdd(next_frame, S);
+            nf = __builtin_amdgcn_readfirstlane(nf);
+#pragma unroll
+            for (int st = 0; st < S; ++st) fn[st] = nf + st;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        read_frames();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_dma(fn);
+        PH_MARK(8);
+        while (f[0] < nwf) {
+            PH_BEGIN();
             int fcur[S];
-            bool live[S];  // stream holds a real, unmasked frame (otherwise its results are dropped)
+            bool live[S];  // stream holds a real frame (otherwise its results are dropped)
 #pragma unroll
             for (int st = 0; st < S; ++st) {
                 fcur[st] = f[st];
                 live[st] = f[st] < nwf;
             }
-            {
-                int nf = 0;
-                if (lane == 0) nf = atomicAdd(next_frame, S);
-                nf = __builtin_amdgcn_readfirstlane(nf);
-#pragma unroll
-                for (int st = 0; st < S; ++st) {
-                    f[st] = nf + st;
-                    if (f[st] < nwf && !ABL(8)) {
-                        const int tl = (a.C == 1) ? f[st] : f[st] / a.C, c = f[st] - tl * a.C;
-                        dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
-                    }
-                }
-            }
             bool masked[S];
 #pragma unroll
             for (int st = 0; st < S; ++st) masked[st] = false;
+            bool all_masked = false;
             if constexpr (BANDS) {
                 if (tb) {
 #pragma unroll
                     for (int st = 0; st < S; ++st)
                         masked[st] = live[st] && in_bands(tb, a.n_tb, t0 + ((a.C == 1) ? fcur[st] : fcur[st] / a.C));
                 }
-                bool all_masked = true;
+                all_masked = true;
 #pragma unroll
                 for (int st = 0; st < S; ++st) all_masked = all_masked && (masked[st] || !live[st]);
-                if (all_masked) {  // wave-uniform: nothing to transform
-#pragma unroll
-                    for (int st = 0; st < S; ++st)
-                        if (live[st])
-                            for (int m = lane; m < a.M; m += kWave) tile_out[m * tile_stride + fcur[st]] = 0.f;
-                    continue;
-                }
             }
+            if (!all_masked) {  // wave-uniform; a fully masked round has nothing to transform
 #pragma unroll
-            for (int st = 0; st < S; ++st)
+                for (int st = 0; st < S; ++st)
 #pragma unroll
-                for (int q = 0; q < P; ++q) x[st][q] *= win[q];
-            if (!ABL(1)) fft_frames<LOG2N, S>(x, tw, lds, lane);
-            cf xlo[S][P / 2], xhi[S][P / 2];
-            // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)
-            untangle_multi<LOG2N, HI, false, S>(x, post, lds, lane, xlo, xhi);
+                    for (int q = 0; q < P; ++q) x[st][q] *= win[q];
+                if (!ABL(1)) fft_frames<LOG2N, S>(x, tw, lds, lane);
+                PH_MARK(3);
+                cf xlo[S][P / 2], xhi[S][P / 2];
+                // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)
+                untangle_multi<LOG2N, HI, false, S>(x, post, lds, lane, xlo, xhi);
 #pragma unroll
-            for (int st = 0; st < S; ++st) {
+                for (int st = 0; st < S; ++st) {
 #pragma unroll
-                for (int q = 0; q < P / 2; ++q) magbuf[st][lane + kWave * q] = cabs_rn(xlo[st][q]);
-                if constexpr (HI) {
-                    float* mhi = magbuf[st] + NC - lane;
+                    for (int q = 0; q < P / 2; ++q) magbuf[st][lane + kWave * q] = cabs_rn(xlo[st][q]);
+                    if constexpr (HI) {
+                        float* mhi = magbuf[st] + NC - lane;
 #pragma unroll
-                    for (int q = 0; q < P / 2; ++q) mhi[-kWave * q] = cabs_rn(xhi[st][q]);
-                    if (lane == 0) magbuf[st][NC / 2] = 2.0f * cabs_rn(x[st][P / 2]);
-                }
-            }
-            wave_sync_lds();
-            if constexpr (BANDS) {
-                if (fb) {
-#pragma unroll
-                    for (int st = 0; st < S; ++st)
-                        for (int i = 0; i < a.n_fb; ++i) {
-                            const int off = fb[2 * i], end = min(off + fb[2 * i + 1], F);
-                            for (int k = off + lane; k < end; k += kWave) magbuf[st][k] = 0.f;
-                        }
-                    wave_sync_lds();
-                }
-            }
-#pragma unroll
-            for (int st = 0; st < S; ++st) {
-                const float keep = masked[st] ? 0.f : scale;
-                if constexpr (MELMODE == 0) {
-                    const float4* mag4 = reinterpret_cast<const float4*>(magbuf[st] + lo0);  // lo0 % 4 == 0
-                    float acc = 0.f;
-#pragma unroll
-                    for (int i = 0; i < kMelRegs / 4; ++i) {
-                        const float4 m4 = mag4[i];
-                        acc = fmaf(wreg[4 * i + 0], m4.x, acc);
-                        acc = fmaf(wreg[4 * i + 1], m4.y, acc);
-                        acc = fmaf(wreg[4 * i + 2], m4.z, acc);
-                        acc = fmaf(wreg[4 * i + 3], m4.w, acc);
+                        for (int q = 0; q < P / 2; ++q) mhi[-kWave * q] = cabs_rn(xhi[st][q]);
+                        if (lane == 0) magbuf[st][NC / 2] = 2.0f * cabs_rn(x[st][P / 2]);
                     }
-                    if (live[st] && lane < a.M) my_tile[fcur[st]] = acc * keep;
-                } else {
-                    if (live[st]) {
-                        for (int m = lane; m < a.M; m += kWave) {
-                            float acc = 0.f;
-                            if constexpr (MELMODE == 1) {
-                                const int lo = lotab[m];
-                                for (int i = 0; i < a.rows; ++i) acc = fmaf(wtab[i * a.M + m], magbuf[st][lo + i], acc);
-                            } else {
-                                const int lo = a.band_lo[m];
-                                for (int i = 0; i < a.rows; ++i)
-                                    acc = fmaf(a.wband[i * a.M + m], magbuf[st][lo + i], acc);
+                }
+                wave_sync_lds();
+                PH_MARK(4);
+            }
+            // prefetch: the next frames have landed (their DMA was issued a whole FFT ago); start
+            // pulling them into the now dead x registers and claim the frames after them
+            const bool more = fn[0] < nwf;  // wave-uniform
+            int claimed = 0;
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                read_frames();
+                if (lane == 0) claimed = atomicAdd(next_frame, S);
+            }
+            if (!all_masked) {
+                if constexpr (BANDS) {
+                    if (fb) {
+#pragma unroll
+                        for (int st = 0; st < S; ++st)
+                            for (int i = 0; i < a.n_fb; ++i) {
+                                const int off = fb[2 * i], end = min(off + fb[2 * i + 1], F);
+                                for (int k = off + lane; k < end; k += kWave) magbuf[st][k] = 0.f;
                             }
-                            tile_out[m * tile_stride + fcur[st]] = acc * keep;
+                        wave_sync_lds();
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < S; ++st) {
+                    const float keep = masked[st] ? 0.f : scale;
+                    if constexpr (MELMODE == 0) {
+                        const float4* mag4 = reinterpret_cast<const float4*>(magbuf[st] + lo0);  // lo0 % 4 == 0
+                        float acc = 0.f;
+#pragma unroll
+                        for (int i = 0; i < kMelRegs / 4; ++i) {
+                            const float4 m4 = mag4[i];
+                            acc = fmaf(wreg[4 * i + 0], m4.x, acc);
+                            acc = fmaf(wreg[4 * i + 1], m4.y, acc);
+                            acc = fmaf(wreg[4 * i + 2], m4.z, acc);
+                            acc = fmaf(wreg[4 * i + 3], m4.w, acc);
+                        }
+                        if (live[st] && lane < a.M) my_tile[fcur[st]] = acc * keep;
+                    } else {
+                        if (live[st]) {
+                            for (int m = lane; m < a.M; m += kWave) {
+                                float acc = 0.f;
+                                if constexpr (MELMODE == 1) {
+                                    const int lo = lotab[m];
+                                    for (int i = 0; i < a.rows; ++i)
+                                        acc = fmaf(wtab[i * a.M + m], magbuf[st][lo + i], acc);
+                                } else {
+                                    const int lo = a.band_lo[m];
+                                    for (int i = 0; i < a.rows; ++i)
+                                        acc = fmaf(a.wband[i * a.M + m], magbuf[st][lo + i], acc);
+                                }
+                                tile_out[m * tile_stride + fcur[st]] = acc * keep;
+                            }
                         }
                     }
                 }
+            } else {
+#pragma unroll
+                for (int st = 0; st < S; ++st)
+                    if (live[st])
+                        for (int m = lane; m < a.M; m += kWave) tile_out[m * tile_stride + fcur[st]] = 0.f;
             }
             wave_sync_lds();
+            PH_MARK(5);
+            // the frame reads and the claim have returned: the landing buffers are free again
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int st = 0; st < S; ++st) f[st] = fn[st];
+            if (more) {
+                claimed = __builtin_amdgcn_readfirstlane(claimed);
+#pragma unroll
+                for (int st = 0; st < S; ++st) fn[st] = claimed + st;
+                issue_dma(fn);
+            }
+            PH_MARK(2);
+            if ABL(4096) ph[7] += 1;
         }
+        PH_BEGIN();
         __syncthreads();
+        PH_MARK(6);
 
         // chunk epilogue: wave per mel row, a contiguous run of nt*C floats each
         const int run = nt * a.C;
         float mn = INFINITY, mx = -INFINITY;
         if constexpr (!FUSE) {
-            for (int m = wv; m < a.M; m += kFusedWaves) {
-                float* dst = a.out + (((size_t)b * a.M + m) * a.T + t0) * a.C;
-                const float* srow = tile_out + m * tile_stride;
-                for (int r = lane; r < run; r += kWave) {
-                    const float v = srow[r];
-                    if (!ABL(16)) dst[r] = v;
-                    mn = fminf(mn, v);
-                    mx = fmaxf(mx, v);
+            // wave w owns mel rows w, w + W, ...; three rows x two 64-float segments are read from
+            // the tile before the first store so that the LDS round trips overlap.  Every wave
+            // leaves its own (min, max) partial: no block reduction, and nothing waits for the
+            // global stores to be acknowledged.
+            float* dst0 = a.out + (((size_t)b * a.M) * a.T + t0) * a.C;
+            const int rowpitch = a.T * a.C;
+            if ABL(8192) {  // probe: one dummy LDS read right after the barrier
+                PH_BEGIN();
+                const float d = tile_out[lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(d) : "memory");
+                PH_MARK(15);
+            }
+            PH_MARK(12);
+            constexpr int RB = 6;  // rows per batch: all LDS reads of a batch are in flight together
+            for (int mb = wv; mb < a.M; mb += RB * kFusedWaves) {
+                for (int r0 = 0; r0 < run; r0 += 2 * kWave) {
+                    const int ra = r0 + lane, rb = ra + kWave;
+                    // clamped columns keep the (unconditional) reads inside the tile
+                    const float* cola = tile_out + min(ra, run - 1);
+                    const float* colb = tile_out + min(rb, run - 1);
+                    const unsigned offa = (unsigned)ra * 4u, offb = (unsigned)rb * 4u;  // byte offsets in a row
+                    float va[RB], vb[RB];
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) {
+                        const int rowoff = min(mb + j * kFusedWaves, a.M - 1) * tile_stride;  // uniform
+                        va[j] = cola[rowoff];
+                        vb[j] = colb[rowoff];
+                    }
+                    PH_MARK(13);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    PH_MARK(14);
+                    // stores: uniform row base (SGPR pair) + per-lane 32-bit byte offset
+                    if (ra < run) {
+#pragma unroll
+                        for (int j = 0; j < RB; ++j) {
+                            const int m = mb + j * kFusedWaves;
+                            if (m < a.M && !ABL(16))
+                                asm volatile("global_store_dword %0, %1, %2" ::"v"(offa), "v"(va[j]),
+                                             "s"(dst0 + (size_t)m * rowpitch)
+                                             : "memory");
+                        }
+                    }
+                    if (rb < run) {
+#pragma unroll
+                        for (int j = 0; j < RB; ++j) {
+                            const int m = mb + j * kFusedWaves;
+                            if (m < a.M && !ABL(16))
+                                asm volatile("global_store_dword %0, %1, %2" ::"v"(offb), "v"(vb[j]),
+                                             "s"(dst0 + (size_t)m * rowpitch)
+                                             : "memory");
+                        }
+                    }
+                    // clamped duplicates are values of this wave's own rows: harmless for min/max
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) {
+                        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(va[j]), "v"(vb[j]));
+                        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(va[j]), "v"(vb[j]));
+                    }
                 }
             }
-            block_minmax(mn, mx, red);  // ends with every thread past the tile reads
-            if (threadIdx.x == 0) {
-                a.partial[(size_t)chunk * 2 + 0] = mn;
-                a.partial[(size_t)chunk * 2 + 1] = mx;
-                *next_frame = kFusedWaves * S;
+            PH_MARK(9);
+            mn = wave_min(mn);
+            mx = wave_max(mx);
+            if (lane == 0) {
+                a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 0] = mn;
+                a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 1] = mx;
             }
-            __syncthreads();
+            if (chunk + (int)gridDim.x < a.n_chunks || ABL(16384)) {  // another chunk follows: recycle tile and queue
+                __syncthreads();
+                if (threadIdx.x == 0) *next_frame = kFusedWaves * S;
+                __syncthreads();
+            }
+            PH_MARK(10);
+            if ABL(16384) ph[pass] += __builtin_amdgcn_s_memtime() - pass_t;
         } else {
         // fused min-max / log: publish this chunk's (min, max), wait for the clip's other
         // chunks, normalise the tile still sitting in LDS and write the final values once.
@@ -718,6 +855,10 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
         }
         __syncthreads();
         }  // FUSE
+    }
+    if (ABL(4096) && lane == 0 && a.dbg && blockIdx.x < 4096) {
+        PH_MARK(11);  // since the last mark: loop exit to kernel end
+        for (int i = 0; i < 16; ++i) a.dbg[kDbgPhase0 + ((size_t)blockIdx.x * 16 + wv) * 16 + i] = ph[i];
     }
     if (ABL(512) && threadIdx.x == 0 && a.dbg) {
         if (blockIdx.x == 0) {
@@ -983,11 +1124,15 @@ __global__ __launch_bounds__(256) void k_minmax_log_apply(float* x, const float*
     float mn = 0.f, den = 1.f;
     if (do_minmax) {
         float lo = INFINITY, hi = -INFINITY;
-        if (n_part <= 64) {  // few partials: every thread folds them itself (uniform loads, no barrier)
-            for (int i = 0; i < n_part; ++i) {
-                lo = fminf(lo, partial[((size_t)row * n_part + i) * 2 + 0]);
-                hi = fmaxf(hi, partial[((size_t)row * n_part + i) * 2 + 1]);
+        if (n_part <= 256) {  // few partials: every wave folds them itself (no barrier)
+            const float2* pr = reinterpret_cast<const float2*>(partial) + (size_t)row * n_part;
+            for (int i = threadIdx.x & 63; i < n_part; i += 64) {
+                const float2 v = pr[i];
+                lo = fminf(lo, v.x);
+                hi = fmaxf(hi, v.y);
             }
+            lo = wave_min(lo);
+            hi = wave_max(hi);
         } else {
             for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
                 lo = fminf(lo, partial[((size_t)row * n_part + i) * 2 + 0]);
@@ -1566,9 +1711,9 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     // frame per tile) + [B, chunks] sums of squares for IRIS_F_NORMALIZE
     const int t_max = 1 + max_len / hop;
     const size_t wav_row = (size_t)channels * max_len;
-    p->ws_floats = 2 * (size_t)max_batch * t_max + (size_t)max_batch * ((wav_row + kChunk - 1) / kChunk) + 64;
-    (void)hipMalloc((void**)&p->d_dbg, (4 + 3 * 4096) * sizeof(unsigned long long));
-    if (p->d_dbg) (void)hipMemset(p->d_dbg, 0, (4 + 3 * 4096) * sizeof(unsigned long long));
+    p->ws_floats = 2 * 16 * (size_t)max_batch * t_max + (size_t)max_batch * ((wav_row + kChunk - 1) / kChunk) + 64;
+    (void)hipMalloc((void**)&p->d_dbg, kDbgWords * sizeof(unsigned long long));
+    if (p->d_dbg) (void)hipMemset(p->d_dbg, 0, kDbgWords * sizeof(unsigned long long));
     std::vector<unsigned> sync_init((size_t)max_batch * kSyncStride + kSyncStride, 0u);
     for (int b = 0; b < max_batch; ++b) sync_init[(size_t)b * kSyncStride + 2] = 0xffffffffu;  // min key
     hipError_t e = hipMalloc((void**)&p->d_sync, sync_init.size() * sizeof(unsigned));
@@ -1590,6 +1735,29 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
 extern "C" int iris_plan_destroy(iris_plan* p) {
     if (!p) return IRIS_OK;
     DeviceGuard guard(p->device);
+    if (p->d_dbg && getenv("IRIS_ABLATE") && (atoi(getenv("IRIS_ABLATE")) & 4096)) {
+        std::vector<unsigned long long> h(kDbgWords, 0);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h.data(), p->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int waves = 0;
+        for (int w = 0; w < 4096 * 16; ++w) {
+            const unsigned long long* r = &h[kDbgPhase0 + (size_t)w * 16];
+            if (!r[7]) continue;
+            ++waves;
+            for (int i = 0; i < 16; ++i) sum[i] += (double)r[i];
+        }
+        if (waves && sum[7] > 0)
+            fprintf(stderr, "[iris dbg] %d waves, %.2f frames each; cycles per frame: dma-wait %.0f, frame-read %.0f, "
+                    "claim+dma-issue %.0f, window+fft %.0f, untangle+mag %.0f, mel %.0f; per wave: chunk setup %.0f, chunk barrier %.0f, tile write-out %.0f, "
+                    "block min/max %.0f, exit %.0f; write-out parts: setup %.0f, lds issue %.0f, lds wait %.0f\n",
+                    waves, sum[7] / waves, sum[0] / sum[7], sum[1] / sum[7], sum[2] / sum[7], sum[3] / sum[7],
+                    sum[4] / sum[7], sum[5] / sum[7], sum[8] / waves, sum[6] / waves, sum[9] / waves,
+                    sum[10] / waves, sum[11] / waves, sum[12] / waves, sum[13] / waves, sum[14] / waves);
+        if (sum[15] > 0) fprintf(stderr, "[iris dbg] dummy LDS read after the barrier: %.0f cycles\n", sum[15] / waves);
+        if (sum[1] > 0 && (atoi(getenv("IRIS_ABLATE")) & 16384)) fprintf(stderr, "[iris dbg] whole chunk, cold pass %.0f cycles, warm pass %.0f cycles\n", sum[0] / waves, sum[1] / waves);
+
+    }
     if (p->d_dbg && getenv("IRIS_ABLATE") && (atoi(getenv("IRIS_ABLATE")) & 512)) {
         std::vector<unsigned long long> h(4 + 3 * 4096, 0);
         (void)hipDeviceSynchronize();
@@ -1818,6 +1986,8 @@ extern "C" int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minm
     hipStream_t s = (hipStream_t)stream;
     const size_t n_part = n_chunks_of(row_len);
     if (do_minmax) {
+        if (reinterpret_cast<uintptr_t>(workspace) & 7)
+            return fail(IRIS_E_INVALID, "iris_minmax_log: workspace must be 8-byte aligned");
         if (!workspace || workspace_floats < iris_minmax_log_workspace(n_rows, row_len))
             return fail(IRIS_E_CAPACITY, "iris_minmax_log: workspace %zu floats < %zu", workspace_floats,
                         iris_minmax_log_workspace(n_rows, row_len));
@@ -1922,7 +2092,11 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     if ((rc = fused_config(p, kernel, batch, a.T, streams, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
         return rc;
     a.n_chunks = batch * a.chunks_per_clip;
-    const size_t n_partial = 2 * (size_t)a.n_chunks;
+    a.chunk_base = a.T / a.chunks_per_clip;
+    a.chunk_rem = a.T % a.chunks_per_clip;
+    const int waves = fused_waves(p->log2n, streams);
+    const int parts_per_chunk = a.fuse ? 1 : waves;
+    const size_t n_partial = 2 * (size_t)a.n_chunks * parts_per_chunk;
     a.partial = p->d_ws;
     a.sumsq = nullptr;
     a.n_sq = 0;
@@ -1949,18 +2123,18 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         }
         FusedArgs args = a;
         void* kargs[] = {&args};
-        e = hipExtLaunchKernel((const void*)kernel, dim3(grid), dim3(64 * fused_waves(p->log2n, streams)), kargs, lds, s,
+        e = hipExtLaunchKernel((const void*)kernel, dim3(grid), dim3(64 * waves), kargs, lds, s,
                                p->ev[2 * p->ev_used], p->ev[2 * p->ev_used + 1], 0);
         if (e == hipSuccess) p->ev_used++;
     } else {
-        kernel<<<grid, 64 * fused_waves(p->log2n, streams), lds, s>>>(a);
+        kernel<<<grid, 64 * waves, lds, s>>>(a);
         e = hipGetLastError();
     }
     HIP_TRY(e);
     if (!a.fuse && (do_minmax || do_log)) {
         const size_t row_len = (size_t)p->n_mel * a.T * p->channels;
         const unsigned n_chunks = (unsigned)((row_len + kChunk - 1) / kChunk);
-        k_minmax_log_apply<<<dim3(n_chunks, batch), 256, 0, s>>>(out, p->d_ws, a.chunks_per_clip, row_len, do_minmax,
+        k_minmax_log_apply<<<dim3(n_chunks, batch), 256, 0, s>>>(out, p->d_ws, a.chunks_per_clip * parts_per_chunk, row_len, do_minmax,
                                                                do_log, 1e-8f, 1e-8f);
         HIP_TRY(hipGetLastError());
     }
