@@ -79,9 +79,7 @@ struct iris_plan {
     int rows, need_hi, mel_mode;
     float* d_ws;  // workspace
     unsigned long long* d_dbg;  // diagnostic stamps
-    unsigned* d_sync;           // [max_batch][kSyncStride] clip lines, then [1] timeout
     int streams;                // IRIS_STREAMS: frames in flight per wave (1 or 2)
-    int fuse_epilogue;          // IRIS_FUSE_MINMAX=1: min-max/log inside K1 (default 0: measured slower)
     size_t ws_floats;
     int num_cu;
     int chunk_target;  // 0 = auto; frames per chunk of the fused kernel (IRIS_CHUNK_FRAMES)
@@ -97,6 +95,14 @@ constexpr int kMaxTimedLaunches = 4096;
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
+// Hides a wave-uniform pointer from loop-invariant code motion: addresses derived from it are
+// computed where they are used instead of being hoisted (and spilled) across the frame loop.
+template <typename T>
+__device__ __forceinline__ T* opaque(T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 __device__ __forceinline__ int reflect_idx(int i, int len) {
     i = i < 0 ? -i : i;
     return i >= len ? 2 * (len - 1) - i : i;
@@ -161,16 +167,6 @@ __device__ __forceinline__ void block_minmax(float& mn, float& mx, float* red /*
         mx = fmaxf(mx, red[16 + i]);
     }
 }
-
-// Order-preserving map float -> uint (and back), so that unsigned atomic min/max order floats.
-__device__ __forceinline__ unsigned f2key(float f) {
-    const unsigned b = __float_as_uint(f);
-    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
-}
-__device__ __forceinline__ float key2f(unsigned k) {
-    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
-}
-constexpr int kSyncStride = 32;  // uint32 words per clip: one 128-byte line {arrive, depart, min key, max key}
 
 // Consecutive logical workgroup ids land on the same XCD (blocks b and b+8 share
 // one; bijective for any grid size).  Placement only affects speed.
@@ -307,17 +303,18 @@ __device__ __forceinline__ void load_consts(const float* consts, int lane, cf (&
 }
 
 // ---------------------------------------------------------------------------
-// K1: fused wav -> mel magnitudes (+ per-chunk min/max partials)
-//   work unit = chunk: `chunk_frames` consecutive frames of one clip, all C channels
+// K1: fused wav -> mel magnitudes (+ per-wave min/max partials)
+//   work unit = chunk: consecutive frames of one clip, all C channels
 //   grid      = min(#chunks, #CUs) workgroups of 12 waves (n_fft 2048: 8) looping over chunks
-//   per wave  = one frame at a time:
-//                 LDS-DMA (global_load_lds) of the NEXT frame into the wave's frame
+//   per wave  = one frame at a time, claimed from the chunk's LDS queue:
+//                 LDS-DMA (global_load_lds) of the NEXT frame into the wave's landing
 //                 buffer -- no VGPRs, reflect padding resolved in the DMA's per-lane
 //                 source address -- while the current frame is windowed, transformed
 //                 (registers + private padded LDS exchanges), untangled, |X| written
-//                 to LDS and reduced over the banded mel weights
-//   LDS       = per wave [frame buffer N floats | exchange buffer] | out tile
-//               [M][chunk_frames*C+1] | red[48] | mel table (mode 1)
+//                 to LDS and reduced over the banded mel weights; lane m stores band m of
+//                 the frame straight to out[b, m, t, c] (the L2 merges the 4-byte stores)
+//   LDS       = landing buffers [waves][N floats] | exchange buffers [waves] | frame queue |
+//               mel table (mode 1); after the prologue the waves share nothing but the queue
 //   MELMODE 0 = band weights in registers (M <= 64, band length <= 16): each lane reads
 //               a 16-byte-aligned window of 20 magnitudes with 5 ds_read_b128
 //           1 = band table staged in LDS, 2 = band table read from global (L1/L2)
@@ -336,7 +333,7 @@ constexpr int fused_waves(int log2n, int streams = 1) { return (log2n >= 11 || s
 struct FusedArgs {
     const float* wav;    // [B, C, L]
     float* out;          // [B, M, T, C]
-    float* partial;      // [B, chunks_per_clip * waves, 2] (min, max) per wave of each chunk (fused epilogue: per chunk)
+    float* partial;      // [B, chunks_per_clip * waves, 2] (min, max) per wave of each chunk
     const float* sumsq;  // nullable [B, n_sq] partial sums of squares (normalize)
     int n_sq;
     const float* consts;  // per-lane constant block (ConstLayout)
@@ -350,11 +347,6 @@ struct FusedArgs {
     int B, C, L, T, hop, M;
     int chunk_frames, chunks_per_clip, n_chunks;
     int chunk_base, chunk_rem;  // T = chunks_per_clip * chunk_base + chunk_rem; the first chunk_rem chunks take one more
-    // fused epilogue (mode 0 = raw mel + min/max partials for k_minmax_log_apply;
-    // 1 = min-max and/or log applied here, clips synchronised through arrive/depart)
-    int fuse, do_minmax, do_log;
-    unsigned* sync;     // [B][kSyncStride]: {arrive, depart, min key, max key} of each clip on its own line
-    unsigned* timeout;  // [1] set when a wait gave up (results for that chunk are not normalised)
     int ablate;  // diagnostic only (IRIS_ABLATE): skip phases, results are wrong when non-zero
     unsigned long long* dbg;  // diagnostic only: [4] shader-clock / 100 MHz stamps of workgroup 0
 };
@@ -439,7 +431,7 @@ __device__ __forceinline__ void dma_frame(const float* clip, int len, int start,
         dma_frame_x1<LOG2N>(clip, len, start, fbuf_lds, lane);
 }
 
-template <int LOG2N, int MELMODE, bool HI, bool BANDS, bool FUSE, int S>
+template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S>
 __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) / 4) void k_wav_to_mel(const FusedArgs a) {
     constexpr int kFusedWaves = fused_waves(LOG2N, S);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
@@ -447,108 +439,138 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the wave index is uniform: keep it (and everything derived from it) in SGPRs
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile_stride = a.chunk_frames * a.C + 1;
 
-    // per wave and stream: frame buffer (LDS-DMA target, N floats) | exchange buffer (also |X|)
+    // LDS: [waves][S] landing buffers (LDS-DMA targets, N floats) | [waves][S] exchange buffers
+    // (also |X|) | frame queue | MELMODE 1 tables.  Nothing is shared between waves but the queue.
     constexpr int kXBufBytes = (lds_padded(NC, FftCfg<LOG2N>::PMMAX) * 8 + 15) & ~15;
-    constexpr int kStreamBytes = N * 4 + kXBufBytes;
-    constexpr int kWaveBytes = S * kStreamBytes;
+    constexpr int kLandBytes = kFusedWaves * S * N * 4;
     const float* fbuf[S];
     unsigned fbuf_lds[S];
     cf* lds[S];
     float* magbuf[S];
 #pragma unroll
     for (int st = 0; st < S; ++st) {
-        char* base = smem + wv * kWaveBytes + st * kStreamBytes;
-        fbuf[st] = reinterpret_cast<const float*>(base);
-        fbuf_lds[st] = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)base);
-        lds[st] = reinterpret_cast<cf*>(base + N * 4);
-        magbuf[st] = reinterpret_cast<float*>(base + N * 4);
+        char* land = smem + (wv * S + st) * (N * 4);
+        char* xb = smem + kLandBytes + (wv * S + st) * kXBufBytes;
+        fbuf[st] = reinterpret_cast<const float*>(land);
+        fbuf_lds[st] = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)land);
+        lds[st] = reinterpret_cast<cf*>(xb);
+        magbuf[st] = reinterpret_cast<float*>(xb);
     }
-    float* tile_out = reinterpret_cast<float*>(smem + kFusedWaves * kWaveBytes);
-    float* red = tile_out + a.M * tile_stride;  // [48]: block_minmax [0,32), fused epilogue [32,34), frame queue [40]
-    int* next_frame = reinterpret_cast<int*>(red + 40);  // next unclaimed wave-frame of the current chunk
-    float* wtab = red + 48;                     // MELMODE 1: [rows][M] then int lo[M]
+    char* xbuf0 = smem + kLandBytes;
+    constexpr int kXAllBytes = kFusedWaves * S * kXBufBytes, kStageBytes = ConstLayout<LOG2N>::NV4 * kWave * 16;
+    int* next_frame = reinterpret_cast<int*>(xbuf0 + (kXAllBytes > kStageBytes ? kXAllBytes : kStageBytes));  // [4]
+    float* wtab = reinterpret_cast<float*>(next_frame + 4);  // MELMODE 1: [rows][M] then int lo[M]
     int* lotab = reinterpret_cast<int*>(wtab + a.rows * a.M);
 
     unsigned long long real_entry = 0;
     if ABL(512) real_entry = __builtin_amdgcn_s_memrealtime();
-    // per-lane constants, resident for the whole kernel
-    cf tw[NTW], post[P / 2], win[P];
-    float wreg[kMelRegs];
-    int lo0;
-    {
-        // the block is the same for every wave: fetch it from global once per workgroup (through
-        // the not-yet-used wave buffers) instead of once per wave
-        float4* stage = reinterpret_cast<float4*>(smem);
-        const float4* g = reinterpret_cast<const float4*>(a.consts);
-        for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
-        __syncthreads();
-        load_consts<LOG2N>(reinterpret_cast<const float*>(stage), lane, tw, post, win, wreg, lo0);
-        __syncthreads();
-    }
-    if constexpr (MELMODE == 1) {
-        for (int i = threadIdx.x; i < a.rows * a.M; i += blockDim.x) wtab[i] = a.wband[i];
-        for (int i = threadIdx.x; i < a.M; i += blockDim.x) lotab[i] = a.band_lo[i];
-    }
-    if (threadIdx.x == 0) *next_frame = kFusedWaves * S;
-    __syncthreads();
-    float* my_tile = tile_out + lane * tile_stride;
-
-    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // diag: cycles per loop phase
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // diag: cycles per phase
     (void)ph;
     (void)ph_t;
     unsigned long long stamp0 = 0, real0 = 0;
-    if ABL(512) {
-        stamp0 = __builtin_amdgcn_s_memtime();
-        real0 = __builtin_amdgcn_s_memrealtime();
-    }
+
+    cf tw[NTW], post[P / 2], win[P];  // per-lane constants, resident for the whole kernel
+    float wreg[kMelRegs];
+    int lo0 = 0;
+
     const int g0 = xcd_remap(blockIdx.x, gridDim.x);
-    unsigned long long pass_t = 0;
-    (void)pass_t;
-    for (int pass = 0; pass < (ABL(16384) ? 2 : 1); ++pass)
+    // chunk -> clip b, first frame t0, frame count nt (balanced split: sizes differ by at most one)
+    auto chunk_clip = [&](int chunk) { return chunk / a.chunks_per_clip; };
+    auto chunk_t0 = [&](int chunk, int b) {
+        const int ci = chunk - b * a.chunks_per_clip;
+        return ci * a.chunk_base + min(ci, a.chunk_rem);
+    };
+    auto chunk_nt = [&](int chunk, int b) {
+        return a.chunk_base + ((chunk - b * a.chunks_per_clip) < a.chunk_rem ? 1 : 0);
+    };
+    // LDS-DMA of wave-frames ff[] (f = tl * C + c) of a chunk into this wave's landing buffers
+    auto issue_dma = [&](const int (&ff)[S], int b, int t0, int nwf) {
+        const float* clip0 = a.wav + (size_t)b * a.C * a.L;
+#pragma unroll
+        for (int st = 0; st < S; ++st)
+            if (ff[st] < nwf && !ABL(8)) {
+                const int tl = (a.C == 1) ? ff[st] : ff[st] / a.C, c = ff[st] - tl * a.C;
+                dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
+            }
+    };
+    int f[S], fn[S];  // frames in registers / frames in flight to the landing buffers
+    if (g0 < a.n_chunks) {  // first frames of the first chunk: in flight while the constants are fetched
+        const int b = chunk_clip(g0);
+#pragma unroll
+        for (int st = 0; st < S; ++st) f[st] = wv * S + st;
+        issue_dma(f, b, chunk_t0(g0, b), chunk_nt(g0, b) * a.C);
+    }
+    {
+        // The constant block is the same for every wave: fetch it from global once per
+        // workgroup, through the exchange buffers (idle until the first FFT).
+        float4* stage = reinterpret_cast<float4*>(xbuf0);
+        const float4* g = reinterpret_cast<const float4*>(a.consts);
+        for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
+        if (threadIdx.x == 0) *next_frame = 2 * kFusedWaves * S;
+        __syncthreads();
+        load_consts<LOG2N>(reinterpret_cast<const float*>(stage), lane, tw, post, win, wreg, lo0);
+        if constexpr (MELMODE == 1) {
+            for (int i = threadIdx.x; i < a.rows * a.M; i += blockDim.x) wtab[i] = a.wband[i];
+            for (int i = threadIdx.x; i < a.M; i += blockDim.x) lotab[i] = a.band_lo[i];
+        }
+        __syncthreads();
+        if ABL(512) {
+            stamp0 = __builtin_amdgcn_s_memtime();
+            real0 = __builtin_amdgcn_s_memrealtime();
+        }
+    }
     for (int chunk = g0; chunk < a.n_chunks; chunk += gridDim.x) {
-        if ABL(16384) pass_t = __builtin_amdgcn_s_memtime();
         PH_BEGIN();
-        const int b = chunk / a.chunks_per_clip, ci = chunk - b * a.chunks_per_clip;
-        // balanced split of the clip's T frames over its chunks (sizes differ by at most one)
-        const int t0 = ci * a.chunk_base + min(ci, a.chunk_rem);
-        const int nt = a.chunk_base + (ci < a.chunk_rem ? 1 : 0);
+        const int b = chunk_clip(chunk);
+        const int t0 = chunk_t0(chunk, b), nt = chunk_nt(chunk, b);
         const int* tb = nullptr;
         const int* fb = nullptr;
         if constexpr (BANDS) {
             tb = a.t_bands ? a.t_bands + (size_t)b * a.n_tb * 2 : nullptr;
             fb = a.f_bands ? a.f_bands + (size_t)b * a.n_fb * 2 : nullptr;
         }
-        const float* clip0 = a.wav + (size_t)b * a.C * a.L;
+        const int nwf = nt * a.C;  // wave-frames in this chunk: f = tl * C + c
+
+        // Each wave keeps S frames in flight ("streams").  Frames are claimed S at a time from
+        // an LDS counter (waves that run ahead take more: the issue arbiter favours older
+        // waves, a static split leaves the younger ones a tail).  All cursor state is
+        // wave-uniform (SGPRs).  The loop is software-pipelined: while frame i is in its mel
+        // phase (its samples are no longer needed in registers) the wave already reads frame
+        // i+1 from its landing buffer and claims frame i+2, whose DMA is issued once those reads
+        // have returned - neither the LDS round trip of the frame read nor the queue atomic
+        // sits on the critical path.
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            f[st] = wv * S + st;
+            fn[st] = (kFusedWaves + wv) * S + st;  // second round is static too: the queue starts at 2 * waves * S
+        }
+        if (chunk != g0) issue_dma(f, b, t0, nwf);
 
         float scale = 1.0f;  // normalize: |X| is linear in the waveform, so 1 / (10 rms) scales the mel
         if (a.sumsq != nullptr) {
-            float s = 0.f;
-            for (int i = lane; i < a.n_sq; i += kWave) s += a.sumsq[(size_t)b * a.n_sq + i];
-            s = wave_sum(s);
-            scale = 1.0f / (sqrtf(s / ((float)a.C * (float)a.L)) * 10.0f);
+            float sq = 0.f;
+            const float* ssq = opaque(a.sumsq) + (size_t)b * a.n_sq;
+            int l0 = lane;
+            asm volatile("" : "+v"(l0));  // keep the (rarely used) per-lane address out of the loop's registers
+            for (int i = l0; i < a.n_sq; i += kWave) sq += ssq[i];
+            sq = wave_sum(sq);
+            scale = 1.0f / (sqrtf(sq / ((float)a.C * (float)a.L)) * 10.0f);
         }
 
-        const int nwf = nt * a.C;  // wave-frames in this chunk: f = tl * C + c
-        // Each wave keeps S frames in flight ("streams"): their butterflies, LDS exchanges and
-        // reductions are issued back to back, so the LDS round trip of one stream hides behind
-        // the arithmetic of the other.  Frames are claimed S at a time from an LDS counter
-        // (waves that run ahead take more: the issue arbiter favours older waves, a static split
-        // leaves the younger ones a tail).  All cursor state is wave-uniform (SGPRs).
-        //
-        // The loop is software-pipelined: while frame i is in its mel phase (its samples are no
-        // longer needed in registers) the wave already reads frame i+1 from its landing buffer and
-        // claims frame i+2, whose DMA is issued once those reads have returned - so neither the
-        // LDS round trip of the frame read nor the queue atomic sits on the critical path.
-        auto issue_dma = [&](const int (&ff)[S]) {
-#pragma unroll
-            for (int st = 0; st < S; ++st)
-                if (ff[st] < nwf && !ABL(8)) {
-                    const int tl = (a.C == 1) ? ff[st] : ff[st] / a.C, c = ff[st] - tl * a.C;
-                    dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
-                }
+        // Output: lane m owns mel band m (+64, ...); a frame's M values go straight to
+        // out[b, m, t, c] - 4-byte stores one row pitch apart, merged into full lines by the L2
+        // (the whole output is a few MB).  No LDS tile, no workgroup barrier, no write-out phase:
+        // after the prologue the waves only share the frame queue.
+        // address = (uniform) out + ((b M T + t0) C + f) * 4  +  (per lane) m * T * C * 4
+        const unsigned rowpitch_b = (unsigned)a.T * (unsigned)a.C * 4u;
+        float* const chunk_out = a.out + ((size_t)b * a.M * a.T + t0) * a.C;
+        auto store_band = [&](int fidx, unsigned off, float v) {
+            if (!ABL(16))
+                asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(chunk_out + fidx) : "memory");
         };
+        float mn = INFINITY, mx = -INFINITY;
+
         cf x[S][P];
         auto read_frames = [&]() {  // landing buffers -> registers (asynchronous: lgkmcnt)
 #pragma unroll
@@ -558,21 +580,10 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                 for (int q = 0; q < P; ++q) x[st][q] = fb2[kWave * q];
             }
         };
-        int f[S], fn[S];  // frames in registers / frames in flight to the landing buffers
-#pragma unroll
-        for (int st = 0; st < S; ++st) f[st] = wv * S + st;
-        issue_dma(f);
-        {
-            int nf = 0;
-            if (lane == 0) nf = atomicAdd(next_frame, S);
-            nf = __builtin_amdgcn_readfirstlane(nf);
-#pragma unroll
-            for (int st = 0; st < S; ++st) fn[st] = nf + st;
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         read_frames();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        issue_dma(fn);
+        issue_dma(fn, b, t0, nwf);
         PH_MARK(8);
         while (f[0] < nwf) {
             PH_BEGIN();
@@ -656,7 +667,12 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                             acc = fmaf(wreg[4 * i + 2], m4.z, acc);
                             acc = fmaf(wreg[4 * i + 3], m4.w, acc);
                         }
-                        if (live[st] && lane < a.M) my_tile[fcur[st]] = acc * keep;
+                        if (live[st] && lane < a.M) {
+                            const float v = acc * keep;
+                            store_band(fcur[st], __umul24((unsigned)lane, rowpitch_b), v);  // host checks rowpitch < 2^24
+                            mn = fminf(mn, v);
+                            mx = fmaxf(mx, v);
+                        }
                     } else {
                         if (live[st]) {
                             for (int m = lane; m < a.M; m += kWave) {
@@ -670,7 +686,10 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                                     for (int i = 0; i < a.rows; ++i)
                                         acc = fmaf(a.wband[i * a.M + m], magbuf[st][lo + i], acc);
                                 }
-                                tile_out[m * tile_stride + fcur[st]] = acc * keep;
+                                const float v = acc * keep;
+                                store_band(fcur[st], (unsigned)m * rowpitch_b, v);
+                                mn = fminf(mn, v);
+                                mx = fmaxf(mx, v);
                             }
                         }
                     }
@@ -679,7 +698,11 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
 #pragma unroll
                 for (int st = 0; st < S; ++st)
                     if (live[st])
-                        for (int m = lane; m < a.M; m += kWave) tile_out[m * tile_stride + fcur[st]] = 0.f;
+                        for (int m = lane; m < a.M; m += kWave) {
+                            store_band(fcur[st], (unsigned)m * rowpitch_b, 0.f);
+                            mn = fminf(mn, 0.f);
+                            mx = fmaxf(mx, 0.f);
+                        }
             }
             wave_sync_lds();
             PH_MARK(5);
@@ -691,170 +714,25 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                 claimed = __builtin_amdgcn_readfirstlane(claimed);
 #pragma unroll
                 for (int st = 0; st < S; ++st) fn[st] = claimed + st;
-                issue_dma(fn);
+                issue_dma(fn, b, t0, nwf);
             }
             PH_MARK(2);
             if ABL(4096) ph[7] += 1;
         }
         PH_BEGIN();
-        __syncthreads();
-        PH_MARK(6);
-
-        // chunk epilogue: wave per mel row, a contiguous run of nt*C floats each
-        const int run = nt * a.C;
-        float mn = INFINITY, mx = -INFINITY;
-        if constexpr (!FUSE) {
-            // wave w owns mel rows w, w + W, ...; three rows x two 64-float segments are read from
-            // the tile before the first store so that the LDS round trips overlap.  Every wave
-            // leaves its own (min, max) partial: no block reduction, and nothing waits for the
-            // global stores to be acknowledged.
-            float* dst0 = a.out + (((size_t)b * a.M) * a.T + t0) * a.C;
-            const int rowpitch = a.T * a.C;
-            if ABL(8192) {  // probe: one dummy LDS read right after the barrier
-                PH_BEGIN();
-                const float d = tile_out[lane];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(d) : "memory");
-                PH_MARK(15);
-            }
-            PH_MARK(12);
-            constexpr int RB = 6;  // rows per batch: all LDS reads of a batch are in flight together
-            for (int mb = wv; mb < a.M; mb += RB * kFusedWaves) {
-                for (int r0 = 0; r0 < run; r0 += 2 * kWave) {
-                    const int ra = r0 + lane, rb = ra + kWave;
-                    // clamped columns keep the (unconditional) reads inside the tile
-                    const float* cola = tile_out + min(ra, run - 1);
-                    const float* colb = tile_out + min(rb, run - 1);
-                    const unsigned offa = (unsigned)ra * 4u, offb = (unsigned)rb * 4u;  // byte offsets in a row
-                    float va[RB], vb[RB];
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) {
-                        const int rowoff = min(mb + j * kFusedWaves, a.M - 1) * tile_stride;  // uniform
-                        va[j] = cola[rowoff];
-                        vb[j] = colb[rowoff];
-                    }
-                    PH_MARK(13);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    PH_MARK(14);
-                    // stores: uniform row base (SGPR pair) + per-lane 32-bit byte offset
-                    if (ra < run) {
-#pragma unroll
-                        for (int j = 0; j < RB; ++j) {
-                            const int m = mb + j * kFusedWaves;
-                            if (m < a.M && !ABL(16))
-                                asm volatile("global_store_dword %0, %1, %2" ::"v"(offa), "v"(va[j]),
-                                             "s"(dst0 + (size_t)m * rowpitch)
-                                             : "memory");
-                        }
-                    }
-                    if (rb < run) {
-#pragma unroll
-                        for (int j = 0; j < RB; ++j) {
-                            const int m = mb + j * kFusedWaves;
-                            if (m < a.M && !ABL(16))
-                                asm volatile("global_store_dword %0, %1, %2" ::"v"(offb), "v"(vb[j]),
-                                             "s"(dst0 + (size_t)m * rowpitch)
-                                             : "memory");
-                        }
-                    }
-                    // clamped duplicates are values of this wave's own rows: harmless for min/max
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) {
-                        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(va[j]), "v"(vb[j]));
-                        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(va[j]), "v"(vb[j]));
-                    }
-                }
-            }
-            PH_MARK(9);
-            mn = wave_min(mn);
-            mx = wave_max(mx);
-            if (lane == 0) {
-                a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 0] = mn;
-                a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 1] = mx;
-            }
-            if (chunk + (int)gridDim.x < a.n_chunks || ABL(16384)) {  // another chunk follows: recycle tile and queue
-                __syncthreads();
-                if (threadIdx.x == 0) *next_frame = kFusedWaves * S;
-                __syncthreads();
-            }
-            PH_MARK(10);
-            if ABL(16384) ph[pass] += __builtin_amdgcn_s_memtime() - pass_t;
-        } else {
-        // fused min-max / log: publish this chunk's (min, max), wait for the clip's other
-        // chunks, normalise the tile still sitting in LDS and write the final values once.
-        // Placement-independent protocol: 8-byte agent-scope atomics carry the payload
-        // (no tearing), an agent-scope counter signals it; every workgroup publishes BEFORE
-        // it waits and the grid never exceeds what is resident, so the wait always ends;
-        // it is bounded anyway (timeout word).
-        float gmn = 0.f, den = 1.f;
-        if (a.do_minmax) {
-            for (int m = wv; m < a.M; m += kFusedWaves) {
-                const float* srow = tile_out + m * tile_stride;
-                for (int r = lane; r < run; r += kWave) {
-                    const float v = srow[r];
-                    mn = fminf(mn, v);
-                    mx = fmaxf(mx, v);
-                }
-            }
-            block_minmax(mn, mx, red);
-            unsigned* line = a.sync + (size_t)b * kSyncStride;
-            if (threadIdx.x == 0) {
-                // memory-side atomics fold this chunk into the clip's (min, max); once they are
-                // acknowledged the arrival is counted
-                const unsigned need = (unsigned)a.chunks_per_clip;
-                __hip_atomic_fetch_min(&line[2], f2key(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_max(&line[3], f2key(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                unsigned seen = __hip_atomic_fetch_add(&line[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-                bool ok = true;
-                unsigned spins = 0;
-                while (!ABL(1024) && seen < need) {  // the last arriver never polls
-                    __builtin_amdgcn_s_sleep(16);     // ~0.5 us: keeps the poll rate per line low
-                    seen = __hip_atomic_load(&line[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (++spins > (1u << 21)) {       // ~1 s: give up, flag it
-                        ok = false;
-                        __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-                float lo = 0.f, hi = 1.f;  // timed out: identity transform for this chunk
-                if (ok) {
-                    const unsigned long long pk = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&line[2]),
-                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    lo = key2f((unsigned)(pk & 0xffffffffull));
-                    hi = key2f((unsigned)(pk >> 32));
-                }
-                red[32] = lo;
-                red[33] = fmaxf(hi - lo, 1e-8f);
-            }
+        // every wave leaves its own (min, max) partial for k_minmax_log_apply
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        if (lane == 0) {
+            a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 0] = mn;
+            a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 1] = mx;
+        }
+        if (chunk + (int)gridDim.x < a.n_chunks) {  // another chunk follows: restart the queue
             __syncthreads();
-            gmn = red[32];
-            den = red[33];
+            if (threadIdx.x == 0) *next_frame = 2 * kFusedWaves * S;
+            __syncthreads();
         }
-        for (int m = wv; m < a.M; m += kFusedWaves) {
-            float* dst = a.out + (((size_t)b * a.M + m) * a.T + t0) * a.C;
-            const float* srow = tile_out + m * tile_stride;
-            for (int r = lane; r < run; r += kWave) {
-                float v = srow[r];
-                if (a.do_minmax) v = (v - gmn) / den;
-                if (a.do_log) v = logf(v + 1e-8f);
-                dst[r] = v;
-            }
-        }
-        if (threadIdx.x == 0) *next_frame = kFusedWaves * S;
-        if (a.do_minmax && threadIdx.x == 0) {
-            // done with the clip's line (off the critical path): the clip's last chunk to get
-            // here re-arms it for the next launch
-            unsigned* line = a.sync + (size_t)b * kSyncStride;
-            const unsigned prev = __hip_atomic_fetch_add(&line[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev + 1 == (unsigned)a.chunks_per_clip) {
-                __hip_atomic_store(&line[2], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&line[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&line[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&line[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-        }  // FUSE
+        PH_MARK(10);
     }
     if (ABL(4096) && lane == 0 && a.dbg && blockIdx.x < 4096) {
         PH_MARK(11);  // since the last mark: loop exit to kernel end
@@ -1376,6 +1254,14 @@ static int fft_ntw(int log2n) {
     }
 }
 static int fft_p(int log2n) { return (1 << log2n) / 2 / 64; }
+static int const_nv4(int log2n) {
+    switch (log2n) {
+        case 11: return ConstLayout<11>::NV4;
+        case 10: return ConstLayout<10>::NV4;
+        case 9: return ConstLayout<9>::NV4;
+        default: return ConstLayout<8>::NV4;
+    }
+}
 static size_t wave_buf_bytes(int log2n) {
     const int NC = (1 << log2n) / 2;
     switch (log2n) {
@@ -1433,51 +1319,48 @@ static int upload(T** dst, const std::vector<T>& src) {
     return IRIS_OK;
 }
 
-static int plan_streams(const iris_plan* p, bool fuse) {
-    return (p->streams == 2 && !fuse && (p->log2n == 9 || p->log2n == 10)) ? 2 : 1;
+static int plan_streams(const iris_plan* p) {
+    return (p->streams == 2 && (p->log2n == 9 || p->log2n == 10)) ? 2 : 1;
 }
 
-static size_t fused_lds_bytes(const iris_plan* p, int chunk_frames, int streams) {
+// LDS of the fused kernel: landing + exchange buffers of every wave (the constant block is
+// staged through the exchange area once), the frame queue, the MELMODE 1 tables
+static size_t fused_lds_bytes(const iris_plan* p, int streams) {
     const size_t xbuf = (wave_buf_bytes(p->log2n) + 15) & ~(size_t)15;
-    size_t bytes = (size_t)fused_waves(p->log2n, streams) * streams * ((size_t)p->n_fft * 4 + xbuf);
-    bytes += ((size_t)p->n_mel * (chunk_frames * p->channels + 1) + 48) * 4;
+    const size_t waves = (size_t)fused_waves(p->log2n, streams) * streams;
+    size_t bytes = waves * (size_t)p->n_fft * 4 + std::max(waves * xbuf, (size_t)const_nv4(p->log2n) * 64 * 16) + 16;
     if (p->mel_mode == 1) bytes += ((size_t)p->rows * p->n_mel + p->n_mel) * 4;
     return bytes;
 }
 
 typedef void (*fused_kernel_t)(const FusedArgs);
 
-template <int LOG2N, int MELMODE, bool FUSE, int S>
+template <int LOG2N, int MELMODE, int S>
 static fused_kernel_t fused_kernel_hb(bool hi, bool bands) {
     if (hi)
-        return bands ? k_wav_to_mel<LOG2N, MELMODE, true, true, FUSE, S>
-                     : k_wav_to_mel<LOG2N, MELMODE, true, false, FUSE, S>;
-    return bands ? k_wav_to_mel<LOG2N, MELMODE, false, true, FUSE, S>
-                 : k_wav_to_mel<LOG2N, MELMODE, false, false, FUSE, S>;
+        return bands ? k_wav_to_mel<LOG2N, MELMODE, true, true, S> : k_wav_to_mel<LOG2N, MELMODE, true, false, S>;
+    return bands ? k_wav_to_mel<LOG2N, MELMODE, false, true, S> : k_wav_to_mel<LOG2N, MELMODE, false, false, S>;
 }
-template <int LOG2N, bool FUSE, int S>
+template <int LOG2N, int S>
 static fused_kernel_t fused_kernel_mm(int mel_mode, bool hi, bool bands) {
-    if (mel_mode == 0) return fused_kernel_hb<LOG2N, 0, FUSE, S>(hi, bands);
-    if (mel_mode == 1) return fused_kernel_hb<LOG2N, 1, FUSE, S>(hi, bands);
-    return fused_kernel_hb<LOG2N, 2, FUSE, S>(hi, bands);
+    if (mel_mode == 0) return fused_kernel_hb<LOG2N, 0, S>(hi, bands);
+    if (mel_mode == 1) return fused_kernel_hb<LOG2N, 1, S>(hi, bands);
+    return fused_kernel_hb<LOG2N, 2, S>(hi, bands);
 }
-// two frame streams per wave exist for n_fft 512 / 1024 without the fused epilogue
-static bool streams2_available(int log2n, bool fuse) { return !fuse && (log2n == 9 || log2n == 10); }
-
+// two frame streams per wave exist for n_fft 512 / 1024
 template <int LOG2N>
-static fused_kernel_t fused_kernel_m(int mel_mode, bool hi, bool bands, bool fuse, int streams) {
+static fused_kernel_t fused_kernel_m(int mel_mode, bool hi, bool bands, int streams) {
     if constexpr (LOG2N == 9 || LOG2N == 10) {
-        if (streams == 2 && !fuse) return fused_kernel_mm<LOG2N, false, 2>(mel_mode, hi, bands);
+        if (streams == 2) return fused_kernel_mm<LOG2N, 2>(mel_mode, hi, bands);
     }
-    if (fuse) return fused_kernel_mm<LOG2N, true, 1>(mel_mode, hi, bands);
-    return fused_kernel_mm<LOG2N, false, 1>(mel_mode, hi, bands);
+    return fused_kernel_mm<LOG2N, 1>(mel_mode, hi, bands);
 }
-static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands, bool fuse, int streams) {
+static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands, int streams) {
     switch (log2n) {
-        case 11: return fused_kernel_m<11>(mel_mode, hi, bands, fuse, streams);
-        case 10: return fused_kernel_m<10>(mel_mode, hi, bands, fuse, streams);
-        case 9: return fused_kernel_m<9>(mel_mode, hi, bands, fuse, streams);
-        default: return fused_kernel_m<8>(mel_mode, hi, bands, fuse, streams);
+        case 11: return fused_kernel_m<11>(mel_mode, hi, bands, streams);
+        case 10: return fused_kernel_m<10>(mel_mode, hi, bands, streams);
+        case 9: return fused_kernel_m<9>(mel_mode, hi, bands, streams);
+        default: return fused_kernel_m<8>(mel_mode, hi, bands, streams);
     }
 }
 static const void* stft_kernel(int log2n) {
@@ -1493,13 +1376,11 @@ static const void* stft_kernel(int log2n) {
 static hipError_t allow_big_lds(const iris_plan* p) {
     constexpr int kMaxLds = 160 * 1024;
     hipError_t e;
-    for (int v = 0; v < 8; ++v) {
-        const bool fuse = (v & 2) != 0;
-        const int streams = (v & 4) ? 2 : 1;
-        if (streams == 2 && !streams2_available(p->log2n, fuse)) continue;
-        e = hipFuncSetAttribute(
-            (const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, (v & 1) != 0, fuse, streams),
-            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    for (int v = 0; v < 4; ++v) {
+        const int streams = (v & 2) ? 2 : 1;
+        if (streams == 2 && p->log2n != 9 && p->log2n != 10) continue;
+        e = hipFuncSetAttribute((const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, (v & 1) != 0, streams),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
         if (e != hipSuccess) return e;
     }
     return hipFuncSetAttribute(stft_kernel(p->log2n), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
@@ -1554,11 +1435,8 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->d_bin_w = nullptr;
     p->d_wband = p->d_mel = p->d_ws = nullptr;
     p->d_dbg = nullptr;
-    p->d_sync = nullptr;
-    p->fuse_epilogue = 0;
     p->streams = 1;
     if (const char* e = getenv("IRIS_STREAMS")) p->streams = atoi(e) == 2 ? 2 : 1;
-    if (const char* e = getenv("IRIS_FUSE_MINMAX")) p->fuse_epilogue = atoi(e) != 0;
     p->timing = false;
     p->ev_used = 0;
 
@@ -1702,9 +1580,9 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     }
     p->chunk_target = 0;
     if (const char* e = getenv("IRIS_CHUNK_FRAMES")) p->chunk_target = std::max(0, atoi(e));
-    if (!mel_only && fused_lds_bytes(p, 1, 1) > 160 * 1024) {
+    if (!mel_only && fused_lds_bytes(p, 1) > 160 * 1024) {
         iris_plan_destroy(p);
-        return fail(IRIS_E_UNSUPPORTED, "n_mel=%d x channels=%d does not fit the LDS out tile", n_mel, channels);
+        return fail(IRIS_E_UNSUPPORTED, "n_mel=%d: the band table does not fit the LDS", n_mel);
     }
 
     // workspace of the fused path: [B, tiles, 2] min/max partials (worst case one
@@ -1714,15 +1592,7 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->ws_floats = 2 * 16 * (size_t)max_batch * t_max + (size_t)max_batch * ((wav_row + kChunk - 1) / kChunk) + 64;
     (void)hipMalloc((void**)&p->d_dbg, kDbgWords * sizeof(unsigned long long));
     if (p->d_dbg) (void)hipMemset(p->d_dbg, 0, kDbgWords * sizeof(unsigned long long));
-    std::vector<unsigned> sync_init((size_t)max_batch * kSyncStride + kSyncStride, 0u);
-    for (int b = 0; b < max_batch; ++b) sync_init[(size_t)b * kSyncStride + 2] = 0xffffffffu;  // min key
-    hipError_t e = hipMalloc((void**)&p->d_sync, sync_init.size() * sizeof(unsigned));
-    if (e == hipSuccess)
-        e = hipMemcpy(p->d_sync, sync_init.data(), sync_init.size() * sizeof(unsigned), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        iris_plan_destroy(p);
-        return fail((int)e, "hipMalloc/hipMemcpy(sync words) failed: %s", hipGetErrorString(e));
-    }
+    hipError_t e;
     e = hipMalloc((void**)&p->d_ws, p->ws_floats * sizeof(float));
     if (e != hipSuccess) {
         iris_plan_destroy(p);
@@ -1792,7 +1662,6 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
                     loop / n * 0.01);
     }
     (void)hipFree(p->d_dbg);
-    (void)hipFree(p->d_sync);
     for (hipEvent_t ev : p->ev) (void)hipEventDestroy(ev);
     (void)hipFree(p->d_consts);
     (void)hipFree(p->d_band_lo);
@@ -2001,46 +1870,33 @@ extern "C" int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minm
 
 // Chunk geometry of the fused kernel for `per_cu` workgroups per CU: every workgroup one
 // chunk when the problem is large enough, chunks never span clips.
-static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int streams, int* chunk_frames,
-                           int* chunks_per_clip) {
+static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int* chunk_frames, int* chunks_per_clip) {
     const int slots = p->num_cu * per_cu;
     const long total = (long)batch * T;
-    // frames per chunk are capped by the LDS left for the out tile (one workgroup per CU owns
-    // the whole 160 KiB)
-    const size_t fixed = fused_lds_bytes(p, 0, streams) + 1024;
-    const size_t room = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
-    int cap = 512;
-    while (cap > 1 && (size_t)p->n_mel * (cap * p->channels) * 4 > room) --cap;
     int target = p->chunk_target > 0 ? p->chunk_target : (int)((total + slots - 1) / slots);
-    target = std::max(std::min(target, cap), std::min(8, cap));
+    target = std::max(target, std::min(8, T));
     int cpc = (T + target - 1) / target;
     // rounding up per clip can overshoot the slots by a few chunks, which would cost a whole
     // second round: prefer slightly larger chunks that fit one round
-    if ((long)batch * cpc > slots && batch <= slots) {
-        const int fit = slots / batch;
-        if (fit >= 1 && (T + fit - 1) / fit <= cap) cpc = fit;
-    }
+    if ((long)batch * cpc > slots && batch <= slots) cpc = std::max(1, slots / batch);
     *chunks_per_clip = cpc;
     *chunk_frames = (T + cpc - 1) / cpc;
 }
 
-// Geometry + grid with the residency the hardware really grants: the fused epilogue
-// makes workgroups of a clip wait for each other, which is only safe when every
-// workgroup of the grid is resident.  LDS use depends on the chunk size and the chunk
-// size on the number of resident workgroups, so iterate from the register-limited
-// occupancy downwards until the occupancy query agrees.
+// Geometry + grid for the residency the hardware really grants (registers and LDS): start from
+// the register-limited occupancy and go down until the occupancy query agrees.
 static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, int* chunk_frames,
                         int* chunks_per_clip, int* grid, size_t* lds) {
+    *lds = fused_lds_bytes(p, streams);
+    if (*lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
     for (int per_cu = fused_occ(p->log2n); per_cu >= 1; --per_cu) {
-        fused_geometry(p, batch, T, per_cu, streams, chunk_frames, chunks_per_clip);
-        *lds = fused_lds_bytes(p, *chunk_frames, streams);
-        if (*lds > 160 * 1024) continue;
         int resident = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
                                                                     64 * fused_waves(p->log2n, streams), *lds);
         if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s",
                                          hipGetErrorString(e));
         if (resident >= per_cu) {
+            fused_geometry(p, batch, T, per_cu, chunk_frames, chunks_per_clip);
             *grid = std::min(batch * *chunks_per_clip, p->num_cu * per_cu);
             return IRIS_OK;
         }
@@ -2076,26 +1932,23 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     a.hop = p->hop;
     a.M = p->n_mel;
     const int do_minmax = (flags & IRIS_F_MINMAX) ? 1 : 0, do_log = (flags & IRIS_F_LOG) ? 1 : 0;
-    a.fuse = (p->fuse_epilogue && (do_minmax || do_log)) ? 1 : 0;
-    a.do_minmax = do_minmax;
-    a.do_log = do_log;
-    a.sync = p->d_sync;
-    a.timeout = p->d_sync + (size_t)p->max_batch * kSyncStride;
     a.ablate = 0;
     if (const char* e = getenv("IRIS_ABLATE")) a.ablate = atoi(e);
     a.dbg = p->d_dbg;
     const bool bands = (n_tb > 0) || (n_fb > 0);
-    const int streams = plan_streams(p, a.fuse != 0);
-    const fused_kernel_t kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, a.fuse != 0, streams);
+    const int streams = plan_streams(p);
+    const fused_kernel_t kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams);
     int grid = 0;
     size_t lds = 0;
     if ((rc = fused_config(p, kernel, batch, a.T, streams, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
         return rc;
+    if ((size_t)p->n_mel * a.T * p->channels * 4 > 0xffffffffull || (size_t)a.T * p->channels * 4 >= (1u << 24))
+        return fail(IRIS_E_UNSUPPORTED, "iris_wav_to_logmel: clip too long (%d frames x %d channels)", a.T, p->channels);
     a.n_chunks = batch * a.chunks_per_clip;
     a.chunk_base = a.T / a.chunks_per_clip;
     a.chunk_rem = a.T % a.chunks_per_clip;
     const int waves = fused_waves(p->log2n, streams);
-    const int parts_per_chunk = a.fuse ? 1 : waves;
+    const int parts_per_chunk = waves;
     const size_t n_partial = 2 * (size_t)a.n_chunks * parts_per_chunk;
     a.partial = p->d_ws;
     a.sumsq = nullptr;
@@ -2131,7 +1984,7 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         e = hipGetLastError();
     }
     HIP_TRY(e);
-    if (!a.fuse && (do_minmax || do_log)) {
+    if (do_minmax || do_log) {
         const size_t row_len = (size_t)p->n_mel * a.T * p->channels;
         const unsigned n_chunks = (unsigned)((row_len + kChunk - 1) / kChunk);
         k_minmax_log_apply<<<dim3(n_chunks, batch), 256, 0, s>>>(out, p->d_ws, a.chunks_per_clip * parts_per_chunk, row_len, do_minmax,

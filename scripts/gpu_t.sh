@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_frontend_gpu.py -x -q -m gpu 2>&1 | tail -40

@@ -267,29 +267,6 @@ def test_linearity_and_silence_at_full_size(dev):
     assert float(((un - fu).abs() / un.abs().clamp_min(1e-3)).max()) <= 2e-6
 
 
-def test_fused_minmax_epilogue_option(golden_dir, dev, monkeypatch):
-    """IRIS_FUSE_MINMAX=1 applies min-max/log inside the main kernel (clip-level arrival
-    counters, one launch).  Same results as the default two-kernel path, launch after
-    launch (the counters re-arm themselves)."""
-    g = np.load(os.path.join(golden_dir, "c1_mono_2s.npz"))
-    monkeypatch.setenv("IRIS_FUSE_MINMAX", "1")
-    plan = make_plan(g, dev, batch=3)
-    monkeypatch.delenv("IRIS_FUSE_MINMAX")
-    plan2 = make_plan(g, dev, batch=3)
-    wav = torch.from_numpy(np.stack([g["wav"], 0.5 * g["wav"][:, ::-1].copy(), 2.0 * g["wav"]])).to(dev)
-    ref = plan2.wav_to_logmel(wav).cpu().numpy()
-    for _ in range(5):
-        out = plan.wav_to_logmel(wav).cpu().numpy()
-        assert np.abs(np.exp(out) - np.exp(ref)).max() <= 2e-6
-    assert np.abs(np.exp(out[0]) - np.exp(g["logmel"])).max() <= 5e-6
-    raw = plan.wav_to_logmel(wav, minmax=False, log=True).cpu().numpy()
-    assert np.abs(raw - plan2.wav_to_logmel(wav, minmax=False, log=True).cpu().numpy()).max() <= 1e-6
-    rng = np.random.default_rng(0)
-    tb = np.stack([R.mask_draw(rng, 126, 24, 6) for _ in range(3)]).transpose(0, 2, 1)
-    out = plan.wav_to_logmel(wav, t_bands=tb).cpu().numpy()
-    assert np.abs(np.exp(out) - np.exp(plan2.wav_to_logmel(wav, t_bands=tb).cpu().numpy())).max() <= 2e-6
-
-
 @pytest.mark.parametrize("n_fft,hop,m,c", [(512, 256, 80, 2), (2048, 512, 128, 2), (256, 64, 40, 1), (1024, 256, 64, 2)])
 def test_bands_all_fft_sizes(dev, n_fft, hop, m, c):
     """SpecAugment / filter bands inside the fused kernel for every FFT size and mel mode."""
