@@ -328,7 +328,9 @@ __device__ __forceinline__ void load_consts(const float* consts, int lane, cf (&
 constexpr int fused_occ(int log2n) { return 1; }
 // waves per workgroup: 3 per SIMD with one frame per wave (168 VGPRs); 2 per SIMD when a wave keeps
 // two frames in flight or at n_fft 2048 (256 VGPRs)
-constexpr int fused_waves(int log2n, int streams = 1) { return (log2n >= 11 || streams > 1) ? 8 : 12; }
+constexpr int fused_waves(int log2n, int streams = 1) {
+    return (log2n >= 11 || streams > 1) ? 8 : (log2n <= 9 ? 16 : 12);
+}
 
 struct FusedArgs {
     const float* wav;    // [B, C, L]
@@ -994,20 +996,31 @@ __global__ __launch_bounds__(256) void k_minmax_partial(const float* x, float* p
     }
 }
 
+// One float4 per thread (kApply elements per block): at a few MB per launch the kernel is bound
+// by instruction latency, not bandwidth, so it wants many short waves.  The element load is
+// issued before the partials are folded (two independent round trips overlap).
+constexpr int kApply = 1024;
 __global__ __launch_bounds__(256) void k_minmax_log_apply(float* x, const float* partial, int n_part,
                                                           size_t row_len, int do_minmax, int do_log,
                                                           float eps_div, float eps_log) {
     __shared__ float red[32];
     const int row = blockIdx.y;
+    float* p = x + (size_t)row * row_len;
+    const size_t beg = (size_t)blockIdx.x * kApply, end = min(beg + (size_t)kApply, row_len);
+    const bool vec = ((row_len & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);  // uniform
+    const size_t iv = beg + 4 * (size_t)threadIdx.x;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec && iv < end) v = *reinterpret_cast<const float4*>(p + iv);
+
     float mn = 0.f, den = 1.f;
     if (do_minmax) {
         float lo = INFINITY, hi = -INFINITY;
         if (n_part <= 256) {  // few partials: every wave folds them itself (no barrier)
             const float2* pr = reinterpret_cast<const float2*>(partial) + (size_t)row * n_part;
             for (int i = threadIdx.x & 63; i < n_part; i += 64) {
-                const float2 v = pr[i];
-                lo = fminf(lo, v.x);
-                hi = fmaxf(hi, v.y);
+                const float2 q = pr[i];
+                lo = fminf(lo, q.x);
+                hi = fmaxf(hi, q.y);
             }
             lo = wave_min(lo);
             hi = wave_max(hi);
@@ -1021,12 +1034,8 @@ __global__ __launch_bounds__(256) void k_minmax_log_apply(float* x, const float*
         mn = lo;
         den = fmaxf(hi - lo, eps_div);
     }
-    float* p = x + (size_t)row * row_len;
-    const size_t beg = (size_t)blockIdx.x * kChunk, end = min(beg + (size_t)kChunk, row_len);
-    const bool vec = ((row_len & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     if (vec) {
-        for (size_t i = beg + 4 * (size_t)threadIdx.x; i < end; i += 4 * (size_t)blockDim.x) {
-            float4 v = *reinterpret_cast<float4*>(p + i);
+        if (iv < end) {
             float* e = reinterpret_cast<float*>(&v);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1035,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_minmax_log_apply(float* x, const float*
                 if (do_log) y = logf(y + eps_log);
                 e[j] = y;
             }
-            *reinterpret_cast<float4*>(p + i) = v;
+            *reinterpret_cast<float4*>(p + iv) = v;
         }
     } else {
         for (size_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
@@ -1862,7 +1871,7 @@ extern "C" int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minm
                         iris_minmax_log_workspace(n_rows, row_len));
         k_minmax_partial<<<dim3((unsigned)n_part, n_rows), 256, 0, s>>>(x, workspace, row_len, (int)n_part);
     }
-    k_minmax_log_apply<<<dim3((unsigned)n_part, n_rows), 256, 0, s>>>(x, workspace, (int)n_part, row_len, do_minmax,
+    k_minmax_log_apply<<<dim3((unsigned)((row_len + kApply - 1) / kApply), n_rows), 256, 0, s>>>(x, workspace, (int)n_part, row_len, do_minmax,
                                                                      do_log, eps_div, eps_log);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
@@ -1986,7 +1995,7 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     HIP_TRY(e);
     if (do_minmax || do_log) {
         const size_t row_len = (size_t)p->n_mel * a.T * p->channels;
-        const unsigned n_chunks = (unsigned)((row_len + kChunk - 1) / kChunk);
+        const unsigned n_chunks = (unsigned)((row_len + kApply - 1) / kApply);
         k_minmax_log_apply<<<dim3(n_chunks, batch), 256, 0, s>>>(out, p->d_ws, a.chunks_per_clip * parts_per_chunk, row_len, do_minmax,
                                                                do_log, 1e-8f, 1e-8f);
         HIP_TRY(hipGetLastError());
