@@ -660,15 +660,14 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                     const float keep = masked[st] ? 0.f : scale;
                     if constexpr (MELMODE == 0) {
                         const float4* mag4 = reinterpret_cast<const float4*>(magbuf[st] + lo0);  // lo0 % 4 == 0
-                        float acc = 0.f;
+                        cf acc2 = mk(0.f, 0.f);  // even / odd bins of the window, packed FMAs
 #pragma unroll
                         for (int i = 0; i < kMelRegs / 4; ++i) {
                             const float4 m4 = mag4[i];
-                            acc = fmaf(wreg[4 * i + 0], m4.x, acc);
-                            acc = fmaf(wreg[4 * i + 1], m4.y, acc);
-                            acc = fmaf(wreg[4 * i + 2], m4.z, acc);
-                            acc = fmaf(wreg[4 * i + 3], m4.w, acc);
+                            acc2 = __builtin_elementwise_fma(mk(wreg[4 * i + 0], wreg[4 * i + 1]), mk(m4.x, m4.y), acc2);
+                            acc2 = __builtin_elementwise_fma(mk(wreg[4 * i + 2], wreg[4 * i + 3]), mk(m4.z, m4.w), acc2);
                         }
+                        const float acc = acc2.x + acc2.y;
                         if (live[st] && lane < a.M) {
                             const float v = acc * keep;
                             store_band(fcur[st], __umul24((unsigned)lane, rowpitch_b), v);  // host checks rowpitch < 2^24
