@@ -24,6 +24,10 @@ using namespace iris;
 #define IRIS_DIAG 0
 #endif
 #define ABL(bit) (IRIS_DIAG && (a.ablate & (bit)))
+// 1: frames go global -> registers (prefetched during the mel phase); 0: through LDS-DMA landing buffers
+#ifndef IRIS_DIRECT_LOAD
+#define IRIS_DIRECT_LOAD 1
+#endif
 // diagnostic buffer: [4] header, [3 * 4096] per-workgroup stamps, [4096 * 16 * 16] per-wave phase cycles
 static constexpr int kDbgPhase0 = 4 + 3 * 4096, kDbgWords = kDbgPhase0 + 4096 * 16 * 16;
 #if IRIS_DIAG
@@ -198,10 +202,14 @@ __device__ __forceinline__ void load_frame(cf (&x)[FftCfg<LOG2N>::P], const floa
 #pragma unroll
         for (int q = 0; q < P; ++q) x[q] = p[lane + kWave * q];
     } else {
+        // rare (clip edges, odd alignment): per-lane reflected indices as 32-bit byte offsets
+        // from the uniform clip base, so no 64-bit address lives in VGPRs
+        const char* base = reinterpret_cast<const char*>(clip);
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             const int n = start + 2 * (lane + kWave * q);
-            x[q] = mk(clip[reflect_idx(n, len)], clip[reflect_idx(n + 1, len)]);
+            const unsigned o0 = (unsigned)reflect_idx(n, len) * 4u, o1 = (unsigned)reflect_idx(n + 1, len) * 4u;
+            x[q] = mk(*reinterpret_cast<const float*>(base + o0), *reinterpret_cast<const float*>(base + o1));
         }
     }
 }
@@ -261,6 +269,46 @@ __device__ __forceinline__ void untangle(const cf (&x)[FftCfg<LOG2N>::P], const 
 }
 
 __device__ __forceinline__ float cabs_rn(cf v) { return __builtin_amdgcn_sqrtf(fmaf(v.x, v.x, v.y * v.y)); }
+
+// Untangle fused with the magnitude: x[q] = Z[lane + 64 q] -> mag[k] = 2 |X[k]| for k <= NC/2
+// (HI: for every k <= NC), written to the wave's magnitude buffer (which aliases the low part of
+// its exchange buffer: the partner rows P/2.. live above byte 8 * lds_pad(NC/2) > 4 * (NC + 1),
+// so magnitudes can land while partner reads are still queued - a wave's DS ops run in order).
+// No complex outputs are kept: each bin's registers die as soon as its magnitude is stored.
+template <int LOG2N, bool HI, int S>
+__device__ __forceinline__ void untangle_mag(const cf (&x)[S][FftCfg<LOG2N>::P], const cf* post, cf* const (&lds)[S],
+                                             float* const (&mag)[S], int lane) {
+    constexpr int P = FftCfg<LOG2N>::P, NC = (1 << LOG2N) / 2;
+    static_assert(8 * lds_pad<1>(NC / 2) >= 4 * (NC + 1), "magnitudes would overwrite partner rows");
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        cf* wp = lds[s] + lds_pad<1>(lane);
+#pragma unroll
+        for (int q = P / 2; q < P; ++q) wp[lds_pad<1>(kWave * q)] = x[s][q];
+    }
+    wave_sync_lds();
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const cf* rp = lds[s] + lds_pad<1>(kWave - lane);
+        cf zp[P / 2];
+#pragma unroll
+        for (int q = 0; q < P / 2; ++q) zp[q] = rp[lds_pad<1>(kWave * (P - 1 - q))];
+        if (lane == 0) zp[0] = x[s][0];  // k = 0 pairs with itself
+        if constexpr (HI) {
+            if (lane == 0) mag[s][NC / 2] = 2.0f * cabs_rn(x[s][P / 2]);  // X[NC/2] = conj(Z[NC/2])
+        }
+#pragma unroll
+        for (int q = 0; q < P / 2; ++q) {
+            const cf zk = x[s][q];
+            const cf zc = mk(zp[q].x, -zp[q].y);  // conj(Z[NC-k])
+            const cf e = zk + zc;                 // 2 E
+            const cf d = zk - zc;                 // 2 i O
+            const cf wo = cmul(mk(d.y, -d.x), post[q]);
+            mag[s][lane + kWave * q] = cabs_rn(e + wo);
+            if constexpr (HI) mag[s][NC - lane - kWave * q] = cabs_rn(e - wo);
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------
 // per-lane constant block: every lane's twiddles / untangle twiddles / window /
@@ -486,14 +534,20 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
     auto chunk_nt = [&](int chunk, int b) {
         return a.chunk_base + ((chunk - b * a.chunks_per_clip) < a.chunk_rem ? 1 : 0);
     };
-    // LDS-DMA of wave-frames ff[] (f = tl * C + c) of a chunk into this wave's landing buffers
+    constexpr bool DIRECT = IRIS_DIRECT_LOAD && LOG2N <= 10;  // n_fft 2048 (16 points per lane) has no registers to spare
+    cf x[S][P];
+    // Fetch of wave-frames ff[] (f = tl * C + c) of a chunk: straight into the x registers
+    // (IRIS_DIRECT_LOAD), or by LDS-DMA into this wave's landing buffers
     auto issue_dma = [&](const int (&ff)[S], int b, int t0, int nwf) {
         const float* clip0 = a.wav + (size_t)b * a.C * a.L;
 #pragma unroll
         for (int st = 0; st < S; ++st)
             if (ff[st] < nwf && !ABL(8)) {
                 const int tl = (a.C == 1) ? ff[st] : ff[st] / a.C, c = ff[st] - tl * a.C;
-                dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
+                if constexpr (DIRECT)
+                    load_frame<LOG2N>(x[st], clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, lane);
+                else
+                    dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
             }
     };
     int f[S], fn[S];  // frames in registers / frames in flight to the landing buffers
@@ -573,7 +627,6 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
         };
         float mn = INFINITY, mx = -INFINITY;
 
-        cf x[S][P];
         auto read_frames = [&]() {  // landing buffers -> registers (asynchronous: lgkmcnt)
 #pragma unroll
             for (int st = 0; st < S; ++st) {
@@ -582,10 +635,12 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                 for (int q = 0; q < P; ++q) x[st][q] = fb2[kWave * q];
             }
         };
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        read_frames();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        issue_dma(fn, b, t0, nwf);
+        if constexpr (!DIRECT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_frames();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_dma(fn, b, t0, nwf);
+        }
         PH_MARK(8);
         while (f[0] < nwf) {
             PH_BEGIN();
@@ -610,6 +665,8 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
 #pragma unroll
                 for (int st = 0; st < S; ++st) all_masked = all_masked && (masked[st] || !live[st]);
             }
+            if constexpr (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the frames (and older stores)
+            PH_MARK(0);
             if (!all_masked) {  // wave-uniform; a fully masked round has nothing to transform
 #pragma unroll
                 for (int st = 0; st < S; ++st)
@@ -617,30 +674,22 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                     for (int q = 0; q < P; ++q) x[st][q] *= win[q];
                 if (!ABL(1)) fft_frames<LOG2N, S>(x, tw, lds, lane);
                 PH_MARK(3);
-                cf xlo[S][P / 2], xhi[S][P / 2];
                 // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)
-                untangle_multi<LOG2N, HI, false, S>(x, post, lds, lane, xlo, xhi);
-#pragma unroll
-                for (int st = 0; st < S; ++st) {
-#pragma unroll
-                    for (int q = 0; q < P / 2; ++q) magbuf[st][lane + kWave * q] = cabs_rn(xlo[st][q]);
-                    if constexpr (HI) {
-                        float* mhi = magbuf[st] + NC - lane;
-#pragma unroll
-                        for (int q = 0; q < P / 2; ++q) mhi[-kWave * q] = cabs_rn(xhi[st][q]);
-                        if (lane == 0) magbuf[st][NC / 2] = 2.0f * cabs_rn(x[st][P / 2]);
-                    }
-                }
+                untangle_mag<LOG2N, HI, S>(x, post, lds, magbuf, lane);
                 wave_sync_lds();
                 PH_MARK(4);
             }
-            // prefetch: the next frames have landed (their DMA was issued a whole FFT ago); start
-            // pulling them into the now dead x registers and claim the frames after them
+            // prefetch into the now dead x registers - straight from global, or from the landing
+            // buffers (their DMA was issued a whole FFT ago) - and claim the frames after these
             const bool more = fn[0] < nwf;  // wave-uniform
             int claimed = 0;
             if (more) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                read_frames();
+                if constexpr (DIRECT) {
+                    issue_dma(fn, b, t0, nwf);
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    read_frames();
+                }
                 if (lane == 0) claimed = atomicAdd(next_frame, S);
             }
             if (!all_masked) {
@@ -715,7 +764,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                 claimed = __builtin_amdgcn_readfirstlane(claimed);
 #pragma unroll
                 for (int st = 0; st < S; ++st) fn[st] = claimed + st;
-                issue_dma(fn, b, t0, nwf);
+                if constexpr (!DIRECT) issue_dma(fn, b, t0, nwf);
             }
             PH_MARK(2);
             if ABL(4096) ph[7] += 1;
@@ -1351,7 +1400,10 @@ static fused_kernel_t fused_kernel_hb(bool hi, bool bands) {
 }
 template <int LOG2N, int S>
 static fused_kernel_t fused_kernel_mm(int mel_mode, bool hi, bool bands) {
-    if (mel_mode == 0) return fused_kernel_hb<LOG2N, 0, S>(hi, bands);
+    if constexpr (LOG2N <= 10) {
+        if (mel_mode == 0)  // register weights exist only for the half-spectrum variant up to n_fft 1024
+            return bands ? k_wav_to_mel<LOG2N, 0, false, true, S> : k_wav_to_mel<LOG2N, 0, false, false, S>;
+    }
     if (mel_mode == 1) return fused_kernel_hb<LOG2N, 1, S>(hi, bands);
     return fused_kernel_hb<LOG2N, 2, S>(hi, bands);
 }
@@ -1512,7 +1564,8 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     // bins the kernel writes to its magnitude buffer: [0, limit)
     const int limit = p->need_hi ? ((n_bins + 3) & ~3) : NC / 2;
     // (n_fft 2048 keeps 16 points per lane: no registers to spare for the weights -> table modes)
-    if (log2n <= 10 && n_mel <= 64 && p->max_band_len + 3 <= kMelRegs && limit >= kMelRegs) {
+    // (the full-spectrum untangle needs the registers too: need_hi -> table modes)
+    if (log2n <= 10 && !p->need_hi && n_mel <= 64 && p->max_band_len + 3 <= kMelRegs && limit >= kMelRegs) {
         p->mel_mode = 0;  // 16-byte aligned register window of kMelRegs bins per band
         p->rows = kMelRegs;
     } else {
