@@ -297,15 +297,29 @@ __device__ __forceinline__ void untangle_mag(const cf (&x)[S][FftCfg<LOG2N>::P],
         if constexpr (HI) {
             if (lane == 0) mag[s][NC / 2] = 2.0f * cabs_rn(x[s][P / 2]);  // X[NC/2] = conj(Z[NC/2])
         }
+        // Two bins at a time, then their stores: independent chains interleave (a packed op
+        // that consumes the previous packed result costs a wait state on this chip) without
+        // keeping the whole spectrum live.
 #pragma unroll
-        for (int q = 0; q < P / 2; ++q) {
-            const cf zk = x[s][q];
-            const cf zc = mk(zp[q].x, -zp[q].y);  // conj(Z[NC-k])
-            const cf e = zk + zc;                 // 2 E
-            const cf d = zk - zc;                 // 2 i O
-            const cf wo = cmul(mk(d.y, -d.x), post[q]);
-            mag[s][lane + kWave * q] = cabs_rn(e + wo);
-            if constexpr (HI) mag[s][NC - lane - kWave * q] = cabs_rn(e - wo);
+        for (int q0 = 0; q0 < P / 2; q0 += 2) {
+            cf lo[2], hi[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = q0 + j;
+                const cf zk = x[s][q];
+                const cf zc = mk(zp[q].x, -zp[q].y);  // conj(Z[NC-k])
+                const cf e = zk + zc;                 // 2 E
+                const cf d = zk - zc;                 // 2 i O
+                const cf wo = cmul(mk(d.y, -d.x), post[q]);
+                lo[j] = e + wo;
+                if constexpr (HI) hi[j] = e - wo;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = q0 + j;
+                mag[s][lane + kWave * q] = cabs_rn(lo[j]);
+                if constexpr (HI) mag[s][NC - lane - kWave * q] = cabs_rn(hi[j]);
+            }
         }
     }
 }
@@ -709,13 +723,16 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                     const float keep = masked[st] ? 0.f : scale;
                     if constexpr (MELMODE == 0) {
                         const float4* mag4 = reinterpret_cast<const float4*>(magbuf[st] + lo0);  // lo0 % 4 == 0
-                        cf acc2 = mk(0.f, 0.f);  // even / odd bins of the window, packed FMAs
+                        // packed FMAs on two independent accumulators (a dependent packed op
+                        // costs a wait state)
+                        cf acc2 = mk(0.f, 0.f), acc3 = mk(0.f, 0.f);
 #pragma unroll
                         for (int i = 0; i < kMelRegs / 4; ++i) {
                             const float4 m4 = mag4[i];
                             acc2 = __builtin_elementwise_fma(mk(wreg[4 * i + 0], wreg[4 * i + 1]), mk(m4.x, m4.y), acc2);
-                            acc2 = __builtin_elementwise_fma(mk(wreg[4 * i + 2], wreg[4 * i + 3]), mk(m4.z, m4.w), acc2);
+                            acc3 = __builtin_elementwise_fma(mk(wreg[4 * i + 2], wreg[4 * i + 3]), mk(m4.z, m4.w), acc3);
                         }
+                        acc2 += acc3;
                         const float acc = acc2.x + acc2.y;
                         if (live[st] && lane < a.M) {
                             const float v = acc * keep;
