@@ -88,7 +88,8 @@ struct iris_plan {
     int num_cu;
     int chunk_target;  // 0 = auto; frames per chunk of the fused kernel (IRIS_CHUNK_FRAMES)
     // timing
-    bool timing;
+    int timing;        // 0 off, n: every n-th launch carries an event pair
+    long launch_no;    // launches since timing was enabled
     std::vector<hipEvent_t> ev;  // pairs
     int ev_used;
 };
@@ -1514,7 +1515,8 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->d_dbg = nullptr;
     p->streams = 1;
     if (const char* e = getenv("IRIS_STREAMS")) p->streams = atoi(e) == 2 ? 2 : 1;
-    p->timing = false;
+    p->timing = 0;
+    p->launch_no = 0;
     p->ev_used = 0;
 
     p->mel.resize((size_t)n_bins * n_mel);
@@ -2044,7 +2046,7 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
 
     // bench hook: the kernel's own start/stop timestamps are attached to an event pair by the
     // AMD launch extension (no extra packets on the stream, unlike hipEventRecord brackets)
-    const bool timed = p->timing && p->ev_used < kMaxTimedLaunches;
+    const bool timed = p->timing > 0 && (p->launch_no++ % p->timing) == 0 && p->ev_used < kMaxTimedLaunches;
     hipError_t e;
     if (timed) {
         while ((int)p->ev.size() < 2 * (p->ev_used + 1)) {
@@ -2104,7 +2106,8 @@ extern "C" int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float 
 
 extern "C" int iris_timing_enable(iris_plan* p, int enable) {
     if (!p) return fail(IRIS_E_INVALID, "iris_timing_enable: NULL plan");
-    p->timing = enable != 0;
+    p->timing = enable > 0 ? enable : 0;
+    p->launch_no = 0;
     p->ev_used = 0;
     return IRIS_OK;
 }

@@ -205,8 +205,9 @@ class FrontendPlan:
         return out
 
     # ---- bench hooks ---------------------------------------------------------
-    def timing_enable(self, enable: bool = True) -> None:
-        N.check(N.lib().iris_timing_enable(self._handle, 1 if enable else 0), "iris_timing_enable")
+    def timing_enable(self, enable=True) -> None:
+        """True / 1: every launch of the main kernel carries an event pair; n > 1: every n-th; False / 0: off."""
+        N.check(N.lib().iris_timing_enable(self._handle, int(enable)), "iris_timing_enable")
 
     def timing_read(self) -> Tuple[int, float]:
         n, ms = C.c_int(0), C.c_float(0)

@@ -195,10 +195,13 @@ int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float clip_factor
                   float clipvalue, void* stream);
 
 /*
- * Per-kernel timing for bench.py: when enabled, the dominant kernel of
- * iris_wav_to_logmel is bracketed by hipEvents on the launch stream.
- * iris_timing_read synchronises those events and returns the number of
- * launches recorded since the last reset and their mean duration in ms.
+ * Per-kernel timing for bench.py: with enable = n > 0 every n-th launch of the
+ * dominant kernel of iris_wav_to_logmel carries a start/stop hipEvent pair on
+ * the launch stream (n = 1: every launch; an event pair costs a few
+ * microseconds of stream time, so sampling keeps the step rate honest);
+ * 0 switches it off.  iris_timing_read synchronises those events and returns
+ * the number of launches recorded since the last reset and their mean
+ * duration in ms.
  */
 int iris_timing_enable(iris_plan* plan, int enable);
 int iris_timing_read(iris_plan* plan, int* n_launches, float* mean_ms);
