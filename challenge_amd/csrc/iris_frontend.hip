@@ -1958,7 +1958,7 @@ static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int
     int cpc = (T + target - 1) / target;
     // rounding up per clip can overshoot the slots by a few chunks, which would cost a whole
     // second round: prefer slightly larger chunks that fit one round
-    if ((long)batch * cpc > slots && batch <= slots) cpc = std::max(1, slots / batch);
+    if (p->chunk_target == 0 && (long)batch * cpc > slots && batch <= slots) cpc = std::max(1, slots / batch);
     *chunks_per_clip = cpc;
     *chunk_frames = (T + cpc - 1) / cpc;
 }

@@ -343,3 +343,25 @@ def test_two_plans_interleaved(dev):
         oa, ob = pa.wav_to_logmel(a), pb.wav_to_logmel(b)
         oa2 = pa.wav_to_logmel(a)
         assert torch.equal(oa, ra) and torch.equal(ob, rb) and torch.equal(oa2, ra)
+
+
+def test_workgroups_looping_over_several_chunks(dev, monkeypatch):
+    """More chunks than workgroups (forced with small chunks): every workgroup restarts its frame
+    queue between chunks; results equal the one-chunk-per-workgroup geometry and the oracle,
+    with and without time bands, including the per-clip min-max built from per-wave partials."""
+    rng = np.random.default_rng(77)
+    b, length = 40, 25600
+    wav = (rng.standard_normal((b, 1, length)) * 0.1).astype(np.float32)
+    n_t = 1 + length // 256
+    tb = np.stack([np.stack(R.mask_draw(rng, n_t, 12, 3), 1) for _ in range(b)])
+    ref_plan = FE().FrontendPlan(1024, 256, 64, 16000, 1, b, length, dev)
+    monkeypatch.setenv("IRIS_CHUNK_FRAMES", "8")
+    small = FE().FrontendPlan(1024, 256, 64, 16000, 1, b, length, dev)
+    monkeypatch.delenv("IRIS_CHUNK_FRAMES")
+    x = torch.from_numpy(wav).to(dev)
+    for kw in ({}, {"t_bands": tb}):
+        raw = small.wav_to_logmel(x, minmax=False, log=False, **kw)
+        assert torch.equal(raw, ref_plan.wav_to_logmel(x, minmax=False, log=False, **kw))
+        assert rel_err(raw.cpu().numpy(), R.wav_to_mel(wav, 1024, 256, 64, 16000, **kw)) <= 1e-5
+        full = small.wav_to_logmel(x, **kw)
+        assert torch.equal(full, ref_plan.wav_to_logmel(x, **kw))
