@@ -365,6 +365,17 @@ __device__ __forceinline__ void load_consts(const float* consts, int lane, cf (&
     lo0 = __float_as_int(cv[CL::OFF_LO]);
 }
 
+// the register mel weights of this lane, straight from the global constant block
+template <int LOG2N>
+__device__ __forceinline__ void reload_wreg(const float* consts, int lane, float (&wreg)[kMelRegs]) {
+    using CL = ConstLayout<LOG2N>;
+#pragma unroll
+    for (int i = 0; i < kMelRegs; ++i) {
+        const int fi = CL::OFF_WREG + i;
+        wreg[i] = consts[((fi / 4) * kWave + lane) * 4 + (fi % 4)];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K1: fused wav -> mel magnitudes (+ per-wave min/max partials)
 //   work unit = chunk: consecutive frames of one clip, all C channels
@@ -500,7 +511,6 @@ template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S>
 __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) / 4) void k_wav_to_mel(const FusedArgs a) {
     constexpr int kFusedWaves = fused_waves(LOG2N, S);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
-    constexpr int F = NC + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the wave index is uniform: keep it (and everything derived from it) in SGPRs
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -527,6 +537,30 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
     int* next_frame = reinterpret_cast<int*>(xbuf0 + (kXAllBytes > kStageBytes ? kXAllBytes : kStageBytes));  // [4]
     float* wtab = reinterpret_cast<float*>(next_frame + 4);  // MELMODE 1: [rows][M] then int lo[M]
     int* lotab = reinterpret_cast<int*>(wtab + a.rows * a.M);
+    // BANDS: bit tl of this bitmap = frame t0 + tl of the current chunk lies in a time band
+    unsigned* tbits = reinterpret_cast<unsigned*>(MELMODE == 1 ? reinterpret_cast<float*>(lotab + a.M) : wtab);
+    // MELMODE 1: the chunk's band table, with the clip's frequency bands folded in (all threads)
+    auto build_wtab = [&](const int* fbc) {
+        for (int i = threadIdx.x; i < a.M; i += blockDim.x) lotab[i] = a.band_lo[i];
+        for (int i = threadIdx.x; i < a.rows * a.M; i += blockDim.x) {
+            float w = a.wband[i];
+            if (BANDS && fbc) {
+                const int r = i / a.M, m = i - r * a.M;
+                if (in_bands(fbc, a.n_fb, a.band_lo[m] + r)) w = 0.f;
+            }
+            wtab[i] = w;
+        }
+    };
+    auto build_tbits = [&](const int* tb, int t0, int nt) {  // all threads; publish with a barrier
+        for (int base = 0; base < nt; base += blockDim.x) {
+            const int i = base + threadIdx.x;
+            const unsigned long long m = __ballot(i < nt && in_bands(tb, a.n_tb, t0 + i));
+            if (lane == 0) {
+                tbits[(base >> 5) + 2 * wv] = (unsigned)m;
+                tbits[(base >> 5) + 2 * wv + 1] = (unsigned)(m >> 32);
+            }
+        }
+    };
 
     unsigned long long real_entry = 0;
     if ABL(512) real_entry = __builtin_amdgcn_s_memrealtime();
@@ -579,11 +613,20 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
         const float4* g = reinterpret_cast<const float4*>(a.consts);
         for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
         if (threadIdx.x == 0) *next_frame = 2 * kFusedWaves * S;
+        if constexpr (BANDS) {
+            if (a.t_bands && g0 < a.n_chunks) {
+                const int b = chunk_clip(g0);
+                build_tbits(a.t_bands + (size_t)b * a.n_tb * 2, chunk_t0(g0, b), chunk_nt(g0, b));
+            }
+        }
         __syncthreads();
         load_consts<LOG2N>(reinterpret_cast<const float*>(stage), lane, tw, post, win, wreg, lo0);
         if constexpr (MELMODE == 1) {
-            for (int i = threadIdx.x; i < a.rows * a.M; i += blockDim.x) wtab[i] = a.wband[i];
-            for (int i = threadIdx.x; i < a.M; i += blockDim.x) lotab[i] = a.band_lo[i];
+            const int* fbc = nullptr;
+            if constexpr (BANDS) {
+                if (a.f_bands && g0 < a.n_chunks) fbc = a.f_bands + (size_t)chunk_clip(g0) * a.n_fb * 2;
+            }
+            build_wtab(fbc);
         }
         __syncthreads();
         if ABL(512) {
@@ -617,6 +660,32 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
             fn[st] = (kFusedWaves + wv) * S + st;  // second round is static too: the queue starts at 2 * waves * S
         }
         if (chunk != g0) issue_dma(f, b, t0, nwf);
+        bool mbit[S];             // the frames in f[] lie in a time band (wave-uniform)
+#pragma unroll
+        for (int st = 0; st < S; ++st) mbit[st] = false;
+        if constexpr (BANDS) {
+            // Frequency bands zero |X| over bin ranges, i.e. they remove those bins from every mel
+            // band: fold them into this chunk's band weights once (register weights here, the
+            // LDS table where the chunk starts) instead of touching the magnitudes of every frame.
+            if constexpr (MELMODE == 0) {
+                if (fb) {
+                    if (chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);  // pristine weights (not hoisted)
+                    for (int i = 0; i < a.n_fb; ++i) {  // band bounds are wave-uniform (scalar loads)
+                        const int off = fb[2 * i] - lo0, end = off + fb[2 * i + 1];
+#pragma unroll
+                        for (int r = 0; r < kMelRegs; ++r)
+                            if (r >= off && r < end) wreg[r] = 0.f;
+                    }
+                }
+            }
+            if (tb) {
+#pragma unroll
+                for (int st = 0; st < S; ++st) {
+                    const int tl = min((a.C == 1) ? f[st] : f[st] / a.C, nt - 1);
+                    mbit[st] = (__builtin_amdgcn_readfirstlane(tbits[tl >> 5]) >> (tl & 31)) & 1u;
+                }
+            }
+        }
 
         float scale = 1.0f;  // normalize: |X| is linear in the waveform, so 1 / (10 rms) scales the mel
         if (a.sumsq != nullptr) {
@@ -666,124 +735,141 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                 fcur[st] = f[st];
                 live[st] = f[st] < nwf;
             }
+            const bool more = fn[0] < nwf;  // wave-uniform
+            int claimed = 0;
+            unsigned mword[S];  // bitmap words of the next frames (LDS reads in flight with the rest)
+            // Prefetch into the (by then dead) x registers - straight from global, or from the
+            // landing buffers (their DMA was issued a whole FFT ago) -, claim the frames after
+            // these and fetch the time-band flags of the next ones.
+            auto prefetch = [&]() {
+                if (more) {
+                    if constexpr (DIRECT) {
+                        issue_dma(fn, b, t0, nwf);
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        read_frames();
+                    }
+                    if (lane == 0) claimed = atomicAdd(next_frame, S);
+                }
+#pragma unroll
+                for (int st = 0; st < S; ++st) mword[st] = 0;
+                if constexpr (BANDS) {
+                    if (tb && more) {
+#pragma unroll
+                        for (int st = 0; st < S; ++st)
+                            mword[st] = tbits[min((a.C == 1) ? fn[st] : fn[st] / a.C, nt - 1) >> 5];
+                    }
+                }
+            };
+            // The frame reads, the claim and the flags have returned: rotate the frame cursors.
+            auto advance = [&]() {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int st = 0; st < S; ++st) {
+                    if constexpr (BANDS) {
+                        const int tl = min((a.C == 1) ? fn[st] : fn[st] / a.C, nt - 1);
+                        mbit[st] = (__builtin_amdgcn_readfirstlane(mword[st]) >> (tl & 31)) & 1u;
+                    }
+                    f[st] = fn[st];
+                }
+                if (more) {
+                    claimed = __builtin_amdgcn_readfirstlane(claimed);
+#pragma unroll
+                    for (int st = 0; st < S; ++st) fn[st] = claimed + st;
+                    if constexpr (!DIRECT) issue_dma(fn, b, t0, nwf);
+                }
+            };
             bool masked[S];
 #pragma unroll
             for (int st = 0; st < S; ++st) masked[st] = false;
-            bool all_masked = false;
             if constexpr (BANDS) {
-                if (tb) {
+                bool all_masked = true;
+#pragma unroll
+                for (int st = 0; st < S; ++st) {
+                    masked[st] = live[st] && mbit[st];
+                    all_masked = all_masked && (masked[st] || !live[st]);
+                }
+                if (all_masked) {  // wave-uniform: nothing to transform, the frames are all-zero columns
+                    prefetch();
 #pragma unroll
                     for (int st = 0; st < S; ++st)
-                        masked[st] = live[st] && in_bands(tb, a.n_tb, t0 + ((a.C == 1) ? fcur[st] : fcur[st] / a.C));
+                        if (live[st])
+                            for (int m = lane; m < a.M; m += kWave) store_band(fcur[st], (unsigned)m * rowpitch_b, 0.f);
+                    mn = fminf(mn, 0.f);
+                    mx = fmaxf(mx, 0.f);
+                    advance();
+                    continue;
                 }
-                all_masked = true;
-#pragma unroll
-                for (int st = 0; st < S; ++st) all_masked = all_masked && (masked[st] || !live[st]);
             }
             if constexpr (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the frames (and older stores)
             PH_MARK(0);
-            if (!all_masked) {  // wave-uniform; a fully masked round has nothing to transform
 #pragma unroll
-                for (int st = 0; st < S; ++st)
+            for (int st = 0; st < S; ++st)
 #pragma unroll
-                    for (int q = 0; q < P; ++q) x[st][q] *= win[q];
-                if (!ABL(1)) fft_frames<LOG2N, S>(x, tw, lds, lane);
-                PH_MARK(3);
-                // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)
-                untangle_mag<LOG2N, HI, S>(x, post, lds, magbuf, lane);
-                wave_sync_lds();
-                PH_MARK(4);
-            }
-            // prefetch into the now dead x registers - straight from global, or from the landing
-            // buffers (their DMA was issued a whole FFT ago) - and claim the frames after these
-            const bool more = fn[0] < nwf;  // wave-uniform
-            int claimed = 0;
-            if (more) {
-                if constexpr (DIRECT) {
-                    issue_dma(fn, b, t0, nwf);
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    read_frames();
-                }
-                if (lane == 0) claimed = atomicAdd(next_frame, S);
-            }
-            if (!all_masked) {
-                if constexpr (BANDS) {
-                    if (fb) {
+                for (int q = 0; q < P; ++q) x[st][q] *= win[q];
+            if (!ABL(1)) fft_frames<LOG2N, S>(x, tw, lds, lane);
+            PH_MARK(3);
+            // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)
+            untangle_mag<LOG2N, HI, S>(x, post, lds, magbuf, lane);
+            wave_sync_lds();
+            PH_MARK(4);
+            prefetch();
+            if constexpr (BANDS && MELMODE == 2) {  // the global table is shared: zero the magnitudes instead
+                if (fb) {
 #pragma unroll
-                        for (int st = 0; st < S; ++st)
-                            for (int i = 0; i < a.n_fb; ++i) {
-                                const int off = fb[2 * i], end = min(off + fb[2 * i + 1], F);
-                                for (int k = off + lane; k < end; k += kWave) magbuf[st][k] = 0.f;
-                            }
-                        wave_sync_lds();
-                    }
-                }
-#pragma unroll
-                for (int st = 0; st < S; ++st) {
-                    const float keep = masked[st] ? 0.f : scale;
-                    if constexpr (MELMODE == 0) {
-                        const float4* mag4 = reinterpret_cast<const float4*>(magbuf[st] + lo0);  // lo0 % 4 == 0
-                        // packed FMAs on two independent accumulators (a dependent packed op
-                        // costs a wait state)
-                        cf acc2 = mk(0.f, 0.f), acc3 = mk(0.f, 0.f);
-#pragma unroll
-                        for (int i = 0; i < kMelRegs / 4; ++i) {
-                            const float4 m4 = mag4[i];
-                            acc2 = __builtin_elementwise_fma(mk(wreg[4 * i + 0], wreg[4 * i + 1]), mk(m4.x, m4.y), acc2);
-                            acc3 = __builtin_elementwise_fma(mk(wreg[4 * i + 2], wreg[4 * i + 3]), mk(m4.z, m4.w), acc3);
+                    for (int st = 0; st < S; ++st)
+                        for (int i = 0; i < a.n_fb; ++i) {
+                            const int off = fb[2 * i], end = min(off + fb[2 * i + 1], NC + 1);
+                            for (int k = off + lane; k < end; k += kWave) magbuf[st][k] = 0.f;
                         }
-                        acc2 += acc3;
-                        const float acc = acc2.x + acc2.y;
-                        if (live[st] && lane < a.M) {
+                    wave_sync_lds();
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < S; ++st) {
+                const float keep = masked[st] ? 0.f : scale;
+                if constexpr (MELMODE == 0) {
+                    const float4* mag4 = reinterpret_cast<const float4*>(magbuf[st] + lo0);  // lo0 % 4 == 0
+                    // packed FMAs on two independent accumulators (a dependent packed op costs
+                    // a wait state)
+                    cf acc2 = mk(0.f, 0.f), acc3 = mk(0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < kMelRegs / 4; ++i) {
+                        const float4 m4 = mag4[i];
+                        acc2 = __builtin_elementwise_fma(mk(wreg[4 * i + 0], wreg[4 * i + 1]), mk(m4.x, m4.y), acc2);
+                        acc3 = __builtin_elementwise_fma(mk(wreg[4 * i + 2], wreg[4 * i + 3]), mk(m4.z, m4.w), acc3);
+                    }
+                    acc2 += acc3;
+                    const float acc = acc2.x + acc2.y;
+                    if (live[st] && lane < a.M) {
+                        const float v = acc * keep;
+                        store_band(fcur[st], __umul24((unsigned)lane, rowpitch_b), v);  // host checks rowpitch < 2^24
+                        mn = fminf(mn, v);
+                        mx = fmaxf(mx, v);
+                    }
+                } else {
+                    if (live[st]) {
+                        for (int m = lane; m < a.M; m += kWave) {
+                            float acc = 0.f;
+                            if constexpr (MELMODE == 1) {
+                                const int lo = lotab[m];
+                                for (int i = 0; i < a.rows; ++i) acc = fmaf(wtab[i * a.M + m], magbuf[st][lo + i], acc);
+                            } else {
+                                const int lo = a.band_lo[m];
+                                for (int i = 0; i < a.rows; ++i)
+                                    acc = fmaf(a.wband[i * a.M + m], magbuf[st][lo + i], acc);
+                            }
                             const float v = acc * keep;
-                            store_band(fcur[st], __umul24((unsigned)lane, rowpitch_b), v);  // host checks rowpitch < 2^24
+                            store_band(fcur[st], (unsigned)m * rowpitch_b, v);
                             mn = fminf(mn, v);
                             mx = fmaxf(mx, v);
                         }
-                    } else {
-                        if (live[st]) {
-                            for (int m = lane; m < a.M; m += kWave) {
-                                float acc = 0.f;
-                                if constexpr (MELMODE == 1) {
-                                    const int lo = lotab[m];
-                                    for (int i = 0; i < a.rows; ++i)
-                                        acc = fmaf(wtab[i * a.M + m], magbuf[st][lo + i], acc);
-                                } else {
-                                    const int lo = a.band_lo[m];
-                                    for (int i = 0; i < a.rows; ++i)
-                                        acc = fmaf(a.wband[i * a.M + m], magbuf[st][lo + i], acc);
-                                }
-                                const float v = acc * keep;
-                                store_band(fcur[st], (unsigned)m * rowpitch_b, v);
-                                mn = fminf(mn, v);
-                                mx = fmaxf(mx, v);
-                            }
-                        }
                     }
                 }
-            } else {
-#pragma unroll
-                for (int st = 0; st < S; ++st)
-                    if (live[st])
-                        for (int m = lane; m < a.M; m += kWave) {
-                            store_band(fcur[st], (unsigned)m * rowpitch_b, 0.f);
-                            mn = fminf(mn, 0.f);
-                            mx = fmaxf(mx, 0.f);
-                        }
             }
             wave_sync_lds();
             PH_MARK(5);
-            // the frame reads and the claim have returned: the landing buffers are free again
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int st = 0; st < S; ++st) f[st] = fn[st];
-            if (more) {
-                claimed = __builtin_amdgcn_readfirstlane(claimed);
-#pragma unroll
-                for (int st = 0; st < S; ++st) fn[st] = claimed + st;
-                if constexpr (!DIRECT) issue_dma(fn, b, t0, nwf);
-            }
+            advance();
             PH_MARK(2);
             if ABL(4096) ph[7] += 1;
         }
@@ -798,6 +884,13 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
         if (chunk + (int)gridDim.x < a.n_chunks) {  // another chunk follows: restart the queue
             __syncthreads();
             if (threadIdx.x == 0) *next_frame = 2 * kFusedWaves * S;
+            if constexpr (BANDS) {
+                const int nc = chunk + (int)gridDim.x, nb = chunk_clip(nc);
+                if (a.t_bands) build_tbits(a.t_bands + (size_t)nb * a.n_tb * 2, chunk_t0(nc, nb), chunk_nt(nc, nb));
+                if constexpr (MELMODE == 1) {
+                    if (a.f_bands) build_wtab(a.f_bands + (size_t)nb * a.n_fb * 2);
+                }
+            }
             __syncthreads();
         }
         PH_MARK(10);
@@ -1400,11 +1493,14 @@ static int plan_streams(const iris_plan* p) {
 
 // LDS of the fused kernel: landing + exchange buffers of every wave (the constant block is
 // staged through the exchange area once), the frame queue, the MELMODE 1 tables
-static size_t fused_lds_bytes(const iris_plan* p, int streams) {
+static size_t fused_lds_bytes(const iris_plan* p, int streams, int chunk_frames = 0) {
     const size_t xbuf = (wave_buf_bytes(p->log2n) + 15) & ~(size_t)15;
     const size_t waves = (size_t)fused_waves(p->log2n, streams) * streams;
     size_t bytes = waves * (size_t)p->n_fft * 4 + std::max(waves * xbuf, (size_t)const_nv4(p->log2n) * 64 * 16) + 16;
     if (p->mel_mode == 1) bytes += ((size_t)p->rows * p->n_mel + p->n_mel) * 4;
+    // time-band bitmap of a chunk, written 2 words per wave per pass over the chunk's frames
+    const size_t pass = (size_t)fused_waves(p->log2n, streams) * 64;
+    bytes += (((size_t)chunk_frames + pass - 1) / pass * pass / 32 + 2) * 4;
     return bytes;
 }
 
@@ -1948,6 +2044,7 @@ extern "C" int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minm
     return IRIS_OK;
 }
 
+constexpr int kMaxChunkFrames = 16384;
 // Chunk geometry of the fused kernel for `per_cu` workgroups per CU: every workgroup one
 // chunk when the problem is large enough, chunks never span clips.
 static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int* chunk_frames, int* chunks_per_clip) {
@@ -1959,6 +2056,7 @@ static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int
     // rounding up per clip can overshoot the slots by a few chunks, which would cost a whole
     // second round: prefer slightly larger chunks that fit one round
     if (p->chunk_target == 0 && (long)batch * cpc > slots && batch <= slots) cpc = std::max(1, slots / batch);
+    cpc = std::max(cpc, (T + kMaxChunkFrames - 1) / kMaxChunkFrames);  // bounds the time-band bitmap in LDS
     *chunks_per_clip = cpc;
     *chunk_frames = (T + cpc - 1) / cpc;
 }
@@ -1967,16 +2065,16 @@ static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int
 // the register-limited occupancy and go down until the occupancy query agrees.
 static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, int* chunk_frames,
                         int* chunks_per_clip, int* grid, size_t* lds) {
-    *lds = fused_lds_bytes(p, streams);
-    if (*lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
     for (int per_cu = fused_occ(p->log2n); per_cu >= 1; --per_cu) {
+        fused_geometry(p, batch, T, per_cu, chunk_frames, chunks_per_clip);
+        *lds = fused_lds_bytes(p, streams, *chunk_frames);
+        if (*lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
         int resident = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
                                                                     64 * fused_waves(p->log2n, streams), *lds);
         if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s",
                                          hipGetErrorString(e));
         if (resident >= per_cu) {
-            fused_geometry(p, batch, T, per_cu, chunk_frames, chunks_per_clip);
             *grid = std::min(batch * *chunks_per_clip, p->num_cu * per_cu);
             return IRIS_OK;
         }
