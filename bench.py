@@ -93,9 +93,7 @@ def side_measurements(dev, rank, world, steps, fence):
     DDP when world > 1, AGC, clipvalue, Adam), batch 64 per GPU, synthetic labels."""
     import torch.distributed as dist
     from challenge_amd import sj_train as S
-    # MIOpen must benchmark its solvers once per conv shape (NORMAL find): the FAST heuristic picks
-    # a CK backward-weight kernel that is ~60x slower on these fp32 shapes (about 35 s, first run only)
-    os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL")
+    S.configure_miopen()  # NORMAL find without the naive reference solvers (see sj_train.configure_miopen)
     batch, length = 64, 130816
     audio_s = batch * length / SR
     cfg = S.ARGS().get(['--v', '9', '--n_mels', str(N_MEL), '--n_frame', '512', '--n_chan', '1',

@@ -539,6 +539,16 @@ def run_name(config) -> str:
     return name if name.endswith('.h5') else name + '.h5'
 
 
+def configure_miopen() -> None:
+    """MIOpen defaults for this model's fp32 conv shapes (only set when the user has not):
+    NORMAL find benchmarks the applicable solvers once per shape - the FAST heuristic picks a CK
+    backward-weight kernel that is ~60x slower here - and the naive reference solvers (hundreds of
+    ms per call, never the winner) are kept out of that benchmark."""
+    os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL")
+    for d in ("FWD", "BWD", "WRW"):
+        os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + d, "0")
+
+
 def init_distributed():
     """One process per GPU (torchrun): returns (rank, world, device).  Backend 'nccl' is
     RCCL on ROCm; 'gloo' on CPU-only hosts (tests)."""
@@ -627,6 +637,7 @@ def main(argv=None):
     config.loss = config.loss.upper()
     if config.loss != 'MSE':
         config.mse_multiplier = 1
+    configure_miopen()
     rank, world, device = init_distributed()
     if rank == 0:
         print(config)
