@@ -195,6 +195,44 @@ int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float clip_factor
                   float clipvalue, void* stream);
 
 /*
+ * Sample synthesis in the complex-STFT domain, deterministic half of
+ * merge_complex_specs (pipeline.py:6-110) for a whole batch: every output sample
+ * is   background crop (tiled along time, pipeline.py:29-35)
+ *    + sum over its voices of gain * crop(zero-padded voice) * no_overlap (:48-84)
+ *    + sum over its noises of gain * crop(zero-padded noise)              (:86-106)
+ * with the frame labels of the accepted voices (:55-66, :78-84).  All random draws
+ * (which sources, offsets, gains) are made by the caller and passed in the source
+ * table; the data-dependent parts - a voice frame is "active" when max over
+ * (freq, chan2) of the frame is > 0 (:57), a voice is dropped when accepting it
+ * would make two labels overlap (:78-80) - are evaluated here.
+ * Additions happen in table order with separately rounded multiply and add, so
+ * the result equals the reference's op-by-op evaluation bit for bit.
+ *
+ * srcs: DEVICE table, the sources of sample b are srcs[first[b] .. first[b+1]) in
+ *       the order background, voices (by slot), noises.  first: DEVICE int32 [B + 1].
+ *   src    DEVICE [F, T, C2] fp32 spectrogram (time axis 1, re block | im block last)
+ *   T      frames in src;  pad: zero frames virtually added on both sides (>= 0);
+ *   off    crop offset in the padded (voice, noise) or tiled (background) source;
+ *   gain   linear gain (ignored for the background);  kind 0 background, 1 voice, 2 noise;
+ *   slot   row of the labels output (kind 1);  label_row: row of label_vecs (kind 1).
+ * label_vecs: DEVICE [n_label_rows, n_classes] fp32 (one-hot rows in the reference).
+ * spec_out: DEVICE [B, F, n_frame, C2];  labels_out: DEVICE [B, V, n_frame, n_classes].
+ * workspace: DEVICE scratch of iris_mix_workspace(n_srcs, n_frame) floats.
+ * Runs on the current HIP device.
+ */
+typedef struct {
+    const float* src;
+    int32_t T, pad, off;
+    float gain;
+    int32_t kind, slot, label_row, reserved;
+} iris_mix_src;
+size_t iris_mix_workspace(int n_srcs, int n_frame);
+int iris_mix_specs(const iris_mix_src* srcs_dev, int n_srcs, const int32_t* first_dev,
+                   const float* label_vecs_dev, float* spec_out, float* labels_out, int batch,
+                   int n_bins, int n_frame, int chan2, int max_voices, int n_classes,
+                   float* workspace, size_t workspace_floats, void* stream);
+
+/*
  * Per-kernel timing for bench.py: with enable = n > 0 every n-th launch of the
  * dominant kernel of iris_wav_to_logmel carries a start/stop hipEvent pair on
  * the launch stream (n = 1: every launch; an event pair costs a few

@@ -275,3 +275,55 @@ def test_eval_path_on_gpu(dev):
     model = S.get_model(cfg).to(dev)
     out = I.evaluate_wav(model, wav, cfg, 16000, overlap_hop=32, device=dev)
     assert tuple(out.shape) == (157, 3) and set(np.unique(out.cpu().numpy())) <= {0.0, 1.0}
+
+
+def test_device_mixer_matches_oracle(dev):
+    """Batched on-device sample synthesis (iris_mix_specs) == merge_complex_specs of the oracle
+    (pipeline.py:6-110) sample by sample, bit for bit: ragged sources, padded groups, tiled
+    backgrounds, silent voice frames, overlapping labels (dropped voices), noises."""
+    from challenge_amd.mixer import DeviceMixer
+    rng = np.random.default_rng(11)
+    F, C2, n_frame, n_classes = 33, 4, 48, 3
+
+    def clip(t, silent_from=None):
+        x = rng.standard_normal((F, t, C2)).astype(np.float32)
+        if silent_from is not None:
+            x[:, silent_from:] = -np.abs(x[:, silent_from:])  # max <= 0: inactive frames
+        return x
+    backgrounds = [clip(t) for t in (20, 70, 48)]
+    voices = [clip(t, s) for t, s in ((30, 20), (55, None), (41, 5), (64, 50), (25, None), (48, 30), (36, None))]
+    labels = np.eye(n_classes, dtype=np.float32)[rng.integers(0, n_classes, len(voices))]
+    noises = [clip(t) for t in (18, 90, 40, 52)]
+    mixer = DeviceMixer(backgrounds, voices, labels, noises, n_frame=n_frame, max_voices=4, max_noises=3,
+                        n_classes=n_classes, device=dev, min_ratio=1, seed=5)
+    draws = mixer.draw(16)
+    spec, lab = mixer.mix(16, draws)
+    assert spec.shape == (16, F, n_frame, C2) and lab.shape == (16, 4, n_frame, n_classes)
+    spec, lab = spec.cpu().numpy(), lab.cpu().numpy()
+    dropped = 0
+    for i, d in enumerate(draws):
+        def padded(bank, idx, length):
+            out = np.zeros((len(idx), F, length, C2), np.float32)
+            for j, k in enumerate(idx):
+                out[j, :, :bank[k].shape[1]] = bank[k]
+            return out
+        v = padded(voices, d["voices"], d["v_len"])
+        n = padded(noises, d["noises"], d["n_len"])
+        ref_spec, ref_lab = R.merge_complex_specs_apply(backgrounds[d["bg"]], v, labels[d["voices"]], n, d,
+                                                        n_frame=n_frame, n_classes=n_classes, min_ratio=1)
+        assert np.array_equal(spec[i], ref_spec), i
+        assert np.array_equal(lab[i], ref_lab), i
+        dropped += int(d["n_voices"] - (ref_lab.max(axis=(1, 2)) > 0).sum())
+    assert dropped > 0  # the overlap rule was exercised
+    # a second batch continues the shuffled streams; no min_ratio override -> padding path
+    mixer2 = DeviceMixer(backgrounds, voices, labels, None, n_frame=n_frame, max_voices=3, n_classes=n_classes,
+                         device=dev, seed=6)
+    d2 = mixer2.draw(5)
+    s2, l2 = mixer2.mix(5, d2)
+    for i, d in enumerate(d2):
+        v = np.zeros((3, F, d["v_len"], C2), np.float32)
+        for j, k in enumerate(d["voices"]):
+            v[j, :, :voices[k].shape[1]] = voices[k]
+        ref_spec, ref_lab = R.merge_complex_specs_apply(backgrounds[d["bg"]], v, labels[d["voices"]], None, d,
+                                                        n_frame=n_frame, n_classes=n_classes)
+        assert np.array_equal(s2[i].cpu().numpy(), ref_spec) and np.array_equal(l2[i].cpu().numpy(), ref_lab)
