@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from . import data_utils as _du
 from . import frontend as _fe
+from . import transforms as _tr
 from .data_utils import (augment, label_downsample, log_on_mel, minmax, mono_chan, multiply_label,  # noqa: F401
                          random_merge_aug, stereo_mono, stft_filter, to_frame_labels)
 from .dataset import AUTOTUNE, Dataset
@@ -102,8 +103,14 @@ def complex_to_mel(n_mels: int, num_spectrogram_bins: int = 257, sample_rate: fl
     n_fft = 2 * (num_spectrogram_bins - 1)
     plans = {}
 
-    def _complex_to_mel(x, y=None):
+    def _complex_to_mel(x, y=None, t_bands=None, f_bands=None):
+        """t_bands / f_bands ([B, n, 2] (offset, size), optional): SpecAugment / stft_filter bands
+        zeroed in the complex spectrum first (== `augment` / `stft_filter` mapped before this stage)."""
         if not x.is_cuda or n_fft not in (256, 512, 1024, 2048):
+            if t_bands is not None:
+                x = _tr.mask_apply(x, -2, t_bands)
+            if f_bands is not None:
+                x = _tr.mask_apply(x, -3, f_bands)
             out = to_mel(complex_to_magphase(x))
         else:
             chan = x.shape[-1] // 2
@@ -113,7 +120,7 @@ def complex_to_mel(n_mels: int, num_spectrogram_bins: int = 257, sample_rate: fl
                 plan = _fe.FrontendPlan(n_fft, None, n_mels, sample_rate, chan, max(int(x.shape[0]), 1), n_fft,
                                         x.device, mel_matrix=to_mel.mel_matrix)
                 plans[key] = plan
-            out = plan.magmel(x.float(), is_magphase=False)
+            out = plan.magmel(x.float(), is_magphase=False, t_bands=t_bands, f_bands=f_bands)
         return out if y is None else (out, y)
     return _complex_to_mel
 
@@ -137,9 +144,8 @@ def synthetic_sources(n_chan: int = 2, n_classes: int = 3, freq: int = 257, n_bg
     return backgrounds, voices, labels, noises
 
 
-def make_dataset(config, training=True, n_classes=3, sources=None):
-    """Stage order of sj_train.py:74-130.  `sources` = (backgrounds, voices, labels, noises)
-    overrides the pickle files (used with --synthetic and by the tests)."""
+def _load_sources(config, training, n_classes, sources):
+    """The pickled corpora of sj_train.py:79-89 (or `sources` / --synthetic stand-ins) with one-hot labels."""
     if sources is None and getattr(config, 'synthetic', False):
         sources = synthetic_sources(2, n_classes, seed=0 if training else 1)
     if sources is None:
@@ -159,6 +165,28 @@ def make_dataset(config, training=True, n_classes=3, sources=None):
     else:
         backgrounds, voices, labels, noises = sources
     labels = np.eye(n_classes, dtype='float32')[np.asarray(labels)]  # to one-hot vectors
+    return backgrounds, voices, labels, noises
+
+
+def _label_tail(pipeline, config):
+    """The stages after the mel features (sj_train.py:121-129)."""
+    if 'nominmax' not in config.name:
+        pipeline = pipeline.map(_du.minmax_log_on_mel)  # :121-123 fused
+    else:
+        pipeline = pipeline.map(log_on_mel)
+    if config.v in label_downsample_model:
+        pipeline = pipeline.map(label_downsample(32))
+    elif config.v == 5:
+        pipeline = pipeline.map(label_downsample(config.n_frame // (config.n_frame * 256 // 16000)))
+    if config.loss.upper() in ('MSE', 'MAE'):
+        pipeline = pipeline.map(multiply_label(config.mse_multiplier))
+    return pipeline.prefetch(AUTOTUNE)
+
+
+def make_dataset(config, training=True, n_classes=3, sources=None):
+    """Stage order of sj_train.py:74-130.  `sources` = (backgrounds, voices, labels, noises)
+    overrides the pickle files (used with --synthetic and by the tests)."""
+    backgrounds, voices, labels, noises = _load_sources(config, training, n_classes, sources)
 
     pipeline = make_pipeline(backgrounds, voices, labels, noises, n_frame=config.n_frame,
                              max_voices=config.max_voices, max_noises=config.max_noises, n_classes=n_classes,
@@ -180,17 +208,50 @@ def make_dataset(config, training=True, n_classes=3, sources=None):
     pipeline = pipeline.batch(config.batch_size, drop_remainder=False)
     n_bins = int(np.asarray(backgrounds[0]).shape[0])
     pipeline = pipeline.map(complex_to_mel(config.n_mels, n_bins))  # :119-120 fused
-    if 'nominmax' not in config.name:
-        pipeline = pipeline.map(_du.minmax_log_on_mel)  # :121-123 fused
-    else:
-        pipeline = pipeline.map(log_on_mel)
-    if config.v in label_downsample_model:
-        pipeline = pipeline.map(label_downsample(32))
-    elif config.v == 5:
-        pipeline = pipeline.map(label_downsample(config.n_frame // (config.n_frame * 256 // 16000)))
-    if config.loss.upper() in ('MSE', 'MAE'):
-        pipeline = pipeline.map(multiply_label(config.mse_multiplier))
-    return pipeline.prefetch(AUTOTUNE)
+    return _label_tail(pipeline, config)
+
+
+def make_device_dataset(config, training=True, n_classes=3, sources=None, device=None, seed=None):
+    """MI355X-native `make_dataset`: same stages, same outputs (sj_train.py:74-130), but a whole
+    batch at a time on the device.  The corpora stay resident in HBM; `DeviceMixer` synthesises the
+    batch in three launches (merge_complex_specs, pipeline.py:6-110); SpecAugment and `stft_filter`
+    reach the mel kernel as band descriptors instead of being multiplied into the 135 MB complex
+    batch (they zero time / frequency ranges, which commutes with the per-bin channel mixes and with
+    the magnitude).  Yields (x [B, n_mels, n_frame, C], y) forever, like the repeated reference graph."""
+    from .mixer import DeviceMixer
+    backgrounds, voices, labels, noises = _load_sources(config, training, n_classes, sources)
+    if config.model_type == 'se' and config.v == 9:
+        raise NotImplementedError("model_type 'se' is outside the accelerated path (SURVEY.md section 2)")
+    mixer = DeviceMixer(backgrounds, voices, labels, noises, n_frame=config.n_frame, max_voices=config.max_voices,
+                        max_noises=config.max_noises, n_classes=n_classes, device=device, snr=config.snr,
+                        min_ratio=1, seed=seed)
+    rng = np.random.default_rng(None if seed is None else seed + 1)
+    to_mel = complex_to_mel(config.n_mels, mixer.n_bins)
+    chan_map = None
+    if config.n_chan == 1:
+        chan_map = mono_chan
+    elif config.n_chan == 3:
+        chan_map = stereo_mono
+    elif config.n_chan > 3:
+        chan_map = random_merge_aug(config.n_chan)
+    filter_bins = int(round(200 / (16000 / 256))) if 'filter' in config.name else 0
+
+    def gen():
+        while True:
+            x, y = to_frame_labels(*mixer.mix(config.batch_size))
+            b = int(x.shape[0])
+            tb = fb = None
+            if training:  # `augment` (data_utils.py:58-61): 6 time masks, 1 frequency mask per sample
+                draws = [_du.augment_draw(config.n_frame, mixer.n_bins, rng) for _ in range(b)]
+                tb, fb = np.stack([d[0] for d in draws]), np.stack([d[1] for d in draws])
+            if filter_bins:  # stft_filter (data_utils.py:126-136): bins 1..k
+                flt = np.tile(np.array([[[1, filter_bins]]], np.int32), (b, 1, 1))
+                fb = flt if fb is None else np.concatenate([fb, flt], axis=1)
+            if chan_map is not None:
+                x, y = chan_map(x, y)
+            yield to_mel(x, y, t_bands=tb, f_bands=fb)
+
+    return _label_tail(Dataset.from_generator(gen), config)
 
 
 class WaveFrontend:

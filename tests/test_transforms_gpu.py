@@ -327,3 +327,53 @@ def test_device_mixer_matches_oracle(dev):
         ref_spec, ref_lab = R.merge_complex_specs_apply(backgrounds[d["bg"]], v, labels[d["voices"]], None, d,
                                                         n_frame=n_frame, n_classes=n_classes)
         assert np.array_equal(s2[i].cpu().numpy(), ref_spec) and np.array_equal(l2[i].cpu().numpy(), ref_lab)
+
+
+@pytest.mark.parametrize("n_chan,name", [(2, "run"), (2, "run_filter"), (3, "run_nominmax")])
+def test_device_dataset_equals_per_sample_stages(dev, n_chan, name):
+    """make_device_dataset == the per-sample stage order of make_dataset (sj_train.py:103-129) on the
+    same mixed samples and the same mask draws: bands handed to the mel kernel instead of multiplied into
+    the complex batch, channel maps applied to the batch."""
+    T, D, S = mods()
+    from challenge_amd.mixer import DeviceMixer
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '40', '--n_frame', '64', '--n_chan', str(n_chan), '--batch_size', '6',
+                        '--max_voices', '4', '--max_noises', '3', '--name', name])
+    backgrounds, voices, labels, noises = S.synthetic_sources(2, 3, freq=257, n_bg=3, n_voice=7, n_noise=4, seed=3)
+    onehot = np.eye(3, dtype=np.float32)[np.asarray(labels)]
+    mixer = DeviceMixer(backgrounds, voices, onehot, noises, n_frame=64, max_voices=4, max_noises=3, n_classes=3,
+                        device=dev, min_ratio=1, seed=9)
+    spec, lab = mixer.mix(6)
+    rng = np.random.default_rng(1)
+    draws = [D.augment_draw(64, 257, rng) for _ in range(6)]
+    tb, fb = np.stack([d[0] for d in draws]), np.stack([d[1] for d in draws])
+    k = int(round(200 / (16000 / 256)))
+    chan_map = {1: D.mono_chan, 2: None, 3: D.stereo_mono}[n_chan]
+    # reference order, sample by sample: to_frame_labels, augment, channel map, stft_filter, batch
+    xs, ys = [], []
+    for i in range(6):
+        x, y = D.to_frame_labels(spec[i], lab[i])
+        x = T.mask_apply(T.mask_apply(x, -2, tb[i]), -3, fb[i])
+        if chan_map is not None:
+            x, y = chan_map(x, y)
+        if 'filter' in name:
+            x, y = D.stft_filter(k)(x, y)
+        xs.append(x)
+        ys.append(y)
+    to_mel = S.complex_to_mel(40, 257)
+    ref_x, ref_y = to_mel(torch.stack(xs), torch.stack(ys))
+    # device order: batch first, bands into the mel kernel
+    x, y = D.to_frame_labels(spec, lab)
+    if chan_map is not None:
+        x, y = chan_map(x, y)
+    fbb = fb if 'filter' not in name else np.concatenate([fb, np.tile(np.array([[[1, k]]], np.int32), (6, 1, 1))], 1)
+    out_x, out_y = to_mel(x, y, t_bands=tb, f_bands=fbb)
+    assert torch.equal(out_x, ref_x) and torch.equal(out_y, ref_y)
+    # and the assembled dataset: shapes / value ranges of the reference graph, batch after batch
+    ds = S.make_device_dataset(cfg, training=True, sources=(backgrounds, voices, labels, noises), device=dev, seed=4)
+    it = iter(ds)
+    for _ in range(3):
+        bx, by = next(it)
+        assert bx.shape == (6, 40, 64, {1: 1, 2: 2, 3: 3}[n_chan]) and by.shape == (6, 2, 3)
+        assert torch.isfinite(bx).all() and float(by.min()) >= 0 and float(by.max()) <= 1
+        if 'nominmax' not in name:
+            assert float(bx.max()) <= 1e-6 and float(bx.min()) >= np.log(1e-8) - 1e-3
