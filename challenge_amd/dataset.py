@@ -6,6 +6,7 @@ generators; heavy work happens inside the mapped functions (HIP kernels / torch
 device ops), so this is glue, not a hot path."""
 from __future__ import annotations
 
+import atexit
 import queue
 import random
 import threading
@@ -29,6 +30,26 @@ def _map_structure(fn, x):
     if isinstance(x, (tuple, list)):
         return tuple(_map_structure(fn, v) for v in x)
     return fn(x)
+
+
+# prefetch workers still running: stopped and joined before the interpreter (and with it the HIP
+# runtime) shuts down - a daemon thread caught inside a HIP call at teardown aborts the process
+_live_workers: list = []
+
+
+def _reap_workers(wait: bool = False) -> None:
+    for stop, t in list(_live_workers):
+        if wait:
+            stop.set()
+            t.join(timeout=5.0)
+        if not t.is_alive():
+            try:
+                _live_workers.remove((stop, t))
+            except ValueError:
+                pass
+
+
+atexit.register(_reap_workers, True)
 
 
 class Dataset:
@@ -157,6 +178,7 @@ class Dataset:
                     q.put(e)
 
             t = threading.Thread(target=worker, daemon=True)
+            _live_workers.append((stop, t))
             t.start()
             try:
                 while True:
@@ -168,6 +190,7 @@ class Dataset:
                     yield item
             finally:
                 stop.set()
+                _reap_workers()
         return Dataset(it, self._infinite)
 
     def __iter__(self):

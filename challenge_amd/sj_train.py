@@ -85,6 +85,9 @@ class ARGS:
         a('--synthetic', action='store_true', help='synthetic sources instead of the pickled datasets')
         a('--online_stft', action='store_true',
           help='generate waveforms and run the fused HIP frontend (STFT on line) instead of mixing spectra')
+        a('--per_sample_pipeline', action='store_true',
+          help='build samples one at a time with the tf.data-shaped graph (make_dataset) instead of the '
+               'batched on-device synthesis (make_device_dataset), which is the default on a GPU')
         a('--no_clipvalue_after_agc', action='store_true',
           help="skip Adam's element-wise clipvalue (TF < 2.4 behaviour of the custom train_step)")
         a('--validation_steps', type=int, default=16)
@@ -715,8 +718,13 @@ def main(argv=None):
         print(NAME, sum(p.numel() for p in model.parameters()), 'parameters')
     if config.pretrain and os.path.exists(NAME.replace('.h5', '.pt')):
         model.load_state_dict(torch.load(NAME.replace('.h5', '.pt'), map_location=device))
-    train_set = make_dataset(config, training=True)
-    test_set = make_dataset(config, training=False)
+    if device.type == 'cuda' and not config.per_sample_pipeline:
+        # corpora resident in HBM, whole batches synthesised on the device (each rank draws its own stream)
+        train_set = make_device_dataset(config, training=True, device=device, seed=1000 + rank)
+        test_set = make_device_dataset(config, training=False, device=device, seed=2000 + rank)
+    else:
+        train_set = make_dataset(config, training=True)
+        test_set = make_dataset(config, training=False)
     from .swa import NO_SWA_ERROR, SWA
     swa = SWA(start_epoch=config.epochs // 4, swa_freq=2)  # sj_train.py:491
     fit(model, train_set, config.epochs, config.steps_per_epoch, test_set, config.validation_steps,
