@@ -133,7 +133,18 @@ def side_measurements(dev, rank, world, steps, fence):
 
     t_fwd = timed(fwd, steps)
     t_train = timed(train, steps)
+
+    # input side of the reference's own training loop (spectra in, sj_train.py:74-130) at its default
+    # shape: whole batches synthesised on the device (iris_mix_specs + mel kernel with bands)
+    dcfg = S.ARGS().get(['--v', '9', '--n_mels', '80', '--n_frame', '512', '--n_chan', '2', '--batch_size', str(batch)])
+    ds = iter(S.make_device_dataset(dcfg, True, sources=S.synthetic_sources(2, 3, n_bg=16, n_voice=64, n_noise=32, seed=rank),
+                                    device=dev, seed=rank))
+    t_data = timed(lambda: next(ds), steps)
+    del ds
     return {
+        "device_dataset": {"ms_per_batch": round(1e3 * t_data, 3), "batch_per_gpu": batch,
+                           "audio_s_per_s": round(world * batch * 512 * HOP / SR / t_data, 1),
+                           "shape": "spectra [257, T_i, 4] resident in HBM -> log-mel [64, 80, 512, 2] + labels"},
         "c3_frontend_specaug_crnn_fwd": {"audio_s_per_s": round(world * audio_s / t_fwd, 1),
                                          "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch},
         "c4_train_step": {"audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3),
