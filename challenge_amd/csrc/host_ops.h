@@ -1,0 +1,348 @@
+// host_ops.h -- host side: the C-ABI entry points of the operators (argument checks, geometry, launches).
+// Part of the single translation unit iris_frontend.hip.
+#pragma once
+// ---------------------------------------------------------------------------
+// host: ops
+// ---------------------------------------------------------------------------
+static size_t n_chunks_of(size_t row_len) { return (row_len + kChunk - 1) / kChunk; }
+
+extern "C" size_t iris_normalize_workspace(int n_rows, size_t row_len) {
+    return n_rows > 0 ? (size_t)n_rows * n_chunks_of(row_len) : 0;
+}
+
+extern "C" int iris_normalize(const float* wav, float* out, int n_rows, size_t row_len, float* workspace,
+                              size_t workspace_floats, void* stream) {
+    if (!wav || !out || !workspace) return fail(IRIS_E_INVALID, "iris_normalize: NULL argument");
+    if (n_rows <= 0 || row_len == 0) return fail(IRIS_E_INVALID, "iris_normalize: empty tensor");
+    if (n_rows > 65535) return fail(IRIS_E_UNSUPPORTED, "iris_normalize: n_rows %d > 65535", n_rows);
+    const size_t n_part = n_chunks_of(row_len);
+    if (workspace_floats < iris_normalize_workspace(n_rows, row_len))
+        return fail(IRIS_E_CAPACITY, "iris_normalize: workspace %zu floats < %zu", workspace_floats,
+                    iris_normalize_workspace(n_rows, row_len));
+    hipStream_t s = (hipStream_t)stream;
+    k_sumsq_partial<<<dim3((unsigned)n_part, n_rows), 256, 0, s>>>(wav, workspace, row_len, (int)n_part);
+    k_normalize_apply<<<dim3((unsigned)n_part, n_rows), 256, 0, s>>>(wav, out, workspace, (int)n_part, row_len);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+template <int LOG2N>
+static hipError_t launch_stft(const StftArgs& a, int grid, size_t lds, hipStream_t s) {
+    k_stft<LOG2N><<<grid, 256, lds, s>>>(a);
+    return hipGetLastError();
+}
+
+extern "C" int iris_stft(iris_plan* p, const float* wav, float* spec, int batch, int len, void* stream) {
+    int rc = check_wav_args(p, wav, spec, batch, len, "iris_stft");
+    if (rc) return rc;
+    DeviceGuard guard(p->device);
+    StftArgs a;
+    a.wav = wav;
+    a.spec = spec;
+    a.consts = p->d_consts;
+    a.B = batch;
+    a.C = p->channels;
+    a.L = len;
+    a.T = 1 + len / p->hop;
+    a.hop = p->hop;
+    const int NC = p->n_fft / 2, F = NC + 1;
+    int tf = 16;
+    auto lds_of = [&](int t) { return 4 * ((wave_buf_bytes(p->log2n) + 15) & ~(size_t)15) + (size_t)F * (t * 2 * p->channels + 1) * 4; };
+    while (tf > 1 && lds_of(tf) > 64 * 1024) tf /= 2;
+    if (lds_of(tf) > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_stft: channels=%d too large", p->channels);
+    a.tile_frames = tf;
+    a.tiles_per_clip = (a.T + tf - 1) / tf;
+    const int grid = batch * a.tiles_per_clip;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    switch (p->log2n) {
+        case 11: e = launch_stft<11>(a, grid, lds_of(tf), s); break;
+        case 10: e = launch_stft<10>(a, grid, lds_of(tf), s); break;
+        case 9: e = launch_stft<9>(a, grid, lds_of(tf), s); break;
+        default: e = launch_stft<8>(a, grid, lds_of(tf), s); break;
+    }
+    HIP_TRY(e);
+    return IRIS_OK;
+}
+
+static int grid_for(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 2048 * 4); }
+
+extern "C" int iris_complex_to_magphase(const float* in, float* out, size_t n_outer, int channels, void* stream) {
+    if (!in || !out || channels <= 0) return fail(IRIS_E_INVALID, "iris_complex_to_magphase: bad argument");
+    if (n_outer == 0) return IRIS_OK;
+    k_complex_to_magphase<<<grid_for(n_outer * channels), 256, 0, (hipStream_t)stream>>>(in, out, n_outer, channels);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_magphase_to_complex(const float* in, float* out, size_t n_outer, int channels, void* stream) {
+    if (!in || !out || channels <= 0) return fail(IRIS_E_INVALID, "iris_magphase_to_complex: bad argument");
+    if (n_outer == 0) return IRIS_OK;
+    k_magphase_to_complex<<<grid_for(n_outer * channels), 256, 0, (hipStream_t)stream>>>(in, out, n_outer, channels);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_magmel(iris_plan* p, const float* spec, float* mel, int batch, int n_frames, int is_magphase,
+                           const int32_t* t_bands, int n_tb, const int32_t* f_bands, int n_fb, void* stream) {
+    if (!p || !spec || !mel) return fail(IRIS_E_INVALID, "iris_magmel: NULL argument");
+    if (batch <= 0 || n_frames <= 0) return fail(IRIS_E_INVALID, "iris_magmel: batch=%d n_frames=%d", batch, n_frames);
+    if (batch > 65535) return fail(IRIS_E_UNSUPPORTED, "iris_magmel: batch %d > 65535", batch);
+    int rc;
+    if ((rc = check_bands(t_bands, n_tb, "iris_magmel")) || (rc = check_bands(f_bands, n_fb, "iris_magmel"))) return rc;
+    DeviceGuard guard(p->device);
+    MagmelArgs a;
+    a.spec = spec;
+    a.mel = mel;
+    a.w = p->d_mel;
+    a.band_lo = p->d_band_lo;
+    a.band_len = p->d_band_len;
+    a.t_bands = n_tb ? t_bands : nullptr;
+    a.n_tb = n_tb;
+    a.f_bands = n_fb ? f_bands : nullptr;
+    a.n_fb = n_fb;
+    a.B = batch;
+    a.C = p->channels;
+    a.F = p->n_bins;
+    a.T = n_frames;
+    a.M = p->n_mel;
+    a.is_magphase = is_magphase;
+    const bool aligned = (reinterpret_cast<uintptr_t>(spec) & (8 * p->channels - 1)) == 0;
+    if (p->tri_ok && (p->channels == 1 || p->channels == 2) && aligned &&
+        (size_t)p->n_mel * 64 * p->channels * sizeof(float) <= 64 * 1024 && getenv("IRIS_MAGMEL_GENERIC") == nullptr) {
+        MagmelTriArgs t;
+        t.spec = spec;
+        t.mel = mel;
+        t.bin_band = p->d_bin_band;
+        t.bin_w = p->d_bin_w;
+        t.t_bands = a.t_bands;
+        t.n_tb = n_tb;
+        t.f_bands = a.f_bands;
+        t.n_fb = n_fb;
+        t.B = batch;
+        t.F = p->n_bins;
+        t.T = n_frames;
+        t.M = p->n_mel;
+        t.is_magphase = is_magphase;
+        t.f_lo = p->tri_f_lo;
+        t.f_hi = p->tri_f_hi;
+        const dim3 grid((n_frames + 63) / 64, batch);
+        // split the bins over 8 waves when the grid alone cannot fill the chip
+        const int threads = (size_t)grid.x * grid.y * 4 < (size_t)p->num_cu * 8 ? 512 : 256;
+        const size_t lds = (size_t)p->n_mel * 64 * p->channels * sizeof(float);
+        if (p->channels == 1) k_magmel_tri<1><<<grid, threads, lds, (hipStream_t)stream>>>(t);
+        else k_magmel_tri<2><<<grid, threads, lds, (hipStream_t)stream>>>(t);
+    } else {
+        const int tc = n_frames * p->channels;
+        k_magmel<<<dim3((tc + 63) / 64, batch), 256, 0, (hipStream_t)stream>>>(a);
+    }
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" size_t iris_minmax_log_workspace(int n_rows, size_t row_len) {
+    return n_rows > 0 ? 2 * (size_t)n_rows * n_chunks_of(row_len) : 0;
+}
+
+extern "C" int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minmax, int do_log, float eps_div,
+                               float eps_log, float* workspace, size_t workspace_floats, void* stream) {
+    if (!x) return fail(IRIS_E_INVALID, "iris_minmax_log: x is NULL");
+    if (n_rows <= 0 || row_len == 0) return fail(IRIS_E_INVALID, "iris_minmax_log: empty tensor");
+    if (n_rows > 65535) return fail(IRIS_E_UNSUPPORTED, "iris_minmax_log: n_rows %d > 65535", n_rows);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n_part = n_chunks_of(row_len);
+    if (do_minmax) {
+        if (reinterpret_cast<uintptr_t>(workspace) & 7)
+            return fail(IRIS_E_INVALID, "iris_minmax_log: workspace must be 8-byte aligned");
+        if (!workspace || workspace_floats < iris_minmax_log_workspace(n_rows, row_len))
+            return fail(IRIS_E_CAPACITY, "iris_minmax_log: workspace %zu floats < %zu", workspace_floats,
+                        iris_minmax_log_workspace(n_rows, row_len));
+        k_minmax_partial<<<dim3((unsigned)n_part, n_rows), 256, 0, s>>>(x, workspace, row_len, (int)n_part);
+    }
+    k_minmax_log_apply<<<dim3((unsigned)((row_len + kApply - 1) / kApply), n_rows), 256, 0, s>>>(x, workspace, (int)n_part, row_len, do_minmax,
+                                                                     do_log, eps_div, eps_log);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+constexpr int kMaxChunkFrames = 16384;
+// Chunk geometry of the fused kernel for `per_cu` workgroups per CU: every workgroup one
+// chunk when the problem is large enough, chunks never span clips.
+static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int* chunk_frames, int* chunks_per_clip) {
+    const int slots = p->num_cu * per_cu;
+    const long total = (long)batch * T;
+    int target = p->chunk_target > 0 ? p->chunk_target : (int)((total + slots - 1) / slots);
+    target = std::max(target, std::min(8, T));
+    int cpc = (T + target - 1) / target;
+    // rounding up per clip can overshoot the slots by a few chunks, which would cost a whole
+    // second round: prefer slightly larger chunks that fit one round
+    if (p->chunk_target == 0 && (long)batch * cpc > slots && batch <= slots) cpc = std::max(1, slots / batch);
+    cpc = std::max(cpc, (T + kMaxChunkFrames - 1) / kMaxChunkFrames);  // bounds the time-band bitmap in LDS
+    *chunks_per_clip = cpc;
+    *chunk_frames = (T + cpc - 1) / cpc;
+}
+
+// Geometry + grid for the residency the hardware really grants (registers and LDS): start from
+// the register-limited occupancy and go down until the occupancy query agrees.
+static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, int* chunk_frames,
+                        int* chunks_per_clip, int* grid, size_t* lds) {
+    for (int per_cu = fused_occ(p->log2n); per_cu >= 1; --per_cu) {
+        fused_geometry(p, batch, T, per_cu, chunk_frames, chunks_per_clip);
+        *lds = fused_lds_bytes(p, streams, *chunk_frames);
+        if (*lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
+        int resident = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
+                                                                    64 * fused_waves(p->log2n, streams), *lds);
+        if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s",
+                                         hipGetErrorString(e));
+        if (resident >= per_cu) {
+            *grid = std::min(batch * *chunks_per_clip, p->num_cu * per_cu);
+            return IRIS_OK;
+        }
+    }
+    return fail(IRIS_E_UNSUPPORTED, "fused kernel does not fit one workgroup per CU (LDS %zu B)", *lds);
+}
+
+extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, int batch, int len, int flags,
+                                  const int32_t* t_bands, int n_tb, const int32_t* f_bands, int n_fb,
+                                  void* stream) {
+    int rc = check_wav_args(p, wav, out, batch, len, "iris_wav_to_logmel");
+    if (rc) return rc;
+    if ((rc = check_bands(t_bands, n_tb, "iris_wav_to_logmel")) ||
+        (rc = check_bands(f_bands, n_fb, "iris_wav_to_logmel")))
+        return rc;
+    DeviceGuard guard(p->device);
+    hipStream_t s = (hipStream_t)stream;
+    FusedArgs a;
+    a.wav = wav;
+    a.out = out;
+    a.consts = p->d_consts;
+    a.band_lo = p->d_fband_lo;
+    a.wband = p->d_wband;
+    a.rows = p->rows;
+    a.t_bands = n_tb ? t_bands : nullptr;
+    a.n_tb = n_tb;
+    a.f_bands = n_fb ? f_bands : nullptr;
+    a.n_fb = n_fb;
+    a.B = batch;
+    a.C = p->channels;
+    a.L = len;
+    a.T = 1 + len / p->hop;
+    a.hop = p->hop;
+    a.M = p->n_mel;
+    const int do_minmax = (flags & IRIS_F_MINMAX) ? 1 : 0, do_log = (flags & IRIS_F_LOG) ? 1 : 0;
+    a.ablate = 0;
+    if (const char* e = getenv("IRIS_ABLATE")) a.ablate = atoi(e);
+    a.dbg = p->d_dbg;
+    const bool bands = (n_tb > 0) || (n_fb > 0);
+    const int streams = plan_streams(p);
+    const fused_kernel_t kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams);
+    int grid = 0;
+    size_t lds = 0;
+    if ((rc = fused_config(p, kernel, batch, a.T, streams, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
+        return rc;
+    if ((size_t)p->n_mel * a.T * p->channels * 4 > 0xffffffffull || (size_t)a.T * p->channels * 4 >= (1u << 24))
+        return fail(IRIS_E_UNSUPPORTED, "iris_wav_to_logmel: clip too long (%d frames x %d channels)", a.T, p->channels);
+    a.n_chunks = batch * a.chunks_per_clip;
+    a.chunk_base = a.T / a.chunks_per_clip;
+    a.chunk_rem = a.T % a.chunks_per_clip;
+    const int waves = fused_waves(p->log2n, streams);
+    const int parts_per_chunk = waves;
+    const size_t n_partial = 2 * (size_t)a.n_chunks * parts_per_chunk;
+    a.partial = p->d_ws;
+    a.sumsq = nullptr;
+    a.n_sq = 0;
+    if (flags & IRIS_F_NORMALIZE) {
+        const size_t row = (size_t)p->channels * len;
+        a.n_sq = (int)((row + kChunk - 1) / kChunk);
+        float* sq = p->d_ws + n_partial;
+        if (n_partial + (size_t)batch * a.n_sq > p->ws_floats)
+            return fail(IRIS_E_CAPACITY, "iris_wav_to_logmel: workspace too small");
+        k_sumsq_partial<<<dim3(a.n_sq, batch), 256, 0, s>>>(wav, sq, row, a.n_sq);
+        a.sumsq = sq;
+    }
+    if (n_partial > p->ws_floats) return fail(IRIS_E_CAPACITY, "iris_wav_to_logmel: workspace too small");
+
+    // bench hook: the kernel's own start/stop timestamps are attached to an event pair by the
+    // AMD launch extension (no extra packets on the stream, unlike hipEventRecord brackets)
+    const bool timed = p->timing > 0 && (p->launch_no++ % p->timing) == 0 && p->ev_used < kMaxTimedLaunches;
+    hipError_t e;
+    if (timed) {
+        while ((int)p->ev.size() < 2 * (p->ev_used + 1)) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreate(&ev));
+            p->ev.push_back(ev);
+        }
+        FusedArgs args = a;
+        void* kargs[] = {&args};
+        e = hipExtLaunchKernel((const void*)kernel, dim3(grid), dim3(64 * waves), kargs, lds, s,
+                               p->ev[2 * p->ev_used], p->ev[2 * p->ev_used + 1], 0);
+        if (e == hipSuccess) p->ev_used++;
+    } else {
+        kernel<<<grid, 64 * waves, lds, s>>>(a);
+        e = hipGetLastError();
+    }
+    HIP_TRY(e);
+    if (do_minmax || do_log) {
+        const size_t row_len = (size_t)p->n_mel * a.T * p->channels;
+        const unsigned n_chunks = (unsigned)((row_len + kApply - 1) / kApply);
+        k_minmax_log_apply<<<dim3(n_chunks, batch), 256, 0, s>>>(out, p->d_ws, a.chunks_per_clip * parts_per_chunk, row_len, do_minmax,
+                                                               do_log, 1e-8f, 1e-8f);
+        HIP_TRY(hipGetLastError());
+    }
+    return IRIS_OK;
+}
+
+extern "C" int iris_mask_apply(void* x, size_t n_outer, size_t axis_len, size_t n_inner, int elem_size,
+                               const int32_t* bands, int n_bands, size_t outer_per_group, void* stream) {
+    if (!x) return fail(IRIS_E_INVALID, "iris_mask_apply: x is NULL");
+    if (elem_size != 4 && elem_size != 8) return fail(IRIS_E_UNSUPPORTED, "iris_mask_apply: elem_size %d", elem_size);
+    int rc = check_bands(bands, n_bands, "iris_mask_apply");
+    if (rc) return rc;
+    if (outer_per_group == 0) return fail(IRIS_E_INVALID, "iris_mask_apply: outer_per_group must be > 0");
+    const size_t total = n_outer * axis_len * n_inner;
+    if (total == 0 || n_bands == 0) return IRIS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (elem_size == 4)
+        k_mask_apply<uint32_t><<<grid_for(total), 256, 0, s>>>((uint32_t*)x, n_outer, axis_len, n_inner, bands,
+                                                              n_bands, outer_per_group);
+    else
+        k_mask_apply<uint64_t><<<grid_for(total), 256, 0, s>>>((uint64_t*)x, n_outer, axis_len, n_inner, bands,
+                                                              n_bands, outer_per_group);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float clip_factor, float eps,
+                             float clipvalue, void* stream) {
+    if (!rows_dev) return fail(IRIS_E_INVALID, "iris_agc_clip: rows is NULL");
+    if (n_rows == 0) return IRIS_OK;
+    const int grid = (int)std::min<size_t>((n_rows + 3) / 4, 4096);
+    k_agc_clip<<<grid, 256, 0, (hipStream_t)stream>>>(rows_dev, n_rows, clip_factor, eps, clipvalue);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_timing_enable(iris_plan* p, int enable) {
+    if (!p) return fail(IRIS_E_INVALID, "iris_timing_enable: NULL plan");
+    p->timing = enable > 0 ? enable : 0;
+    p->launch_no = 0;
+    p->ev_used = 0;
+    return IRIS_OK;
+}
+
+extern "C" int iris_timing_read(iris_plan* p, int* n_launches, float* mean_ms) {
+    if (!p || !n_launches || !mean_ms) return fail(IRIS_E_INVALID, "iris_timing_read: NULL argument");
+    DeviceGuard guard(p->device);
+    double total = 0.0;
+    for (int i = 0; i < p->ev_used; ++i) {
+        HIP_TRY(hipEventSynchronize(p->ev[2 * i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]));
+        total += ms;
+    }
+    *n_launches = p->ev_used;
+    *mean_ms = p->ev_used ? (float)(total / p->ev_used) : 0.f;
+    p->ev_used = 0;
+    return IRIS_OK;
+}

@@ -1,0 +1,214 @@
+// k_elementwise.h -- min-max / log, normalize, magnitude-phase, mask apply, adaptive gradient clipping.
+// Part of the single translation unit iris_frontend.hip.
+#pragma once
+// ---------------------------------------------------------------------------
+// K4/K5: min-max (+ log): partial reduce, then apply
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_minmax_partial(const float* x, float* partial, size_t row_len,
+                                                        int n_part) {
+    __shared__ float red[32];
+    const int row = blockIdx.y, part = blockIdx.x;
+    const float* p = x + (size_t)row * row_len;
+    const size_t beg = (size_t)part * kChunk, end = min(beg + (size_t)kChunk, row_len);
+    float mn = INFINITY, mx = -INFINITY;
+    for (size_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+        const float v = p[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    block_minmax(mn, mx, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)row * n_part + part) * 2 + 0] = mn;
+        partial[((size_t)row * n_part + part) * 2 + 1] = mx;
+    }
+}
+
+// One float4 per thread (kApply elements per block): at a few MB per launch the kernel is bound
+// by instruction latency, not bandwidth, so it wants many short waves.  The element load is
+// issued before the partials are folded (two independent round trips overlap).
+constexpr int kApply = 1024;
+__global__ __launch_bounds__(256) void k_minmax_log_apply(float* x, const float* partial, int n_part,
+                                                          size_t row_len, int do_minmax, int do_log,
+                                                          float eps_div, float eps_log) {
+    __shared__ float red[32];
+    const int row = blockIdx.y;
+    float* p = x + (size_t)row * row_len;
+    const size_t beg = (size_t)blockIdx.x * kApply, end = min(beg + (size_t)kApply, row_len);
+    const bool vec = ((row_len & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);  // uniform
+    const size_t iv = beg + 4 * (size_t)threadIdx.x;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec && iv < end) v = *reinterpret_cast<const float4*>(p + iv);
+
+    float mn = 0.f, den = 1.f;
+    if (do_minmax) {
+        float lo = INFINITY, hi = -INFINITY;
+        if (n_part <= 256) {  // few partials: every wave folds them itself (no barrier)
+            const float2* pr = reinterpret_cast<const float2*>(partial) + (size_t)row * n_part;
+            for (int i = threadIdx.x & 63; i < n_part; i += 64) {
+                const float2 q = pr[i];
+                lo = fminf(lo, q.x);
+                hi = fmaxf(hi, q.y);
+            }
+            lo = wave_min(lo);
+            hi = wave_max(hi);
+        } else {
+            for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
+                lo = fminf(lo, partial[((size_t)row * n_part + i) * 2 + 0]);
+                hi = fmaxf(hi, partial[((size_t)row * n_part + i) * 2 + 1]);
+            }
+            block_minmax(lo, hi, red);
+        }
+        mn = lo;
+        den = fmaxf(hi - lo, eps_div);
+    }
+    if (vec) {
+        if (iv < end) {
+            float* e = reinterpret_cast<float*>(&v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float y = e[j];
+                if (do_minmax) y = (y - mn) / den;
+                if (do_log) y = logf(y + eps_log);
+                e[j] = y;
+            }
+            *reinterpret_cast<float4*>(p + iv) = v;
+        }
+    } else {
+        for (size_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+            float y = p[i];
+            if (do_minmax) y = (y - mn) / den;
+            if (do_log) y = logf(y + eps_log);
+            p[i] = y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// normalize: partial sums of squares, then scale
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sumsq_partial(const float* x, float* partial, size_t row_len, int n_part) {
+    __shared__ float red[4];
+    const int row = blockIdx.y, part = blockIdx.x;
+    const float* p = x + (size_t)row * row_len;
+    const size_t beg = (size_t)part * kChunk, end = min(beg + (size_t)kChunk, row_len);
+    float s = 0.f;
+    for (size_t i = beg + threadIdx.x; i < end; i += blockDim.x) s = fmaf(p[i], p[i], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)row * n_part + part] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_normalize_apply(const float* x, float* out, const float* partial,
+                                                         int n_part, size_t row_len) {
+    __shared__ float red[4];
+    const int row = blockIdx.y;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) s += partial[(size_t)row * n_part + i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const float rms10 = sqrtf(s / (float)row_len) * 10.0f;
+    const float* p = x + (size_t)row * row_len;
+    float* o = out + (size_t)row * row_len;
+    const size_t beg = (size_t)blockIdx.x * kChunk, end = min(beg + (size_t)kChunk, row_len);
+    for (size_t i = beg + threadIdx.x; i < end; i += blockDim.x) o[i] = p[i] / rms10;
+}
+
+// ---------------------------------------------------------------------------
+// elementwise: magnitude/phase, mask apply
+// ---------------------------------------------------------------------------
+__global__ void k_complex_to_magphase(const float* in, float* out, size_t n_outer, int C) {
+    const size_t total = n_outer * (size_t)C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = i / C;
+        const int c = (int)(i - o * C);
+        const float re = in[o * 2 * C + c], im = in[o * 2 * C + C + c];
+        out[o * 2 * C + c] = sqrtf(re * re + im * im);
+        out[o * 2 * C + C + c] = atan2f(im, re);
+    }
+}
+
+__global__ void k_magphase_to_complex(const float* in, float* out, size_t n_outer, int C) {
+    const size_t total = n_outer * (size_t)C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = i / C;
+        const int c = (int)(i - o * C);
+        const float mag = in[o * 2 * C + c], ph = in[o * 2 * C + C + c];
+        float s, co;
+        sincosf(ph, &s, &co);
+        out[o * 2 * C + c] = mag * co;
+        out[o * 2 * C + C + c] = mag * s;
+    }
+}
+
+template <typename T>
+__global__ void k_mask_apply(T* x, size_t n_outer, size_t axis_len, size_t n_inner, const int* bands, int n_bands,
+                             size_t outer_per_group) {
+    const size_t total = n_outer * axis_len * n_inner;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t oa = i / n_inner;
+        const size_t o = oa / axis_len;
+        const int ax = (int)(oa - o * axis_len);
+        const int* bd = bands + (o / outer_per_group) * (size_t)n_bands * 2;
+        if (in_bands(bd, n_bands, ax)) x[i] = T(0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// adaptive gradient clipping + clipvalue, one wave per output unit (row)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_agc_clip(const iris_agc_row* rows, size_t n_rows, float clip_factor,
+                                                  float eps, float clipvalue) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * 4;
+    for (size_t r = wave; r < n_rows; r += n_waves) {
+        const float* p = rows[r].param;
+        float* g = rows[r].grad;
+        const long len = rows[r].len;
+        float sp = 0.f, sg = 0.f;
+        const bool vec = ((len & 3) == 0) && (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g)) & 15) == 0);
+        if (vec) {
+            for (long i = 4 * lane; i < len; i += 4 * kWave) {
+                const float4 a = *reinterpret_cast<const float4*>(p + i);
+                const float4 b = *reinterpret_cast<const float4*>(g + i);
+                sp += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+                sg += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+            }
+        } else {
+            for (long i = lane; i < len; i += kWave) {
+                sp += p[i] * p[i];
+                sg += g[i] * g[i];
+            }
+        }
+        const float p_norm = sqrtf(wave_sum(sp)), g_norm = sqrtf(wave_sum(sg));
+        const float max_norm = fmaxf(p_norm, eps) * clip_factor;
+        const float scale = g_norm < max_norm ? 1.0f : max_norm / fmaxf(g_norm, 1e-6f);
+        const bool clamp = clipvalue > 0.f;
+        if (scale == 1.0f && !clamp) continue;  // wave-uniform
+        if (vec) {
+            for (long i = 4 * lane; i < len; i += 4 * kWave) {
+                float4 b = *reinterpret_cast<float4*>(g + i);
+                b.x *= scale; b.y *= scale; b.z *= scale; b.w *= scale;
+                if (clamp) {
+                    b.x = fminf(fmaxf(b.x, -clipvalue), clipvalue);
+                    b.y = fminf(fmaxf(b.y, -clipvalue), clipvalue);
+                    b.z = fminf(fmaxf(b.z, -clipvalue), clipvalue);
+                    b.w = fminf(fmaxf(b.w, -clipvalue), clipvalue);
+                }
+                *reinterpret_cast<float4*>(g + i) = b;
+            }
+        } else {
+            for (long i = lane; i < len; i += kWave) {
+                float v = g[i] * scale;
+                if (clamp) v = fminf(fmaxf(v, -clipvalue), clipvalue);
+                g[i] = v;
+            }
+        }
+    }
+}

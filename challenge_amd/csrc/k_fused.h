@@ -1,0 +1,536 @@
+// k_fused.h -- K1, the fused hot path: waveform -> mel magnitudes in one kernel.
+// Part of the single translation unit iris_frontend.hip.
+#pragma once
+// ---------------------------------------------------------------------------
+// K1: fused wav -> mel magnitudes (+ per-wave min/max partials)
+//   work unit = chunk: consecutive frames of one clip, all C channels
+//   grid      = min(#chunks, #CUs) workgroups of 12 waves (n_fft 2048: 8) looping over chunks
+//   per wave  = one frame at a time, claimed from the chunk's LDS queue:
+//                 LDS-DMA (global_load_lds) of the NEXT frame into the wave's landing
+//                 buffer -- no VGPRs, reflect padding resolved in the DMA's per-lane
+//                 source address -- while the current frame is windowed, transformed
+//                 (registers + private padded LDS exchanges), untangled, |X| written
+//                 to LDS and reduced over the banded mel weights; lane m stores band m of
+//                 the frame straight to out[b, m, t, c] (the L2 merges the 4-byte stores)
+//   LDS       = landing buffers [waves][N floats] | exchange buffers [waves] | frame queue |
+//               mel table (mode 1); after the prologue the waves share nothing but the queue
+//   MELMODE 0 = band weights in registers (M <= 64, band length <= 16): each lane reads
+//               a 16-byte-aligned window of 20 magnitudes with 5 ds_read_b128
+//           1 = band table staged in LDS, 2 = band table read from global (L1/L2)
+//   HI        = some band needs bins above n_fft/4 (both halves of the untangle)
+//   BANDS     = SpecAugment / filter bands present
+// ---------------------------------------------------------------------------
+// waves per workgroup: one workgroup per CU holding every wave of the CU, so that all waves are
+// of one age class for the issue arbiter (which favours older waves) and share one frame queue
+// workgroups per CU (= waves per SIMD): 3 -> <= 168 VGPRs; n_fft 2048 keeps 16 points per
+// lane and needs the 256-VGPR budget of 2
+constexpr int fused_occ(int log2n) { return 1; }
+// waves per workgroup: 3 per SIMD with one frame per wave (168 VGPRs); 2 per SIMD when a wave keeps
+// two frames in flight or at n_fft 2048 (256 VGPRs)
+constexpr int fused_waves(int log2n, int streams = 1) {
+    return (log2n >= 11 || streams > 1) ? 8 : (log2n <= 9 ? 16 : 12);
+}
+
+struct FusedArgs {
+    const float* wav;    // [B, C, L]
+    float* out;          // [B, M, T, C]
+    float* partial;      // [B, chunks_per_clip * waves, 2] (min, max) per wave of each chunk
+    const float* sumsq;  // nullable [B, n_sq] partial sums of squares (normalize)
+    int n_sq;
+    const float* consts;  // per-lane constant block (ConstLayout)
+    const int* band_lo;   // [M] first bin read by band m (clamped so lo + rows <= limit)
+    const float* wband;   // [rows][M], 0.5 * W[lo + i][m]
+    int rows;
+    const int* t_bands;  // nullable [B, n_tb, 2]
+    int n_tb;
+    const int* f_bands;  // nullable [B, n_fb, 2]
+    int n_fb;
+    int B, C, L, T, hop, M;
+    int chunk_frames, chunks_per_clip, n_chunks;
+    int chunk_base, chunk_rem;  // T = chunks_per_clip * chunk_base + chunk_rem; the first chunk_rem chunks take one more
+    int ablate;  // diagnostic only (IRIS_ABLATE): skip phases, results are wrong when non-zero
+    unsigned long long* dbg;  // diagnostic only: [4] shader-clock / 100 MHz stamps of workgroup 0
+};
+
+// LDS-DMA of one frame.  Inline asm on purpose: hipcc drains an LDS-DMA it knows about
+// (s_waitcnt vmcnt(0)) before the next DS access that might alias it, which would
+// serialise the prefetch with the FFT.  Hidden from the compiler the DMA stays in flight
+// across the whole frame computation; the kernel waits for it by hand right before it
+// reads the frame buffer.  M0 = wave-uniform LDS byte address (saved / restored inside
+// the statement); the instruction offset applies to the global and the LDS address alike.
+//   dma_frame_x4: frame interior and 16-byte aligned -> N/256 pieces of 16 B per lane,
+//                 source = SGPR base + lane*16 + imm
+//   dma_frame_x1: any frame -> N/64 pieces of 4 B per lane with per-lane source
+//                 addresses (reflect padding costs nothing extra)
+template <int LOG2N>
+__device__ __forceinline__ void dma_frame_x4(const float* src /*uniform*/, unsigned fbuf_lds, unsigned lane16) {
+    static_assert(LOG2N >= 8 && LOG2N <= 11, "");
+    unsigned keep;
+    if constexpr (LOG2N == 8)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src), "s"(fbuf_lds) : "memory");
+    else if constexpr (LOG2N == 9)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src), "s"(fbuf_lds) : "memory");
+    else if constexpr (LOG2N == 10)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src), "s"(fbuf_lds) : "memory");
+    else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src), "s"(fbuf_lds) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src + 1024), "s"(fbuf_lds + 4096) : "memory");
+    }
+}
+
+__device__ __forceinline__ void glds4(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int LOG2N>
+__device__ __forceinline__ void dma_frame_x1(const float* clip, int len, int start, unsigned fbuf_lds, int lane) {
+    constexpr int N = 1 << LOG2N;
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < N / 64; ++i)
+        glds4(clip + reflect_idx(start + 64 * i + lane, len), __builtin_amdgcn_readfirstlane(fbuf_lds + 256 * i));
+}
+
+template <int LOG2N>
+__device__ __forceinline__ void dma_frame(const float* clip, int len, int start, unsigned fbuf_lds, int lane) {
+    constexpr int N = 1 << LOG2N;
+    // clip/start are wave-uniform by construction; make that provable for the "s" operands
+    const uint64_t u = reinterpret_cast<uint64_t>(clip + start);
+    const uint32_t ulo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t uhi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    const float* src = reinterpret_cast<const float*>(((uint64_t)uhi << 32) | ulo);
+    start = __builtin_amdgcn_readfirstlane(start);
+    if ((start >= 0) && (start + N <= len) && ((ulo & 15u) == 0))
+        dma_frame_x4<LOG2N>(src, fbuf_lds, (unsigned)lane * 16u);
+    else
+        dma_frame_x1<LOG2N>(clip, len, start, fbuf_lds, lane);
+}
+
+template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S>
+__global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) / 4) void k_wav_to_mel(const FusedArgs a) {
+    constexpr int kFusedWaves = fused_waves(LOG2N, S);
+    constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // the wave index is uniform: keep it (and everything derived from it) in SGPRs
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // LDS: [waves][S] landing buffers (LDS-DMA targets, N floats) | [waves][S] exchange buffers
+    // (also |X|) | frame queue | MELMODE 1 tables.  Nothing is shared between waves but the queue.
+    constexpr int kXBufBytes = (lds_padded(NC, FftCfg<LOG2N>::PMMAX) * 8 + 15) & ~15;
+    constexpr int kLandBytes = kFusedWaves * S * N * 4;
+    const float* fbuf[S];
+    unsigned fbuf_lds[S];
+    cf* lds[S];
+    float* magbuf[S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+        char* land = smem + (wv * S + st) * (N * 4);
+        char* xb = smem + kLandBytes + (wv * S + st) * kXBufBytes;
+        fbuf[st] = reinterpret_cast<const float*>(land);
+        fbuf_lds[st] = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)land);
+        lds[st] = reinterpret_cast<cf*>(xb);
+        magbuf[st] = reinterpret_cast<float*>(xb);
+    }
+    char* xbuf0 = smem + kLandBytes;
+    constexpr int kXAllBytes = kFusedWaves * S * kXBufBytes, kStageBytes = ConstLayout<LOG2N>::NV4 * kWave * 16;
+    int* next_frame = reinterpret_cast<int*>(xbuf0 + (kXAllBytes > kStageBytes ? kXAllBytes : kStageBytes));  // [4]
+    float* wtab = reinterpret_cast<float*>(next_frame + 4);  // MELMODE 1: [rows][M] then int lo[M]
+    int* lotab = reinterpret_cast<int*>(wtab + a.rows * a.M);
+    // BANDS: bit tl of this bitmap = frame t0 + tl of the current chunk lies in a time band
+    unsigned* tbits = reinterpret_cast<unsigned*>(MELMODE == 1 ? reinterpret_cast<float*>(lotab + a.M) : wtab);
+    // MELMODE 1: the chunk's band table, with the clip's frequency bands folded in (all threads)
+    auto build_wtab = [&](const int* fbc) {
+        for (int i = threadIdx.x; i < a.M; i += blockDim.x) lotab[i] = a.band_lo[i];
+        for (int i = threadIdx.x; i < a.rows * a.M; i += blockDim.x) {
+            float w = a.wband[i];
+            if (BANDS && fbc) {
+                const int r = i / a.M, m = i - r * a.M;
+                if (in_bands(fbc, a.n_fb, a.band_lo[m] + r)) w = 0.f;
+            }
+            wtab[i] = w;
+        }
+    };
+    auto build_tbits = [&](const int* tb, int t0, int nt) {  // all threads; publish with a barrier
+        for (int base = 0; base < nt; base += blockDim.x) {
+            const int i = base + threadIdx.x;
+            const unsigned long long m = __ballot(i < nt && in_bands(tb, a.n_tb, t0 + i));
+            if (lane == 0) {
+                tbits[(base >> 5) + 2 * wv] = (unsigned)m;
+                tbits[(base >> 5) + 2 * wv + 1] = (unsigned)(m >> 32);
+            }
+        }
+    };
+
+    unsigned long long real_entry = 0;
+    if ABL(512) real_entry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // diag: cycles per phase
+    (void)ph;
+    (void)ph_t;
+    unsigned long long stamp0 = 0, real0 = 0;
+
+    cf tw[NTW], post[P / 2], win[P];  // per-lane constants, resident for the whole kernel
+    float wreg[kMelRegs];
+    int lo0 = 0;
+
+    const int g0 = xcd_remap(blockIdx.x, gridDim.x);
+    // chunk -> clip b, first frame t0, frame count nt (balanced split: sizes differ by at most one)
+    auto chunk_clip = [&](int chunk) { return chunk / a.chunks_per_clip; };
+    auto chunk_t0 = [&](int chunk, int b) {
+        const int ci = chunk - b * a.chunks_per_clip;
+        return ci * a.chunk_base + min(ci, a.chunk_rem);
+    };
+    auto chunk_nt = [&](int chunk, int b) {
+        return a.chunk_base + ((chunk - b * a.chunks_per_clip) < a.chunk_rem ? 1 : 0);
+    };
+    constexpr bool DIRECT = IRIS_DIRECT_LOAD && LOG2N <= 10;  // n_fft 2048 (16 points per lane) has no registers to spare
+    cf x[S][P];
+    // Fetch of wave-frames ff[] (f = tl * C + c) of a chunk: straight into the x registers
+    // (IRIS_DIRECT_LOAD), or by LDS-DMA into this wave's landing buffers
+    auto issue_dma = [&](const int (&ff)[S], int b, int t0, int nwf) {
+        const float* clip0 = a.wav + (size_t)b * a.C * a.L;
+#pragma unroll
+        for (int st = 0; st < S; ++st)
+            if (ff[st] < nwf && !ABL(8)) {
+                const int tl = (a.C == 1) ? ff[st] : ff[st] / a.C, c = ff[st] - tl * a.C;
+                if constexpr (DIRECT)
+                    load_frame<LOG2N>(x[st], clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, lane);
+                else
+                    dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
+            }
+    };
+    int f[S], fn[S];  // frames in registers / frames in flight to the landing buffers
+    if (g0 < a.n_chunks) {  // first frames of the first chunk: in flight while the constants are fetched
+        const int b = chunk_clip(g0);
+#pragma unroll
+        for (int st = 0; st < S; ++st) f[st] = wv * S + st;
+        issue_dma(f, b, chunk_t0(g0, b), chunk_nt(g0, b) * a.C);
+    }
+    {
+        // The constant block is the same for every wave: fetch it from global once per
+        // workgroup, through the exchange buffers (idle until the first FFT).
+        float4* stage = reinterpret_cast<float4*>(xbuf0);
+        const float4* g = reinterpret_cast<const float4*>(a.consts);
+        for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
+        if (threadIdx.x == 0) *next_frame = 2 * kFusedWaves * S;
+        if constexpr (BANDS) {
+            if (a.t_bands && g0 < a.n_chunks) {
+                const int b = chunk_clip(g0);
+                build_tbits(a.t_bands + (size_t)b * a.n_tb * 2, chunk_t0(g0, b), chunk_nt(g0, b));
+            }
+        }
+        __syncthreads();
+        load_consts<LOG2N>(reinterpret_cast<const float*>(stage), lane, tw, post, win, wreg, lo0);
+        if constexpr (MELMODE == 1) {
+            const int* fbc = nullptr;
+            if constexpr (BANDS) {
+                if (a.f_bands && g0 < a.n_chunks) fbc = a.f_bands + (size_t)chunk_clip(g0) * a.n_fb * 2;
+            }
+            build_wtab(fbc);
+        }
+        __syncthreads();
+        if ABL(512) {
+            stamp0 = __builtin_amdgcn_s_memtime();
+            real0 = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+    for (int chunk = g0; chunk < a.n_chunks; chunk += gridDim.x) {
+        PH_BEGIN();
+        const int b = chunk_clip(chunk);
+        const int t0 = chunk_t0(chunk, b), nt = chunk_nt(chunk, b);
+        const int* tb = nullptr;
+        const int* fb = nullptr;
+        if constexpr (BANDS) {
+            tb = a.t_bands ? a.t_bands + (size_t)b * a.n_tb * 2 : nullptr;
+            fb = a.f_bands ? a.f_bands + (size_t)b * a.n_fb * 2 : nullptr;
+        }
+        const int nwf = nt * a.C;  // wave-frames in this chunk: f = tl * C + c
+
+        // Each wave keeps S frames in flight ("streams").  Frames are claimed S at a time from
+        // an LDS counter (waves that run ahead take more: the issue arbiter favours older
+        // waves, a static split leaves the younger ones a tail).  All cursor state is
+        // wave-uniform (SGPRs).  The loop is software-pipelined: while frame i is in its mel
+        // phase (its samples are no longer needed in registers) the wave already reads frame
+        // i+1 from its landing buffer and claims frame i+2, whose DMA is issued once those reads
+        // have returned - neither the LDS round trip of the frame read nor the queue atomic
+        // sits on the critical path.
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            f[st] = wv * S + st;
+            fn[st] = (kFusedWaves + wv) * S + st;  // second round is static too: the queue starts at 2 * waves * S
+        }
+        if (chunk != g0) issue_dma(f, b, t0, nwf);
+        bool mbit[S];             // the frames in f[] lie in a time band (wave-uniform)
+#pragma unroll
+        for (int st = 0; st < S; ++st) mbit[st] = false;
+        if constexpr (BANDS) {
+            // Frequency bands zero |X| over bin ranges, i.e. they remove those bins from every mel
+            // band: fold them into this chunk's band weights once (register weights here, the
+            // LDS table where the chunk starts) instead of touching the magnitudes of every frame.
+            if constexpr (MELMODE == 0) {
+                if (fb) {
+                    if (chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);  // pristine weights (not hoisted)
+                    for (int i = 0; i < a.n_fb; ++i) {  // band bounds are wave-uniform (scalar loads)
+                        const int off = fb[2 * i] - lo0, end = off + fb[2 * i + 1];
+#pragma unroll
+                        for (int r = 0; r < kMelRegs; ++r)
+                            if (r >= off && r < end) wreg[r] = 0.f;
+                    }
+                }
+            }
+            if (tb) {
+#pragma unroll
+                for (int st = 0; st < S; ++st) {
+                    const int tl = min((a.C == 1) ? f[st] : f[st] / a.C, nt - 1);
+                    mbit[st] = (__builtin_amdgcn_readfirstlane(tbits[tl >> 5]) >> (tl & 31)) & 1u;
+                }
+            }
+        }
+
+        float scale = 1.0f;  // normalize: |X| is linear in the waveform, so 1 / (10 rms) scales the mel
+        if (a.sumsq != nullptr) {
+            float sq = 0.f;
+            const float* ssq = opaque(a.sumsq) + (size_t)b * a.n_sq;
+            int l0 = lane;
+            asm volatile("" : "+v"(l0));  // keep the (rarely used) per-lane address out of the loop's registers
+            for (int i = l0; i < a.n_sq; i += kWave) sq += ssq[i];
+            sq = wave_sum(sq);
+            scale = 1.0f / (sqrtf(sq / ((float)a.C * (float)a.L)) * 10.0f);
+        }
+
+        // Output: lane m owns mel band m (+64, ...); a frame's M values go straight to
+        // out[b, m, t, c] - 4-byte stores one row pitch apart, merged into full lines by the L2
+        // (the whole output is a few MB).  No LDS tile, no workgroup barrier, no write-out phase:
+        // after the prologue the waves only share the frame queue.
+        // address = (uniform) out + ((b M T + t0) C + f) * 4  +  (per lane) m * T * C * 4
+        const unsigned rowpitch_b = (unsigned)a.T * (unsigned)a.C * 4u;
+        float* const chunk_out = a.out + ((size_t)b * a.M * a.T + t0) * a.C;
+        auto store_band = [&](int fidx, unsigned off, float v) {
+            if (!ABL(16))
+                asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(chunk_out + fidx) : "memory");
+        };
+        float mn = INFINITY, mx = -INFINITY;
+
+        auto read_frames = [&]() {  // landing buffers -> registers (asynchronous: lgkmcnt)
+#pragma unroll
+            for (int st = 0; st < S; ++st) {
+                const cf* fb2 = reinterpret_cast<const cf*>(fbuf[st]) + lane;
+#pragma unroll
+                for (int q = 0; q < P; ++q) x[st][q] = fb2[kWave * q];
+            }
+        };
+        if constexpr (!DIRECT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_frames();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_dma(fn, b, t0, nwf);
+        }
+        PH_MARK(8);
+        while (f[0] < nwf) {
+            PH_BEGIN();
+            int fcur[S];
+            bool live[S];  // stream holds a real frame (otherwise its results are dropped)
+#pragma unroll
+            for (int st = 0; st < S; ++st) {
+                fcur[st] = f[st];
+                live[st] = f[st] < nwf;
+            }
+            const bool more = fn[0] < nwf;  // wave-uniform
+            int claimed = 0;
+            unsigned mword[S];  // bitmap words of the next frames (LDS reads in flight with the rest)
+            // Prefetch into the (by then dead) x registers - straight from global, or from the
+            // landing buffers (their DMA was issued a whole FFT ago) -, claim the frames after
+            // these and fetch the time-band flags of the next ones.
+            auto prefetch = [&]() {
+                if (more) {
+                    if constexpr (DIRECT) {
+                        issue_dma(fn, b, t0, nwf);
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        read_frames();
+                    }
+                    if (lane == 0) claimed = atomicAdd(next_frame, S);
+                }
+#pragma unroll
+                for (int st = 0; st < S; ++st) mword[st] = 0;
+                if constexpr (BANDS) {
+                    if (tb && more) {
+#pragma unroll
+                        for (int st = 0; st < S; ++st)
+                            mword[st] = tbits[min((a.C == 1) ? fn[st] : fn[st] / a.C, nt - 1) >> 5];
+                    }
+                }
+            };
+            // The frame reads, the claim and the flags have returned: rotate the frame cursors.
+            auto advance = [&]() {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int st = 0; st < S; ++st) {
+                    if constexpr (BANDS) {
+                        const int tl = min((a.C == 1) ? fn[st] : fn[st] / a.C, nt - 1);
+                        mbit[st] = (__builtin_amdgcn_readfirstlane(mword[st]) >> (tl & 31)) & 1u;
+                    }
+                    f[st] = fn[st];
+                }
+                if (more) {
+                    claimed = __builtin_amdgcn_readfirstlane(claimed);
+#pragma unroll
+                    for (int st = 0; st < S; ++st) fn[st] = claimed + st;
+                    if constexpr (!DIRECT) issue_dma(fn, b, t0, nwf);
+                }
+            };
+            bool masked[S];
+#pragma unroll
+            for (int st = 0; st < S; ++st) masked[st] = false;
+            if constexpr (BANDS) {
+                bool all_masked = true;
+#pragma unroll
+                for (int st = 0; st < S; ++st) {
+                    masked[st] = live[st] && mbit[st];
+                    all_masked = all_masked && (masked[st] || !live[st]);
+                }
+                if (all_masked) {  // wave-uniform: nothing to transform, the frames are all-zero columns
+                    prefetch();
+#pragma unroll
+                    for (int st = 0; st < S; ++st)
+                        if (live[st])
+                            for (int m = lane; m < a.M; m += kWave) store_band(fcur[st], (unsigned)m * rowpitch_b, 0.f);
+                    mn = fminf(mn, 0.f);
+                    mx = fmaxf(mx, 0.f);
+                    advance();
+                    continue;
+                }
+            }
+            if constexpr (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the frames (and older stores)
+            PH_MARK(0);
+#pragma unroll
+            for (int st = 0; st < S; ++st)
+#pragma unroll
+                for (int q = 0; q < P; ++q) x[st][q] *= win[q];
+            if (!ABL(1)) fft_frames<LOG2N, S>(x, tw, lds, lane);
+            PH_MARK(3);
+            // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)
+            untangle_mag<LOG2N, HI, S>(x, post, lds, magbuf, lane);
+            wave_sync_lds();
+            PH_MARK(4);
+            prefetch();
+            if constexpr (BANDS && MELMODE == 2) {  // the global table is shared: zero the magnitudes instead
+                if (fb) {
+#pragma unroll
+                    for (int st = 0; st < S; ++st)
+                        for (int i = 0; i < a.n_fb; ++i) {
+                            const int off = fb[2 * i], end = min(off + fb[2 * i + 1], NC + 1);
+                            for (int k = off + lane; k < end; k += kWave) magbuf[st][k] = 0.f;
+                        }
+                    wave_sync_lds();
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < S; ++st) {
+                const float keep = masked[st] ? 0.f : scale;
+                if constexpr (MELMODE == 0) {
+                    const float4* mag4 = reinterpret_cast<const float4*>(magbuf[st] + lo0);  // lo0 % 4 == 0
+                    // packed FMAs on two independent accumulators (a dependent packed op costs
+                    // a wait state)
+                    cf acc2 = mk(0.f, 0.f), acc3 = mk(0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < kMelRegs / 4; ++i) {
+                        const float4 m4 = mag4[i];
+                        acc2 = __builtin_elementwise_fma(mk(wreg[4 * i + 0], wreg[4 * i + 1]), mk(m4.x, m4.y), acc2);
+                        acc3 = __builtin_elementwise_fma(mk(wreg[4 * i + 2], wreg[4 * i + 3]), mk(m4.z, m4.w), acc3);
+                    }
+                    acc2 += acc3;
+                    const float acc = acc2.x + acc2.y;
+                    if (live[st] && lane < a.M) {
+                        const float v = acc * keep;
+                        store_band(fcur[st], __umul24((unsigned)lane, rowpitch_b), v);  // host checks rowpitch < 2^24
+                        mn = fminf(mn, v);
+                        mx = fmaxf(mx, v);
+                    }
+                } else {
+                    if (live[st]) {
+                        for (int m = lane; m < a.M; m += kWave) {
+                            float acc = 0.f;
+                            if constexpr (MELMODE == 1) {
+                                const int lo = lotab[m];
+                                for (int i = 0; i < a.rows; ++i) acc = fmaf(wtab[i * a.M + m], magbuf[st][lo + i], acc);
+                            } else {
+                                const int lo = a.band_lo[m];
+                                for (int i = 0; i < a.rows; ++i)
+                                    acc = fmaf(a.wband[i * a.M + m], magbuf[st][lo + i], acc);
+                            }
+                            const float v = acc * keep;
+                            store_band(fcur[st], (unsigned)m * rowpitch_b, v);
+                            mn = fminf(mn, v);
+                            mx = fmaxf(mx, v);
+                        }
+                    }
+                }
+            }
+            wave_sync_lds();
+            PH_MARK(5);
+            advance();
+            PH_MARK(2);
+            if ABL(4096) ph[7] += 1;
+        }
+        PH_BEGIN();
+        // every wave leaves its own (min, max) partial for k_minmax_log_apply
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        if (lane == 0) {
+            a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 0] = mn;
+            a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 1] = mx;
+        }
+        if (chunk + (int)gridDim.x < a.n_chunks) {  // another chunk follows: restart the queue
+            __syncthreads();
+            if (threadIdx.x == 0) *next_frame = 2 * kFusedWaves * S;
+            if constexpr (BANDS) {
+                const int nc = chunk + (int)gridDim.x, nb = chunk_clip(nc);
+                if (a.t_bands) build_tbits(a.t_bands + (size_t)nb * a.n_tb * 2, chunk_t0(nc, nb), chunk_nt(nc, nb));
+                if constexpr (MELMODE == 1) {
+                    if (a.f_bands) build_wtab(a.f_bands + (size_t)nb * a.n_fb * 2);
+                }
+            }
+            __syncthreads();
+        }
+        PH_MARK(10);
+    }
+    if (ABL(4096) && lane == 0 && a.dbg && blockIdx.x < 4096) {
+        PH_MARK(11);  // since the last mark: loop exit to kernel end
+        for (int i = 0; i < 16; ++i) a.dbg[kDbgPhase0 + ((size_t)blockIdx.x * 16 + wv) * 16 + i] = ph[i];
+    }
+    if (ABL(512) && threadIdx.x == 0 && a.dbg) {
+        if (blockIdx.x == 0) {
+            a.dbg[0] = __builtin_amdgcn_s_memtime() - stamp0;
+            a.dbg[1] = __builtin_amdgcn_s_memrealtime() - real0;
+        }
+        a.dbg[4 + 3 * blockIdx.x + 0] = real_entry;
+        a.dbg[4 + 3 * blockIdx.x + 1] = real0;
+        a.dbg[4 + 3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    }
+}

@@ -1,0 +1,134 @@
+// k_mix.h -- batched sample synthesis (merge_complex_specs) kernels and entry point.
+// Part of the single translation unit iris_frontend.hip.
+#pragma once
+// ---------------------------------------------------------------------------
+// batched sample synthesis (merge_complex_specs, pipeline.py:6-110)
+// ---------------------------------------------------------------------------
+// frame t of the output -> frame of the (virtually zero-padded) source, or -1 inside the padding
+__device__ __forceinline__ int mix_frame(const iris_mix_src& s, int t) {
+    const int fr = s.off + t - s.pad;
+    return (fr >= 0 && fr < s.T) ? fr : -1;
+}
+
+// active[s][t] = 1 when max over (freq, chan2) of voice frame t is > 0 (pipeline.py:57); one thread
+// per output frame walks the bins (loads coalesced along t)
+__global__ __launch_bounds__(256) void k_mix_active(const iris_mix_src* srcs, int n_bins, int n_frame, int chan2,
+                                                    float* active) {
+    const iris_mix_src s = srcs[blockIdx.y];
+    if (s.kind != 1) return;  // uniform
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_frame) return;
+    const int fr = mix_frame(s, t);
+    float mx = -INFINITY;
+    if (fr >= 0) {
+        const float* p = s.src + (size_t)fr * chan2;
+        for (int f = 0; f < n_bins; ++f, p += (size_t)s.T * chan2)
+            for (int c = 0; c < chan2; ++c) mx = fmaxf(mx, p[c]);
+    }
+    active[(size_t)blockIdx.y * n_frame + t] = (fr >= 0 && mx > 0.f) ? 1.f : 0.f;
+}
+
+// One block per sample: voices are accepted in slot order unless their labels would overlap the
+// labels accepted so far (pipeline.py:72-84); writes the sample's label planes and one flag per voice.
+__global__ __launch_bounds__(256) void k_mix_labels(const iris_mix_src* srcs, const int32_t* first,
+                                                    const float* label_vecs, const float* active, float* flags,
+                                                    float* labels, int n_frame, int max_voices, int n_classes) {
+    extern __shared__ float lsum[];  // [n_frame][n_classes] labels accepted so far, summed over voices
+    const int b = blockIdx.x, plane = n_frame * n_classes;
+    float* lab = labels + (size_t)b * max_voices * plane;
+    for (int i = threadIdx.x; i < max_voices * plane; i += blockDim.x) lab[i] = 0.f;
+    for (int i = threadIdx.x; i < plane; i += blockDim.x) lsum[i] = 0.f;
+    __syncthreads();
+    for (int si = first[b]; si < first[b + 1]; ++si) {
+        const iris_mix_src s = srcs[si];
+        if (s.kind != 1) continue;  // uniform
+        const float* lv = label_vecs + (size_t)s.label_row * n_classes;
+        const float* act = active + (size_t)si * n_frame;
+        int over = 0;
+        for (int i = threadIdx.x; i < plane; i += blockDim.x) {
+            const int t = i / n_classes, c = i - t * n_classes;
+            over |= (lsum[i] + lv[c] * act[t]) >= 2.f;
+        }
+        over = __syncthreads_or(over);
+        if (threadIdx.x == 0) flags[si] = over ? 0.f : 1.f;
+        if (!over && s.slot >= 0 && s.slot < max_voices) {
+            for (int i = threadIdx.x; i < plane; i += blockDim.x) {
+                const int t = i / n_classes, c = i - t * n_classes;
+                const float l = lv[c] * act[t];
+                lsum[i] += l;
+                lab[(size_t)s.slot * plane + i] = l;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// spec_out[b, f, t, :] = background + accepted voices + noises, added in table order with
+// separately rounded multiply and add (no FMA contraction: equals the op-by-op reference)
+template <int C2>
+__global__ __launch_bounds__(256) void k_mix_sum(const iris_mix_src* srcs, const int32_t* first, const float* flags,
+                                                 float* out, int n_bins, int n_frame) {
+#pragma clang fp contract(off)  // gain * x is rounded before it is added, as in the op-by-op reference
+    typedef float vecT __attribute__((ext_vector_type(C2)));
+    const int b = blockIdx.z, f = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_frame) return;
+    vecT acc = vecT(0.f);
+    for (int si = first[b]; si < first[b + 1]; ++si) {
+        const iris_mix_src s = srcs[si];  // uniform
+        if (s.kind == 0) {
+            const int fr = (s.off + t) % s.T;
+            acc = *reinterpret_cast<const vecT*>(s.src + ((size_t)f * s.T + fr) * C2);
+            continue;
+        }
+        const float keep = s.kind == 1 ? flags[si] : 1.f;
+        const int fr = mix_frame(s, t);
+        if (fr < 0 || keep == 0.f) continue;  // adds exactly zero
+        const vecT v = *reinterpret_cast<const vecT*>(s.src + ((size_t)f * s.T + fr) * C2);
+#pragma unroll
+        for (int c = 0; c < C2; ++c) {
+            const float scaled = s.gain * v[c];
+            acc[c] = acc[c] + scaled;
+        }
+    }
+    *reinterpret_cast<vecT*>(out + (((size_t)b * n_bins + f) * n_frame + t) * C2) = acc;
+}
+
+extern "C" size_t iris_mix_workspace(int n_srcs, int n_frame) {
+    return (size_t)std::max(n_srcs, 0) * ((size_t)std::max(n_frame, 0) + 1);
+}
+
+extern "C" int iris_mix_specs(const iris_mix_src* srcs_dev, int n_srcs, const int32_t* first_dev,
+                              const float* label_vecs_dev, float* spec_out, float* labels_out, int batch,
+                              int n_bins, int n_frame, int chan2, int max_voices, int n_classes, float* workspace,
+                              size_t workspace_floats, void* stream) {
+    if (!srcs_dev || !first_dev || !label_vecs_dev || !spec_out || !labels_out || !workspace)
+        return fail(IRIS_E_INVALID, "iris_mix_specs: NULL argument");
+    if (batch <= 0 || n_srcs < batch || n_bins <= 0 || n_frame <= 0 || max_voices <= 0 || n_classes <= 0)
+        return fail(IRIS_E_INVALID, "iris_mix_specs: bad sizes (batch %d, %d sources, %d bins, %d frames)", batch,
+                    n_srcs, n_bins, n_frame);
+    if (chan2 != 1 && chan2 != 2 && chan2 != 4 && chan2 != 8)
+        return fail(IRIS_E_UNSUPPORTED, "iris_mix_specs: chan2 %d (1, 2, 4 or 8)", chan2);
+    if (batch > 65535 || n_bins > 65535 || n_srcs > 65535)
+        return fail(IRIS_E_UNSUPPORTED, "iris_mix_specs: batch / bins / sources above 65535");
+    if (workspace_floats < iris_mix_workspace(n_srcs, n_frame))
+        return fail(IRIS_E_CAPACITY, "iris_mix_specs: workspace %zu floats < %zu", workspace_floats,
+                    iris_mix_workspace(n_srcs, n_frame));
+    const size_t lds = (size_t)n_frame * n_classes * sizeof(float);
+    if (lds > 64 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_mix_specs: n_frame x n_classes too large for the LDS");
+    hipStream_t s = (hipStream_t)stream;
+    float* active = workspace;                           // [n_srcs][n_frame]
+    float* flags = workspace + (size_t)n_srcs * n_frame;  // [n_srcs]
+    const unsigned tblocks = (unsigned)((n_frame + 255) / 256);
+    k_mix_active<<<dim3(tblocks, n_srcs), 256, 0, s>>>(srcs_dev, n_bins, n_frame, chan2, active);
+    k_mix_labels<<<batch, 256, lds, s>>>(srcs_dev, first_dev, label_vecs_dev, active, flags, labels_out, n_frame,
+                                         max_voices, n_classes);
+    const dim3 grid(tblocks, n_bins, batch);
+    switch (chan2) {
+        case 1: k_mix_sum<1><<<grid, 256, 0, s>>>(srcs_dev, first_dev, flags, spec_out, n_bins, n_frame); break;
+        case 2: k_mix_sum<2><<<grid, 256, 0, s>>>(srcs_dev, first_dev, flags, spec_out, n_bins, n_frame); break;
+        case 4: k_mix_sum<4><<<grid, 256, 0, s>>>(srcs_dev, first_dev, flags, spec_out, n_bins, n_frame); break;
+        default: k_mix_sum<8><<<grid, 256, 0, s>>>(srcs_dev, first_dev, flags, spec_out, n_bins, n_frame); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
