@@ -37,6 +37,7 @@ SIGNATURES = {
     "iris_wav_to_logmel": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "iris_mask_apply": (_i, [_vp, _sz, _sz, _sz, _i, _vp, _i, _sz, _vp]),
     "iris_agc_clip": (_i, [_vp, _sz, _f, _f, _f, _vp]),
+    "iris_mix_frame_active": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "iris_mix_workspace": (_sz, [_i, _i]),
     "iris_mix_specs": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "iris_timing_enable": (_i, [_vp, _i]),

@@ -10,29 +10,24 @@ __device__ __forceinline__ int mix_frame(const iris_mix_src& s, int t) {
     return (fr >= 0 && fr < s.T) ? fr : -1;
 }
 
-// active[s][t] = 1 when max over (freq, chan2) of voice frame t is > 0 (pipeline.py:57); one thread
-// per output frame walks the bins (loads coalesced along t)
-__global__ __launch_bounds__(256) void k_mix_active(const iris_mix_src* srcs, int n_bins, int n_frame, int chan2,
-                                                    float* active) {
-    const iris_mix_src s = srcs[blockIdx.y];
-    if (s.kind != 1) return;  // uniform
+// active[t] = 1 when max over (freq, chan2) of frame t is > 0 (pipeline.py:57); one thread per frame
+// walks the bins (loads coalesced along t).  A property of the source: computed once per corpus.
+__global__ __launch_bounds__(256) void k_mix_frame_active(const float* src, int n_bins, int T, int chan2,
+                                                          float* active) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_frame) return;
-    const int fr = mix_frame(s, t);
+    if (t >= T) return;
     float mx = -INFINITY;
-    if (fr >= 0) {
-        const float* p = s.src + (size_t)fr * chan2;
-        for (int f = 0; f < n_bins; ++f, p += (size_t)s.T * chan2)
-            for (int c = 0; c < chan2; ++c) mx = fmaxf(mx, p[c]);
-    }
-    active[(size_t)blockIdx.y * n_frame + t] = (fr >= 0 && mx > 0.f) ? 1.f : 0.f;
+    const float* p = src + (size_t)t * chan2;
+    for (int f = 0; f < n_bins; ++f, p += (size_t)T * chan2)
+        for (int c = 0; c < chan2; ++c) mx = fmaxf(mx, p[c]);
+    active[t] = mx > 0.f ? 1.f : 0.f;
 }
 
 // One block per sample: voices are accepted in slot order unless their labels would overlap the
 // labels accepted so far (pipeline.py:72-84); writes the sample's label planes and one flag per voice.
 __global__ __launch_bounds__(256) void k_mix_labels(const iris_mix_src* srcs, const int32_t* first,
-                                                    const float* label_vecs, const float* active, float* flags,
-                                                    float* labels, int n_frame, int max_voices, int n_classes) {
+                                                    const float* label_vecs, float* flags, float* labels,
+                                                    int n_frame, int max_voices, int n_classes) {
     extern __shared__ float lsum[];  // [n_frame][n_classes] labels accepted so far, summed over voices
     const int b = blockIdx.x, plane = n_frame * n_classes;
     float* lab = labels + (size_t)b * max_voices * plane;
@@ -43,18 +38,21 @@ __global__ __launch_bounds__(256) void k_mix_labels(const iris_mix_src* srcs, co
         const iris_mix_src s = srcs[si];
         if (s.kind != 1) continue;  // uniform
         const float* lv = label_vecs + (size_t)s.label_row * n_classes;
-        const float* act = active + (size_t)si * n_frame;
+        auto act = [&](int t) {  // frame t of the output lies in the padding, or in a silent / active frame
+            const int fr = mix_frame(s, t);
+            return fr >= 0 ? s.active[fr] : 0.f;
+        };
         int over = 0;
         for (int i = threadIdx.x; i < plane; i += blockDim.x) {
             const int t = i / n_classes, c = i - t * n_classes;
-            over |= (lsum[i] + lv[c] * act[t]) >= 2.f;
+            over |= (lsum[i] + lv[c] * act(t)) >= 2.f;
         }
         over = __syncthreads_or(over);
         if (threadIdx.x == 0) flags[si] = over ? 0.f : 1.f;
         if (!over && s.slot >= 0 && s.slot < max_voices) {
             for (int i = threadIdx.x; i < plane; i += blockDim.x) {
                 const int t = i / n_classes, c = i - t * n_classes;
-                const float l = lv[c] * act[t];
+                const float l = lv[c] * act(t);
                 lsum[i] += l;
                 lab[(size_t)s.slot * plane + i] = l;
             }
@@ -93,8 +91,20 @@ __global__ __launch_bounds__(256) void k_mix_sum(const iris_mix_src* srcs, const
     *reinterpret_cast<vecT*>(out + (((size_t)b * n_bins + f) * n_frame + t) * C2) = acc;
 }
 
+extern "C" int iris_mix_frame_active(const float* src, int n_bins, int n_frames, int chan2, float* active_out,
+                                     void* stream) {
+    if (!src || !active_out) return fail(IRIS_E_INVALID, "iris_mix_frame_active: NULL argument");
+    if (n_bins <= 0 || n_frames <= 0 || chan2 <= 0)
+        return fail(IRIS_E_INVALID, "iris_mix_frame_active: bad sizes (%d bins, %d frames, %d chan2)", n_bins, n_frames,
+                    chan2);
+    k_mix_frame_active<<<(n_frames + 255) / 256, 256, 0, (hipStream_t)stream>>>(src, n_bins, n_frames, chan2, active_out);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
 extern "C" size_t iris_mix_workspace(int n_srcs, int n_frame) {
-    return (size_t)std::max(n_srcs, 0) * ((size_t)std::max(n_frame, 0) + 1);
+    (void)n_frame;
+    return (size_t)std::max(n_srcs, 0);  // one accept flag per source
 }
 
 extern "C" int iris_mix_specs(const iris_mix_src* srcs_dev, int n_srcs, const int32_t* first_dev,
@@ -116,12 +126,10 @@ extern "C" int iris_mix_specs(const iris_mix_src* srcs_dev, int n_srcs, const in
     const size_t lds = (size_t)n_frame * n_classes * sizeof(float);
     if (lds > 64 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_mix_specs: n_frame x n_classes too large for the LDS");
     hipStream_t s = (hipStream_t)stream;
-    float* active = workspace;                           // [n_srcs][n_frame]
-    float* flags = workspace + (size_t)n_srcs * n_frame;  // [n_srcs]
+    float* flags = workspace;  // [n_srcs]
     const unsigned tblocks = (unsigned)((n_frame + 255) / 256);
-    k_mix_active<<<dim3(tblocks, n_srcs), 256, 0, s>>>(srcs_dev, n_bins, n_frame, chan2, active);
-    k_mix_labels<<<batch, 256, lds, s>>>(srcs_dev, first_dev, label_vecs_dev, active, flags, labels_out, n_frame,
-                                         max_voices, n_classes);
+    k_mix_labels<<<batch, 256, lds, s>>>(srcs_dev, first_dev, label_vecs_dev, flags, labels_out, n_frame, max_voices,
+                                         n_classes);
     const dim3 grid(tblocks, n_bins, batch);
     switch (chan2) {
         case 1: k_mix_sum<1><<<grid, 256, 0, s>>>(srcs_dev, first_dev, flags, spec_out, n_bins, n_frame); break;

@@ -3,7 +3,7 @@
 The reference builds every training sample on the host, one at a time: a tf.data graph
 picks a background, up to N voices and noises and mixes them in the complex-STFT domain
 (pipeline.py:6-175).  On an MI355X every source spectrogram of the corpus fits in HBM, so
-this module keeps them resident and synthesises a whole batch with three kernel launches
+this module keeps them resident and synthesises a whole batch with two kernel launches
 (`iris_mix_specs`, include/iris_frontend.h): the host only draws the random decisions
 (`pipeline.merge_draw`, same distributions as the reference) and uploads a table of a few
 dozen bytes per source.
@@ -23,9 +23,9 @@ from . import _native as N
 from . import pipeline as _pl
 
 # mirrors iris_mix_src (include/iris_frontend.h)
-MIX_SRC = np.dtype([("src", "<u8"), ("T", "<i4"), ("pad", "<i4"), ("off", "<i4"), ("gain", "<f4"),
-                    ("kind", "<i4"), ("slot", "<i4"), ("label_row", "<i4"), ("reserved", "<i4")])
-assert MIX_SRC.itemsize == 40
+MIX_SRC = np.dtype([("src", "<u8"), ("active", "<u8"), ("T", "<i4"), ("pad", "<i4"), ("off", "<i4"),
+                    ("gain", "<f4"), ("kind", "<i4"), ("slot", "<i4"), ("label_row", "<i4"), ("reserved", "<i4")])
+assert MIX_SRC.itemsize == 48
 
 KIND_BACKGROUND, KIND_VOICE, KIND_NOISE = 0, 1, 2
 
@@ -97,6 +97,20 @@ class DeviceMixer:
                 if t.shape[0] != self.n_bins or t.shape[2] != self.chan2:
                     raise ValueError("voices / noises must share the backgrounds' freq and chan2 sizes")
         self.label_vecs = torch.from_numpy(labels).to(self.device)
+        # which frames of a voice are active (max over freq, chan2 > 0; pipeline.py:57) is a property of
+        # the source: one pass over the corpus now instead of one per use
+        self.voice_active = []
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            for v in self.voices:
+                act = torch.empty(int(v.shape[1]), device=self.device, dtype=torch.float32)
+                N.check(N.lib().iris_mix_frame_active(v.data_ptr(), self.n_bins, int(v.shape[1]), self.chan2,
+                                                      act.data_ptr(), stream), "iris_mix_frame_active")
+                self.voice_active.append(act)
+        # (pointer, frames) of every source, looked up per record when a batch's table is built
+        self._bg_rec = [(t.data_ptr(), int(t.shape[1])) for t in self.backgrounds]
+        self._v_rec = [(t.data_ptr(), a.data_ptr(), int(t.shape[1])) for t, a in zip(self.voices, self.voice_active)]
+        self._n_rec = [(t.data_ptr(), int(t.shape[1])) for t in self.noises] if self.noises is not None else []
         self._b = _Stream(len(self.backgrounds), self.rng)
         self._v = _Stream(len(self.voices), self.rng)
         self._n = _Stream(len(self.noises), self.rng) if self.noises is not None else None
@@ -110,9 +124,9 @@ class DeviceMixer:
             bg = self._b.take(1)[0]
             vs = self._v.take(self.max_voices)
             ns = self._n.take(self.max_noises) if self._n is not None else None
-            v_len = max(int(self.voices[i].shape[1]) for i in vs)       # padded_batch: longest of the group
-            n_len = max(int(self.noises[i].shape[1]) for i in ns) if ns else 0
-            d = _pl.merge_draw(int(self.backgrounds[bg].shape[1]), [v_len] * len(vs),
+            v_len = max(self._v_rec[i][2] for i in vs)       # padded_batch: longest of the group
+            n_len = max(self._n_rec[i][1] for i in ns) if ns else 0
+            d = _pl.merge_draw(self._bg_rec[bg][1], [v_len] * len(vs),
                                [n_len] * len(ns) if ns is not None else None, self.n_frame, self.min_ratio,
                                self.min_noise_ratio, self.snr, rng=self.rng)
             d.update(bg=bg, voices=vs, noises=ns, v_len=v_len, n_len=n_len)
@@ -124,25 +138,25 @@ class DeviceMixer:
         """Source table (iris_mix_src records) and the per-sample ranges for a list of draws."""
         recs, first = [], [0]
         for d in draws:
-            bg = self.backgrounds[d["bg"]]
-            recs.append((bg.data_ptr(), int(bg.shape[1]), 0, int(d["bg_offset"]), 1.0, KIND_BACKGROUND, 0, 0, 0))
+            ptr, frames = self._bg_rec[d["bg"]]
+            recs.append((ptr, 0, frames, 0, int(d["bg_offset"]), 1.0, KIND_BACKGROUND, 0, 0, 0))
             pad = self.n_frame - int(np.float32(self.min_ratio) * np.float32(d["v_len"]))
             for v in range(d["n_voices"]):
-                src = self.voices[d["voices"][v]]
-                recs.append((src.data_ptr(), int(src.shape[1]), max(pad, 0), int(d["v_offset"][v]),
-                             np.float32(d["v_gain"][v]), KIND_VOICE, v, d["voices"][v], 0))
+                ptr, act, frames = self._v_rec[d["voices"][v]]
+                recs.append((ptr, act, frames, max(pad, 0), int(d["v_offset"][v]), np.float32(d["v_gain"][v]),
+                             KIND_VOICE, v, d["voices"][v], 0))
             if d["noises"] is not None:
                 pad = self.n_frame - int(np.float32(self.min_noise_ratio) * np.float32(d["n_len"]))
                 for n in range(d["n_noises"]):
-                    src = self.noises[d["noises"][n]]
-                    recs.append((src.data_ptr(), int(src.shape[1]), max(pad, 0), int(d["n_offset"][n]),
-                                 np.float32(d["n_gain"][n]), KIND_NOISE, 0, 0, 0))
+                    ptr, frames = self._n_rec[d["noises"][n]]
+                    recs.append((ptr, 0, frames, max(pad, 0), int(d["n_offset"][n]), np.float32(d["n_gain"][n]),
+                                 KIND_NOISE, 0, 0, 0))
             first.append(len(recs))
         return np.array(recs, dtype=MIX_SRC), np.asarray(first, np.int32)
 
     def mix(self, batch: int, draws: Optional[List[dict]] = None):
         """One batch of (complex spectrogram [B, F, n_frame, 2C], labels [B, max_voices, n_frame,
-        n_classes]) - `merge_complex_specs` (pipeline.py:6-110) for every sample, three launches."""
+        n_classes]) - `merge_complex_specs` (pipeline.py:6-110) for every sample, two launches."""
         draws = self.draw(batch) if draws is None else draws
         batch = len(draws)
         table, first = self.table(draws)

@@ -217,7 +217,7 @@ def make_dataset(config, training=True, n_classes=3, sources=None):
 def make_device_dataset(config, training=True, n_classes=3, sources=None, device=None, seed=None):
     """MI355X-native `make_dataset`: same stages, same outputs (sj_train.py:74-130), but a whole
     batch at a time on the device.  The corpora stay resident in HBM; `DeviceMixer` synthesises the
-    batch in three launches (merge_complex_specs, pipeline.py:6-110); SpecAugment and `stft_filter`
+    batch in two launches (merge_complex_specs, pipeline.py:6-110); SpecAugment and `stft_filter`
     reach the mel kernel as band descriptors instead of being multiplied into the 135 MB complex
     batch (they zero time / frequency ranges, which commutes with the per-bin channel mixes and with
     the magnitude).  Yields (x [B, n_mels, n_frame, C], y) forever, like the repeated reference graph."""

@@ -211,6 +211,8 @@ int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float clip_factor
  * srcs: DEVICE table, the sources of sample b are srcs[first[b] .. first[b+1]) in
  *       the order background, voices (by slot), noises.  first: DEVICE int32 [B + 1].
  *   src    DEVICE [F, T, C2] fp32 spectrogram (time axis 1, re block | im block last)
+ *   active DEVICE [T] fp32 0/1 flags of a voice's frames from iris_mix_frame_active (kind 1;
+ *          they depend on the source only, so they are computed once per corpus, not per use)
  *   T      frames in src;  pad: zero frames virtually added on both sides (>= 0);
  *   off    crop offset in the padded (voice, noise) or tiled (background) source;
  *   gain   linear gain (ignored for the background);  kind 0 background, 1 voice, 2 noise;
@@ -222,10 +224,14 @@ int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float clip_factor
  */
 typedef struct {
     const float* src;
+    const float* active;
     int32_t T, pad, off;
     float gain;
     int32_t kind, slot, label_row, reserved;
 } iris_mix_src;
+/* active_out[t] = 1 when max over (freq, chan2) of src[:, t, :] is > 0, else 0 (pipeline.py:57) */
+int iris_mix_frame_active(const float* src, int n_bins, int n_frames, int chan2, float* active_out,
+                          void* stream);
 size_t iris_mix_workspace(int n_srcs, int n_frame);
 int iris_mix_specs(const iris_mix_src* srcs_dev, int n_srcs, const int32_t* first_dev,
                    const float* label_vecs_dev, float* spec_out, float* labels_out, int batch,
