@@ -26,9 +26,11 @@ extern "C" int iris_normalize(const float* wav, float* out, int n_rows, size_t r
     return IRIS_OK;
 }
 
+static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int* chunk_frames, int* chunks_per_clip);
+
 template <int LOG2N>
 static hipError_t launch_stft(const StftArgs& a, int grid, size_t lds, hipStream_t s) {
-    k_stft<LOG2N><<<grid, 256, lds, s>>>(a);
+    k_stft<LOG2N><<<grid, 64 * stft_waves(LOG2N), lds, s>>>(a);
     return hipGetLastError();
 }
 
@@ -45,21 +47,34 @@ extern "C" int iris_stft(iris_plan* p, const float* wav, float* spec, int batch,
     a.L = len;
     a.T = 1 + len / p->hop;
     a.hop = p->hop;
-    const int NC = p->n_fft / 2, F = NC + 1;
-    int tf = 16;
-    auto lds_of = [&](int t) { return 4 * ((wave_buf_bytes(p->log2n) + 15) & ~(size_t)15) + (size_t)F * (t * 2 * p->channels + 1) * 4; };
-    while (tf > 1 && lds_of(tf) > 64 * 1024) tf /= 2;
-    if (lds_of(tf) > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_stft: channels=%d too large", p->channels);
+    const int NC = p->n_fft / 2, F = NC + 1, waves = stft_waves(p->log2n), C2 = 2 * p->channels;
+    // tile = as many frames as the LDS left by the waves' exchange buffers holds (one workgroup per
+    // CU owns the whole 160 KiB); at least the constant block must fit (it is staged through the tile)
+    const size_t xbufs = (size_t)waves * ((wave_buf_bytes(p->log2n) + 15) & ~(size_t)15);
+    const size_t room = 160 * 1024 - 1024 - xbufs;
+    auto tile_bytes = [&](int t) { return (size_t)F * ((size_t)t * C2 + 1) * 4; };
+    int tf = 1;
+    while (tf < 256 && tile_bytes(tf + 1) <= room) ++tf;
+    if (tile_bytes(tf) > room) return fail(IRIS_E_UNSUPPORTED, "iris_stft: channels=%d too large", p->channels);
+    // a whole number of rounds of the workgroup's waves
+    const int per_round = std::max(1, waves / std::max(1, p->channels));
+    if (tf > per_round) tf -= tf % per_round;
     a.tile_frames = tf;
-    a.tiles_per_clip = (a.T + tf - 1) / tf;
-    const int grid = batch * a.tiles_per_clip;
+    int chunk_frames = 0;
+    fused_geometry(p, batch, a.T, 1, &chunk_frames, &a.chunks_per_clip);  // K1's balanced chunks, one per CU
+    a.chunk_base = a.T / a.chunks_per_clip;
+    a.chunk_rem = a.T % a.chunks_per_clip;
+    a.n_chunks = batch * a.chunks_per_clip;
+    const size_t lds = xbufs + std::max(tile_bytes(tf), (size_t)const_nv4(p->log2n) * 64 * 16);
+    if (lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_stft: %zu B of LDS", lds);
+    const int grid = std::min(a.n_chunks, p->num_cu);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     switch (p->log2n) {
-        case 11: e = launch_stft<11>(a, grid, lds_of(tf), s); break;
-        case 10: e = launch_stft<10>(a, grid, lds_of(tf), s); break;
-        case 9: e = launch_stft<9>(a, grid, lds_of(tf), s); break;
-        default: e = launch_stft<8>(a, grid, lds_of(tf), s); break;
+        case 11: e = launch_stft<11>(a, grid, lds, s); break;
+        case 10: e = launch_stft<10>(a, grid, lds, s); break;
+        case 9: e = launch_stft<9>(a, grid, lds, s); break;
+        default: e = launch_stft<8>(a, grid, lds, s); break;
     }
     HIP_TRY(e);
     return IRIS_OK;
