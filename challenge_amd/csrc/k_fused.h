@@ -232,9 +232,13 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
         issue_dma(f, b, chunk_t0(g0, b), chunk_nt(g0, b) * a.C);
     }
     {
-        // The constant block is the same for every wave: fetch it from global once per
-        // workgroup, through the exchange buffers (idle until the first FFT).
-        float4* stage = reinterpret_cast<float4*>(xbuf0);
+        // The constant block is the same for every wave: fetch it from global once per workgroup.
+        // With direct frame loads the landing area is free for it, so a wave whose constants have
+        // arrived starts transforming while the others still read theirs (the 12 x 19 KB go through
+        // one LDS pipe); with LDS-DMA frames it is staged through the exchange buffers, which need a
+        // second barrier before the first FFT may overwrite them.
+        static_assert(!DIRECT || kLandBytes >= kStageBytes, "constant block does not fit the landing area");
+        float4* stage = reinterpret_cast<float4*>(DIRECT ? smem : xbuf0);
         const float4* g = reinterpret_cast<const float4*>(a.consts);
         for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
         if (threadIdx.x == 0) *next_frame = 2 * kFusedWaves * S;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
             }
             build_wtab(fbc);
         }
-        __syncthreads();
+        if constexpr (!DIRECT || MELMODE == 1) __syncthreads();
         if ABL(512) {
             stamp0 = __builtin_amdgcn_s_memtime();
             real0 = __builtin_amdgcn_s_memrealtime();
