@@ -430,7 +430,8 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                     continue;
                 }
             }
-            if constexpr (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the frames (and older stores)
+            // (direct loads: the compiler waits for each sample register where it is first used; stores issued
+            // from inline asm only make those counted waits more conservative, never less)
             PH_MARK(0);
 #pragma unroll
             for (int st = 0; st < S; ++st)
