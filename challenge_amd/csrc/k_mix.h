@@ -10,17 +10,29 @@ __device__ __forceinline__ int mix_frame(const iris_mix_src& s, int t) {
     return (fr >= 0 && fr < s.T) ? fr : -1;
 }
 
-// active[t] = 1 when max over (freq, chan2) of frame t is > 0 (pipeline.py:57); one thread per frame
-// walks the bins (loads coalesced along t).  A property of the source: computed once per corpus.
+// active[t] = 1 when max over (freq, chan2) of frame t is > 0 (pipeline.py:57).  A property of the
+// source: computed once per corpus.  64 frames x 4 bin groups per block, blockIdx.y splits the bins
+// further; loads are coalesced along t; groups combine through LDS, blocks through an atomic max on
+// the flag's bit pattern (1.0f > 0.0f as integers; `active` is zeroed by the caller).
 __global__ __launch_bounds__(256) void k_mix_frame_active(const float* src, int n_bins, int T, int chan2,
                                                           float* active) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, fg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tx;
+    const int groups = 4 * gridDim.y, g = blockIdx.y * 4 + fg;
     float mx = -INFINITY;
-    const float* p = src + (size_t)t * chan2;
-    for (int f = 0; f < n_bins; ++f, p += (size_t)T * chan2)
-        for (int c = 0; c < chan2; ++c) mx = fmaxf(mx, p[c]);
-    active[t] = mx > 0.f ? 1.f : 0.f;
+    if (t < T) {
+        for (int f = g; f < n_bins; f += groups) {
+            const float* p = src + ((size_t)f * T + t) * chan2;
+            for (int c = 0; c < chan2; ++c) mx = fmaxf(mx, p[c]);
+        }
+    }
+    part[fg][tx] = mx;
+    __syncthreads();
+    if (fg == 0 && t < T) {
+        mx = fmaxf(fmaxf(part[0][tx], part[1][tx]), fmaxf(part[2][tx], part[3][tx]));
+        if (mx > 0.f) atomicMax(reinterpret_cast<int*>(active) + t, __float_as_int(1.0f));
+    }
 }
 
 // One block per sample: voices are accepted in slot order unless their labels would overlap the
@@ -97,7 +109,10 @@ extern "C" int iris_mix_frame_active(const float* src, int n_bins, int n_frames,
     if (n_bins <= 0 || n_frames <= 0 || chan2 <= 0)
         return fail(IRIS_E_INVALID, "iris_mix_frame_active: bad sizes (%d bins, %d frames, %d chan2)", n_bins, n_frames,
                     chan2);
-    k_mix_frame_active<<<(n_frames + 255) / 256, 256, 0, (hipStream_t)stream>>>(src, n_bins, n_frames, chan2, active_out);
+    HIP_TRY(hipMemsetAsync(active_out, 0, (size_t)n_frames * sizeof(float), (hipStream_t)stream));
+    const int ysplit = std::max(1, std::min(16, n_bins / 16));
+    k_mix_frame_active<<<dim3((n_frames + 63) / 64, ysplit), 256, 0, (hipStream_t)stream>>>(src, n_bins, n_frames, chan2,
+                                                                                          active_out);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
