@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
             if (!ABL(1)) fft_frames<LOG2N, S>(x, tw, lds, lane);
             PH_MARK(3);
             // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)
-            untangle_mag<LOG2N, HI, S>(x, post, lds, magbuf, lane);
+            if (!ABL(2)) untangle_mag<LOG2N, HI, S>(x, post, lds, magbuf, lane);
             wave_sync_lds();
             PH_MARK(4);
             prefetch();
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                     cf acc2 = mk(0.f, 0.f), acc3 = mk(0.f, 0.f);
 #pragma unroll
                     for (int i = 0; i < kMelRegs / 4; ++i) {
-                        const float4 m4 = mag4[i];
+                        const float4 m4 = ABL(4) ? make_float4(1.f, 1.f, 1.f, 1.f) : mag4[i];
                         acc2 = __builtin_elementwise_fma(mk(wreg[4 * i + 0], wreg[4 * i + 1]), mk(m4.x, m4.y), acc2);
                         acc3 = __builtin_elementwise_fma(mk(wreg[4 * i + 2], wreg[4 * i + 3]), mk(m4.z, m4.w), acc3);
                     }

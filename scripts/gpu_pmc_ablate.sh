@@ -2,7 +2,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for ab in "$@"; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcabl/$ab; rm -rf $OUT; mkdir -p $OUT
-  IRIS_LIB=$GRAFT_REPO_ROOT/challenge_amd/csrc/libiris_frontend_diag.so IRIS_ABLATE=$ab rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT -o pmc -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/log 2>&1
+  IRIS_LIB=$GRAFT_REPO_ROOT/challenge_amd/csrc/libiris_frontend_diag.so IRIS_ABLATE=$ab rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT -o pmc -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extras > $OUT/log 2>&1
   f=$(find $OUT -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$ab" <<'PY'
 import csv, sys, collections
