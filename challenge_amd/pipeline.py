@@ -60,7 +60,12 @@ def merge_draw(bg_frame: int, voice_frames, noise_frames=None, n_frame: int = 30
 
 def merge_complex_specs_apply(background, voices, labels, noises, draws, n_frame=300, n_classes=3,
                               min_ratio=2 / 3, min_noise_ratio=1 / 2, seperate_noise_voice=False):
-    """Deterministic part of merge_complex_specs (t_axis = 1)."""
+    """Deterministic part of merge_complex_specs (t_axis = 1).  Device tensors take the HIP path
+    (`iris_mix_specs`, a handful of launches instead of ~15 torch ops per voice); CPU tensors and
+    `seperate_noise_voice` use the op-by-op torch form below.  Both equal the oracle bit for bit."""
+    if background.is_cuda and not seperate_noise_voice and voices.is_cuda and (noises is None or noises.is_cuda):
+        return _merge_apply_hip(background, voices, labels, noises, draws, n_frame, n_classes, min_ratio,
+                                min_noise_ratio)
     bg_frame = background.shape[1]
     reps = (n_frame + bg_frame - 1) // bg_frame
     tiled = background.repeat(1, reps, 1)
@@ -107,6 +112,55 @@ def merge_complex_specs_apply(background, voices, labels, noises, draws, n_frame
     if seperate_noise_voice:
         label = (label, only_voice, only_noise)
     return complex_spec, label
+
+
+def _merge_apply_hip(background, voices, labels, noises, draws, n_frame, n_classes, min_ratio, min_noise_ratio):
+    """One sample through the batched synthesis kernels (include/iris_frontend.h: iris_mix_specs)."""
+    import ctypes as C
+
+    from . import _native as N
+    from .mixer import KIND_BACKGROUND, KIND_NOISE, KIND_VOICE, MIX_SRC
+    dev = background.device
+    background = background.to(torch.float32).contiguous()
+    voices = voices.to(torch.float32).contiguous()
+    label_vecs = labels.to(device=dev, dtype=torch.float32).contiguous()
+    n_bins, chan2 = int(background.shape[0]), int(background.shape[2])
+    max_voices, v_frame = int(voices.shape[0]), int(voices.shape[2])
+    lib = N.lib()
+    keep = [background, voices, label_vecs]
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        recs = [(background.data_ptr(), 0, int(background.shape[1]), 0, int(draws["bg_offset"]), 1.0,
+                 KIND_BACKGROUND, 0, 0, 0)]
+        pad = n_frame - int(np.float32(min_ratio) * np.float32(v_frame))
+        active = torch.empty((max(draws["n_voices"], 1), v_frame), device=dev, dtype=torch.float32)
+        keep.append(active)
+        for v in range(draws["n_voices"]):
+            N.check(lib.iris_mix_frame_active(voices[v].data_ptr(), n_bins, v_frame, chan2, active[v].data_ptr(), stream),
+                    "iris_mix_frame_active")
+            recs.append((voices[v].data_ptr(), active[v].data_ptr(), v_frame, max(pad, 0), int(draws["v_offset"][v]),
+                         np.float32(draws["v_gain"][v]), KIND_VOICE, v, v, 0))
+        if noises is not None and draws["n_noises"]:
+            noises = noises.to(torch.float32).contiguous()
+            keep.append(noises)
+            ns_frame = int(noises.shape[2])
+            pad = n_frame - int(np.float32(min_noise_ratio) * np.float32(ns_frame))
+            for n in range(draws["n_noises"]):
+                recs.append((noises[n].data_ptr(), 0, ns_frame, max(pad, 0), int(draws["n_offset"][n]),
+                             np.float32(draws["n_gain"][n]), KIND_NOISE, 0, 0, 0))
+        table = np.array(recs, dtype=MIX_SRC)
+        table_d = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(dev)
+        first_d = torch.tensor([0, len(recs)], dtype=torch.int32, device=dev)
+        spec = torch.empty((1, n_bins, n_frame, chan2), device=dev, dtype=torch.float32)
+        label = torch.empty((1, max_voices, n_frame, n_classes), device=dev, dtype=torch.float32)
+        ws_floats = int(lib.iris_mix_workspace(len(recs), n_frame))
+        ws = torch.empty(max(ws_floats, 1), device=dev, dtype=torch.float32)
+        N.check(lib.iris_mix_specs(table_d.data_ptr(), len(recs), first_d.data_ptr(), label_vecs.data_ptr(),
+                                   spec.data_ptr(), label.data_ptr(), 1, n_bins, n_frame, chan2, max_voices, n_classes,
+                                   ws.data_ptr(), ws_floats, stream), "iris_mix_specs")
+        for t in keep + [table_d, first_d, ws]:
+            t.record_stream(torch.cuda.current_stream(dev))
+    return spec[0], label[0]
 
 
 def merge_complex_specs(background, voices_and_labels, noises=None, n_frame=300, n_classes=3, t_axis=1,
