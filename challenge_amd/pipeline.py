@@ -193,13 +193,15 @@ def make_pipeline(backgrounds, voices, labels, noises=None, n_frame=300, max_voi
     def to_dev(x):
         return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device, non_blocking=True)
 
-    def gen_of(data):
-        g = list_to_generator(data)
+    def resident(data):
+        """Every source goes to the device once, here (the corpora fit in HBM many times over), not once
+        per sample it is drawn for."""
+        if isinstance(data, tuple):
+            return tuple(resident(d) for d in data)
+        return [to_dev(x) for x in data]
 
-        def _gen():
-            for item in g():
-                yield tuple(to_dev(v) for v in item) if isinstance(item, tuple) else to_dev(item)
-        return _gen
+    def gen_of(data):
+        return list_to_generator(resident(data))
 
     b_dataset = Dataset.from_generator(gen_of(backgrounds)).repeat().shuffle(len(backgrounds))
     v_dataset = Dataset.from_generator(gen_of((voices, labels))).repeat().shuffle(len(voices))
