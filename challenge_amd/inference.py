@@ -10,7 +10,6 @@ the reference's untouched metrics.py.
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 from . import data_utils as D

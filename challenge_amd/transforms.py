@@ -15,7 +15,7 @@ halves are what the parity tests pin (`mask_apply`, `random_shift_apply`)."""
 from __future__ import annotations
 
 from math import e, log
-from typing import Optional, Sequence
+from typing import Optional
 
 import numpy as np
 import torch
