@@ -286,3 +286,16 @@ def test_device_mixer_has_no_cpu_fallback():
     x = [np.zeros((5, 7, 2), np.float32)]
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         DeviceMixer(x, x, np.eye(3, dtype=np.float32)[:1], None, n_frame=4, device="cpu")
+
+
+def test_bench_cpu_baseline_leg_runs_without_gpu():
+    """bench.py's `cpu_baseline` object comes from the oracle / torch-CPU legs only: it must work
+    (and report sane fields) on a host with no GPU."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    wav = (np.random.default_rng(0).standard_normal((2, 1, 16000)) * 0.1).astype(np.float32)
+    r = bench.cpu_baseline(wav)
+    assert r["kind"] == "port" and r["unit"] == "audio-s/s" and r["value"] > 0 and r["cores"] >= 1
+    assert r["value"] == max(r["numpy_1thread"], r["torch_best"])
