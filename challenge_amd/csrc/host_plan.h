@@ -340,13 +340,20 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
         p->mel_mode = 0;  // 16-byte aligned register window of kMelRegs bins per band
         p->rows = kMelRegs;
     } else {
-        p->rows = std::min(std::max(p->max_band_len, 1), limit);
-        p->mel_mode = ((size_t)p->rows * n_mel + n_mel) * 4 <= 32 * 1024 ? 1 : 2;
+        // LDS table, read as float4: windows start on a multiple of 4 bins and span a multiple of 4
+        const int rows4 = (std::max(p->max_band_len, 1) + 3 + 3) & ~3;
+        if (rows4 <= limit && ((size_t)rows4 * n_mel + n_mel) * 4 <= 40 * 1024) {
+            p->mel_mode = 1;
+            p->rows = rows4;
+        } else {  // global table, any window
+            p->mel_mode = 2;
+            p->rows = std::min(std::max(p->max_band_len, 1), limit);
+        }
     }
     std::vector<int> flo(n_mel, 0);
     std::vector<float> wband((size_t)p->rows * n_mel, 0.f);
     for (int m = 0; m < n_mel; ++m) {
-        int first = p->mel_mode == 0 ? (lo[m] & ~3) : lo[m];
+        int first = p->mel_mode <= 1 ? (lo[m] & ~3) : lo[m];
         flo[m] = std::max(0, std::min(first, limit - p->rows));
         for (int i = 0; i < p->rows; ++i) {
             const int f = flo[m] + i;

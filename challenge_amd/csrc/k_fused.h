@@ -164,16 +164,17 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
     int* lotab = reinterpret_cast<int*>(wtab + a.rows * a.M);
     // BANDS: bit tl of this bitmap = frame t0 + tl of the current chunk lies in a time band
     unsigned* tbits = reinterpret_cast<unsigned*>(MELMODE == 1 ? reinterpret_cast<float*>(lotab + a.M) : wtab);
-    // MELMODE 1: the chunk's band table, with the clip's frequency bands folded in (all threads)
+    // MELMODE 1: the chunk's band table as float4 [rows / 4][M] (weights of 4 consecutive bins of a
+    // band's 16-byte aligned window), with the clip's frequency bands folded in (all threads)
     auto build_wtab = [&](const int* fbc) {
         for (int i = threadIdx.x; i < a.M; i += blockDim.x) lotab[i] = a.band_lo[i];
         for (int i = threadIdx.x; i < a.rows * a.M; i += blockDim.x) {
+            const int r = i / a.M, m = i - r * a.M;
             float w = a.wband[i];
             if (BANDS && fbc) {
-                const int r = i / a.M, m = i - r * a.M;
                 if (in_bands(fbc, a.n_fb, a.band_lo[m] + r)) w = 0.f;
             }
-            wtab[i] = w;
+            wtab[((r >> 2) * a.M + m) * 4 + (r & 3)] = w;
         }
     };
     auto build_tbits = [&](const int* tb, int t0, int nt) {  // all threads; publish with a barrier
@@ -482,8 +483,16 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                         for (int m = lane; m < a.M; m += kWave) {
                             float acc = 0.f;
                             if constexpr (MELMODE == 1) {
-                                const int lo = lotab[m];
-                                for (int i = 0; i < a.rows; ++i) acc = fmaf(wtab[i * a.M + m], magbuf[st][lo + i], acc);
+                                const float4* g4 = reinterpret_cast<const float4*>(magbuf[st] + lotab[m]);  // lo % 4 == 0
+                                const float4* w4 = reinterpret_cast<const float4*>(wtab) + m;
+                                cf acc2 = mk(0.f, 0.f), acc3 = mk(0.f, 0.f);
+                                for (int i4 = 0; i4 < a.rows / 4; ++i4) {
+                                    const float4 w = w4[i4 * a.M], g = g4[i4];
+                                    acc2 = __builtin_elementwise_fma(mk(w.x, w.y), mk(g.x, g.y), acc2);
+                                    acc3 = __builtin_elementwise_fma(mk(w.z, w.w), mk(g.z, g.w), acc3);
+                                }
+                                acc2 += acc3;
+                                acc = acc2.x + acc2.y;
                             } else {
                                 const int lo = a.band_lo[m];
                                 for (int i = 0; i < a.rows; ++i)
