@@ -482,7 +482,9 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                     if (live[st]) {
                         for (int m = lane; m < a.M; m += kWave) {
                             float acc = 0.f;
-                            if constexpr (MELMODE == 1) {
+                            if (ABL(32)) {
+                                acc = 1.f;
+                            } else if constexpr (MELMODE == 1) {
                                 const float4* g4 = reinterpret_cast<const float4*>(magbuf[st] + lotab[m]);  // lo % 4 == 0
                                 const float4* w4 = reinterpret_cast<const float4*>(wtab) + m;
                                 cf acc2 = mk(0.f, 0.f), acc3 = mk(0.f, 0.f);
