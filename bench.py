@@ -174,12 +174,20 @@ def main():
         print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1 here)", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
+    # test hook: IRIS_BENCH_SHARE_GPU=1 lets several ranks share cuda:0 over gloo, to exercise the N > 1
+    # control flow (barriers, max over ranks, DDP) on a one-GPU box; never set in a real run
+    share = os.environ.get("IRIS_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
 
     from challenge_amd.frontend import FrontendPlan, normalize
 
