@@ -173,6 +173,7 @@ static fused_kernel_t fused_kernel_mm(int mel_mode, bool hi, bool bands) {
     if constexpr (LOG2N <= 10) {
         if (mel_mode == 0)  // register weights exist only for the half-spectrum variant up to n_fft 1024
             return bands ? k_wav_to_mel<LOG2N, 0, false, true, S> : k_wav_to_mel<LOG2N, 0, false, false, S>;
+        if (mel_mode == 3) return bands ? k_wav_to_mel<LOG2N, 3, false, true, S> : k_wav_to_mel<LOG2N, 3, false, false, S>;
     }
     if (mel_mode == 1) return fused_kernel_hb<LOG2N, 1, S>(hi, bands);
     return fused_kernel_hb<LOG2N, 2, S>(hi, bands);
@@ -336,9 +337,14 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     const int limit = p->need_hi ? ((n_bins + 3) & ~3) : NC / 2;
     // (n_fft 2048 keeps 16 points per lane: no registers to spare for the weights -> table modes)
     // (the full-spectrum untangle needs the registers too: need_hi -> table modes)
+    int max_span = 0;  // widest band counted from the 4-bin boundary below its first bin
+    for (int m = 0; m < n_mel; ++m) max_span = std::max(max_span, (lo[m] & 3) + len[m]);
     if (log2n <= 10 && !p->need_hi && n_mel <= 64 && p->max_band_len + 3 <= kMelRegs && limit >= kMelRegs) {
         p->mel_mode = 0;  // 16-byte aligned register window of kMelRegs bins per band
         p->rows = kMelRegs;
+    } else if (log2n <= 10 && !p->need_hi && n_mel > 64 && n_mel <= 128 && max_span <= 8 && limit >= 8) {
+        p->mel_mode = 3;  // two bands per lane, 16-byte aligned register windows of 8 bins
+        p->rows = 8;
     } else {
         // LDS table, read as float4: windows start on a multiple of 4 bins and span a multiple of 4
         const int rows4 = (std::max(p->max_band_len, 1) + 3 + 3) & ~3;
@@ -353,7 +359,7 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     std::vector<int> flo(n_mel, 0);
     std::vector<float> wband((size_t)p->rows * n_mel, 0.f);
     for (int m = 0; m < n_mel; ++m) {
-        int first = p->mel_mode <= 1 ? (lo[m] & ~3) : lo[m];
+        int first = p->mel_mode != 2 ? (lo[m] & ~3) : lo[m];
         flo[m] = std::max(0, std::min(first, limit - p->rows));
         for (int i = 0; i < p->rows; ++i) {
             const int f = flo[m] + i;
@@ -391,6 +397,17 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
             for (int i = 0; i < p->rows; ++i) put(lane, off_wreg + i, wband[(size_t)i * n_mel + lane]);
             float bits;
             memcpy(&bits, &flo[lane], sizeof(float));
+            put(lane, off_lo, bits);
+        }
+        if (p->mel_mode == 3) {  // bands lane and lane + 64: 8 weights each, window starts packed 16 | 16
+            const int mb = lane + 64 < n_mel ? lane + 64 : -1;
+            for (int i = 0; i < 8; ++i) {
+                put(lane, off_wreg + i, wband[(size_t)i * n_mel + lane]);
+                put(lane, off_wreg + 8 + i, mb >= 0 ? wband[(size_t)i * n_mel + mb] : 0.f);
+            }
+            const int packed = flo[lane] | ((mb >= 0 ? flo[mb] : 0) << 16);
+            float bits;
+            memcpy(&bits, &packed, sizeof(float));
             put(lane, off_lo, bits);
         }
     }

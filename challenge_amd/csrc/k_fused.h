@@ -14,6 +14,8 @@
 //                 the frame straight to out[b, m, t, c] (the L2 merges the 4-byte stores)
 //   LDS       = landing buffers [waves][N floats] | exchange buffers [waves] | frame queue |
 //               mel table (mode 1); after the prologue the waves share nothing but the queue
+//   MELMODE 3 = band weights in registers, two bands per lane (64 < M <= 128, aligned band span <= 8
+//               bins - e.g. the reference's 80 mel over 257 bins): 2 x 2 ds_read_b128 per frame
 //   MELMODE 0 = band weights in registers (M <= 64, band length <= 16): each lane reads
 //               a 16-byte-aligned window of 20 magnitudes with 5 ds_read_b128
 //           1 = band table staged in LDS, 2 = band table read from global (L1/L2)
@@ -308,6 +310,20 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
                     }
                 }
             }
+            if constexpr (MELMODE == 3) {  // two windows of 8 bins: wreg[0..7] at lo0 & 0xffff, wreg[8..15] at lo0 >> 16
+                if (fb) {
+                    if (chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);
+                    for (int i = 0; i < a.n_fb; ++i) {
+                        const int offa = fb[2 * i] - (lo0 & 0xffff), enda = offa + fb[2 * i + 1];
+                        const int offb = fb[2 * i] - (lo0 >> 16), endb = offb + fb[2 * i + 1];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            if (r >= offa && r < enda) wreg[r] = 0.f;
+                            if (r >= offb && r < endb) wreg[8 + r] = 0.f;
+                        }
+                    }
+                }
+            }
             if (tb) {
 #pragma unroll
                 for (int st = 0; st < S; ++st) {
@@ -459,7 +475,31 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
 #pragma unroll
             for (int st = 0; st < S; ++st) {
                 const float keep = masked[st] ? 0.f : scale;
-                if constexpr (MELMODE == 0) {
+                if constexpr (MELMODE == 3) {
+                    // two bands per lane (m = lane and lane + 64), 8-bin windows: four reads, then the FMAs
+                    const float4* ga = reinterpret_cast<const float4*>(magbuf[st] + (lo0 & 0xffff));
+                    const float4* gb = reinterpret_cast<const float4*>(magbuf[st] + (lo0 >> 16));
+                    const float4 a0 = ga[0], a1 = ga[1], b0 = gb[0], b1 = gb[1];
+                    cf sa = mk(wreg[0], wreg[1]) * mk(a0.x, a0.y), sb = mk(wreg[8], wreg[9]) * mk(b0.x, b0.y);
+                    cf ta = mk(wreg[2], wreg[3]) * mk(a0.z, a0.w), tb2 = mk(wreg[10], wreg[11]) * mk(b0.z, b0.w);
+                    sa = __builtin_elementwise_fma(mk(wreg[4], wreg[5]), mk(a1.x, a1.y), sa);
+                    sb = __builtin_elementwise_fma(mk(wreg[12], wreg[13]), mk(b1.x, b1.y), sb);
+                    ta = __builtin_elementwise_fma(mk(wreg[6], wreg[7]), mk(a1.z, a1.w), ta);
+                    tb2 = __builtin_elementwise_fma(mk(wreg[14], wreg[15]), mk(b1.z, b1.w), tb2);
+                    sa += ta;
+                    sb += tb2;
+                    if (live[st]) {
+                        const float va = (sa.x + sa.y) * keep, vb = (sb.x + sb.y) * keep;
+                        store_band(fcur[st], __umul24((unsigned)lane, rowpitch_b), va);
+                        mn = fminf(mn, va);
+                        mx = fmaxf(mx, va);
+                        if (lane + kWave < a.M) {
+                            store_band(fcur[st], __umul24((unsigned)(lane + kWave), rowpitch_b), vb);
+                            mn = fminf(mn, vb);
+                            mx = fmaxf(mx, vb);
+                        }
+                    }
+                } else if constexpr (MELMODE == 0) {
                     const float4* mag4 = reinterpret_cast<const float4*>(magbuf[st] + lo0);  // lo0 % 4 == 0
                     // packed FMAs on two independent accumulators (a dependent packed op costs
                     // a wait state)
