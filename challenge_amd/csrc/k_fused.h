@@ -4,31 +4,35 @@
 // ---------------------------------------------------------------------------
 // K1: fused wav -> mel magnitudes (+ per-wave min/max partials)
 //   work unit = chunk: consecutive frames of one clip, all C channels
-//   grid      = min(#chunks, #CUs) workgroups of 12 waves (n_fft 2048: 8) looping over chunks
-//   per wave  = one frame at a time, claimed from the chunk's LDS queue:
-//                 LDS-DMA (global_load_lds) of the NEXT frame into the wave's landing
-//                 buffer -- no VGPRs, reflect padding resolved in the DMA's per-lane
-//                 source address -- while the current frame is windowed, transformed
-//                 (registers + private padded LDS exchanges), untangled, |X| written
-//                 to LDS and reduced over the banded mel weights; lane m stores band m of
-//                 the frame straight to out[b, m, t, c] (the L2 merges the 4-byte stores)
-//   LDS       = landing buffers [waves][N floats] | exchange buffers [waves] | frame queue |
-//               mel table (mode 1); after the prologue the waves share nothing but the queue
-//   MELMODE 3 = band weights in registers, two bands per lane (64 < M <= 128, aligned band span <= 8
+//   grid      = min(#chunks, #CUs) workgroups looping over chunks; one workgroup per CU with every
+//               wave the registers allow (16 at n_fft <= 512, 12 at 1024, 8 at 2048)
+//   per wave  = one frame at a time, claimed from the chunk's LDS queue, software-pipelined:
+//                 frame i is windowed, transformed (registers + private padded LDS exchanges),
+//                 untangled with the magnitude fused in, |X| goes to LDS; then - its sample
+//                 registers now dead - frame i+1 is loaded into them straight from global memory
+//                 and frame i+2 claimed, both in flight behind the banded mel reduction of frame i;
+//                 lane m stores band m of the frame straight to out[b, m, t, c] (the L2 merges the
+//                 4-byte stores).  n_fft 2048 has no registers to spare and lands frames by
+//                 LDS-DMA (global_load_lds) instead.
+//   LDS       = landing buffers [waves][N floats] (LDS-DMA targets; with direct loads only the
+//               staging area of the constant block) | exchange buffers [waves] (also |X|) | frame
+//               queue | mel table (mode 1) | time-band bitmap (BANDS); after the prologue the waves
+//               share nothing but the queue
+//   MELMODE 0 = band weights in registers (M <= 64, aligned band span <= 20, half spectrum): each lane
+//               reads a 16-byte-aligned window of 20 magnitudes with 5 ds_read_b128
+//           3 = band weights in registers, two bands per lane (64 < M <= 128, aligned band span <= 8
 //               bins - e.g. the reference's 80 mel over 257 bins): 2 x 2 ds_read_b128 per frame
-//   MELMODE 0 = band weights in registers (M <= 64, band length <= 16): each lane reads
-//               a 16-byte-aligned window of 20 magnitudes with 5 ds_read_b128
-//           1 = band table staged in LDS, 2 = band table read from global (L1/L2)
+//           1 = band table staged in LDS as float4 rows, 2 = band table read from global (L1/L2)
 //   HI        = some band needs bins above n_fft/4 (both halves of the untangle)
-//   BANDS     = SpecAugment / filter bands present
+//   BANDS     = SpecAugment / filter bands present (time bands: per-chunk bitmap, masked frames skip
+//               the transform; frequency bands: folded into the chunk's band weights)
+//   S         = frames in flight per wave (1; 2 exists for n_fft 512 / 1024 and measured slower)
 // ---------------------------------------------------------------------------
-// waves per workgroup: one workgroup per CU holding every wave of the CU, so that all waves are
-// of one age class for the issue arbiter (which favours older waves) and share one frame queue
-// workgroups per CU (= waves per SIMD): 3 -> <= 168 VGPRs; n_fft 2048 keeps 16 points per
-// lane and needs the 256-VGPR budget of 2
+// One workgroup per CU holding every wave of the CU: all waves are of one age class for the issue
+// arbiter (which favours older waves) and share one frame queue.
 constexpr int fused_occ(int log2n) { return 1; }
-// waves per workgroup: 3 per SIMD with one frame per wave (168 VGPRs); 2 per SIMD when a wave keeps
-// two frames in flight or at n_fft 2048 (256 VGPRs)
+// waves per workgroup: 4 per SIMD at n_fft <= 512 (<= 128 VGPRs), 3 at 1024 (<= 168), 2 when a wave
+// keeps two frames in flight or at n_fft 2048 (256 VGPRs)
 constexpr int fused_waves(int log2n, int streams = 1) {
     return (log2n >= 11 || streams > 1) ? 8 : (log2n <= 9 ? 16 : 12);
 }
