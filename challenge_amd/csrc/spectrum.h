@@ -120,9 +120,10 @@ __device__ __forceinline__ void untangle_mag(const cf (&x)[S][FftCfg<LOG2N>::P],
             for (int j = 0; j < 2; ++j) {
                 const int q = q0 + j;
                 const cf zk = x[s][q];
-                const cf zc = mk(zp[q].x, -zp[q].y);  // conj(Z[NC-k])
-                const cf e = zk + zc;                 // 2 E
-                const cf d = zk - zc;                 // 2 i O
+                // zc = conj(Z[NC-k]); e = zk + zc, d = zk - zc as one packed FMA each (the sign pattern
+                // rides on a (+-1, -+1) constant, exact)
+                const cf e = __builtin_elementwise_fma(zp[q], mk(1.0f, -1.0f), zk);  // 2 E
+                const cf d = __builtin_elementwise_fma(zp[q], mk(-1.0f, 1.0f), zk);  // 2 i O
                 const cf wo = cmul(mk(d.y, -d.x), post[q]);
                 lo[j] = e + wo;
                 if constexpr (HI) hi[j] = e - wo;
