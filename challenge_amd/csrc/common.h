@@ -81,7 +81,9 @@ struct iris_plan {
     float* d_wband;   // [rows][M] fused kernel: 0.5 * W[lo + i][m]
     int rows, need_hi, mel_mode;
     float* d_ws;  // workspace
-    unsigned long long* d_dbg;  // diagnostic stamps
+    unsigned long long* d_dbg;  // diagnostic stamps (IRIS_DIAG builds only; nullptr otherwise)
+    int ablate;                 // IRIS_DIAG builds: IRIS_ABLATE bits, read once at plan creation
+    bool magmel_generic;        // IRIS_MAGMEL_GENERIC set at plan creation: iris_magmel takes the generic kernel
     int streams;                // IRIS_STREAMS: frames in flight per wave (1 or 2)
     size_t ws_floats;
     int num_cu;

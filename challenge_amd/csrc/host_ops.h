@@ -124,7 +124,7 @@ extern "C" int iris_magmel(iris_plan* p, const float* spec, float* mel, int batc
     a.is_magphase = is_magphase;
     const bool aligned = (reinterpret_cast<uintptr_t>(spec) & (8 * p->channels - 1)) == 0;
     if (p->tri_ok && (p->channels == 1 || p->channels == 2) && aligned &&
-        (size_t)p->n_mel * 64 * p->channels * sizeof(float) <= 64 * 1024 && getenv("IRIS_MAGMEL_GENERIC") == nullptr) {
+        (size_t)p->n_mel * 64 * p->channels * sizeof(float) <= 64 * 1024 && !p->magmel_generic) {
         MagmelTriArgs t;
         t.spec = spec;
         t.mel = mel;
@@ -246,8 +246,7 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     a.hop = p->hop;
     a.M = p->n_mel;
     const int do_minmax = (flags & IRIS_F_MINMAX) ? 1 : 0, do_log = (flags & IRIS_F_LOG) ? 1 : 0;
-    a.ablate = 0;
-    if (const char* e = getenv("IRIS_ABLATE")) a.ablate = atoi(e);
+    a.ablate = p->ablate;  // 0 unless this is an IRIS_DIAG build
     a.dbg = p->d_dbg;
     const bool bands = (n_tb > 0) || (n_fb > 0);
     const int streams = plan_streams(p);

@@ -266,8 +266,10 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->d_bin_w = nullptr;
     p->d_wband = p->d_mel = p->d_ws = nullptr;
     p->d_dbg = nullptr;
+    p->ablate = 0;
     p->streams = 1;
     if (const char* e = getenv("IRIS_STREAMS")) p->streams = atoi(e) == 2 ? 2 : 1;
+    p->magmel_generic = getenv("IRIS_MAGMEL_GENERIC") != nullptr;  // test hook: read once, never per launch
     p->timing = 0;
     p->launch_no = 0;
     p->ev_used = 0;
@@ -446,8 +448,11 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     const int t_max = 1 + max_len / hop;
     const size_t wav_row = (size_t)channels * max_len;
     p->ws_floats = 2 * 16 * (size_t)max_batch * t_max + (size_t)max_batch * ((wav_row + kChunk - 1) / kChunk) + 64;
+#if IRIS_DIAG
     (void)hipMalloc((void**)&p->d_dbg, kDbgWords * sizeof(unsigned long long));
     if (p->d_dbg) (void)hipMemset(p->d_dbg, 0, kDbgWords * sizeof(unsigned long long));
+    if (const char* ab = getenv("IRIS_ABLATE")) p->ablate = atoi(ab);
+#endif
     hipError_t e;
     e = hipMalloc((void**)&p->d_ws, p->ws_floats * sizeof(float));
     if (e != hipSuccess) {
@@ -461,7 +466,8 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
 extern "C" int iris_plan_destroy(iris_plan* p) {
     if (!p) return IRIS_OK;
     DeviceGuard guard(p->device);
-    if (p->d_dbg && getenv("IRIS_ABLATE") && (atoi(getenv("IRIS_ABLATE")) & 4096)) {
+#if IRIS_DIAG
+    if (p->d_dbg && (p->ablate & 4096)) {
         std::vector<unsigned long long> h(kDbgWords, 0);
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h.data(), p->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -481,10 +487,10 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
                     sum[4] / sum[7], sum[5] / sum[7], sum[8] / waves, sum[6] / waves, sum[9] / waves,
                     sum[10] / waves, sum[11] / waves, sum[12] / waves, sum[13] / waves, sum[14] / waves);
         if (sum[15] > 0) fprintf(stderr, "[iris dbg] dummy LDS read after the barrier: %.0f cycles\n", sum[15] / waves);
-        if (sum[1] > 0 && (atoi(getenv("IRIS_ABLATE")) & 16384)) fprintf(stderr, "[iris dbg] whole chunk, cold pass %.0f cycles, warm pass %.0f cycles\n", sum[0] / waves, sum[1] / waves);
+        if (sum[1] > 0 && (p->ablate & 16384)) fprintf(stderr, "[iris dbg] whole chunk, cold pass %.0f cycles, warm pass %.0f cycles\n", sum[0] / waves, sum[1] / waves);
 
     }
-    if (p->d_dbg && getenv("IRIS_ABLATE") && (atoi(getenv("IRIS_ABLATE")) & 512)) {
+    if (p->d_dbg && (p->ablate & 512)) {
         std::vector<unsigned long long> h(4 + 3 * 4096, 0);
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h.data(), p->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -518,6 +524,7 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
                     loop / n * 0.01);
     }
     (void)hipFree(p->d_dbg);
+#endif
     for (hipEvent_t ev : p->ev) (void)hipEventDestroy(ev);
     (void)hipFree(p->d_consts);
     (void)hipFree(p->d_band_lo);

@@ -672,10 +672,21 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
         if validation_data is not None:
             vit = iter(validation_data)
             vl = torch.stack([model.test_step(next(vit))['loss'] for _ in range(validation_steps)]).mean()
+            if world > 1:  # every rank validates its own shard: the monitored value is the mean over ranks
+                torch.distributed.all_reduce(vl)
+                vl = vl / world
             row['val_loss'] = float(vl)
         history.append(row)
         if swa is not None:
             swa.on_epoch_end(epoch, model)
+        # The monitored value is identical on every rank (all-reduced above), so best / bad / stop are
+        # computed by all ranks alike and they leave the loop together; only file I/O is rank 0's.
+        monitor = row.get('val_loss', row['loss'])
+        improved = monitor < best
+        if improved:
+            best, bad = monitor, 0
+        else:
+            bad += 1
         if rank == 0:
             if verbose:
                 print(row)
@@ -686,14 +697,14 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
                     if new:
                         w.writeheader()
                     w.writerow(row)
-            monitor = row.get('val_loss', row['loss'])
-            if monitor < best:
-                best, bad = monitor, 0
-                if checkpoint_path:
-                    torch.save(model.state_dict(), checkpoint_path)
-            else:
-                bad += 1
-        if patience is not None and bad > patience:
+            if improved and checkpoint_path:
+                torch.save(model.state_dict(), checkpoint_path)
+        stop = patience is not None and not improved and bad >= patience  # Keras EarlyStopping: wait >= patience, tested on a non-improving epoch
+        if world > 1:  # belt and braces: one int per epoch, rank 0's decision wins
+            flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=loss.device)
+            torch.distributed.broadcast(flag, src=0)
+            stop = bool(int(flag.item()))
+        if stop:
             break
     return history
 

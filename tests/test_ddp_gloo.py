@@ -65,3 +65,63 @@ def test_ddp_two_ranks_gloo(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert torch.load(tmp_path / f"rank{r}.pt")["ok"]
+
+
+def _fit_worker(rank, world, port, out_dir):
+    """fit() under DDP with early stopping: the ranks see different data (so their local losses differ)
+    and must still leave the epoch loop together (sj_train.py:495 EarlyStopping, :513-519 fit)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from challenge_amd import sj_train as S
+    r, w, device = S.init_distributed()
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '32', '--n_frame', '64', '--n_chan', '1'])
+    torch.manual_seed(0)
+    model = S.get_model(cfg)
+    model.compile(S.make_optimizer(cfg, model.parameters()), S.binary_crossentropy, clipvalue=cfg.clipvalue,
+                  ddp=S.wrap_ddp(model, device, world))
+
+    def stream(seed):
+        g = torch.Generator().manual_seed(seed)
+        while True:
+            yield torch.randn(2, 32, 64, 1, generator=g), (torch.rand(2, 2, 3, generator=g) > 0.8).float()
+
+    class Val:  # a fresh, rank-specific validation stream each epoch: the rank-local val losses differ
+        def __iter__(self):
+            return stream(500 + rank)
+
+    csv_path = os.path.join(out_dir, "log.csv")
+    ckpt = os.path.join(out_dir, "best.pt")
+    # lr so large that the loss cannot keep improving: early stopping fires long before `epochs`
+    for g_ in model.optimizer.param_groups:
+        g_['lr'] = 0.5
+    hist = S.fit(model, stream(100 + rank), epochs=12, steps_per_epoch=2, validation_data=Val(), validation_steps=1,
+                 scheduler=None, csv_path=csv_path, checkpoint_path=ckpt, patience=0, rank=rank, world=world,
+                 verbose=False)
+    # every rank made the same decisions on the same (all-reduced) numbers
+    n = torch.tensor([len(hist)])
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    torch.distributed.all_gather(ns, n)
+    assert int(ns[0]) == int(ns[1]), ns
+    v = torch.tensor([h['val_loss'] for h in hist], dtype=torch.float64)
+    vs = [torch.zeros_like(v) for _ in range(world)]
+    torch.distributed.all_gather(vs, v)
+    assert torch.equal(vs[0], vs[1])
+    torch.save({"ok": True, "epochs": len(hist)}, os.path.join(out_dir, f"fit{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_fit_early_stopping_two_ranks_gloo(tmp_path):
+    """Round-1 defect: rank 0 alone updated the early-stopping counter and left the loop; the other
+    ranks blocked in the next all-reduce.  All ranks must return, after the same number of epochs."""
+    port = _free_port()
+    mp.spawn(_fit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(tmp_path / f"fit{r}.pt") for r in range(2)]
+    assert all(r["ok"] for r in res) and res[0]["epochs"] == res[1]["epochs"]
+    assert res[0]["epochs"] < 12, "early stopping never fired"
+    import csv as _csv
+    with open(tmp_path / "log.csv") as f:
+        rows = list(_csv.DictReader(f))
+    assert len(rows) == res[0]["epochs"] and (tmp_path / "best.pt").exists()
