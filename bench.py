@@ -5,14 +5,23 @@
 
 One "step" = one pass of the fused hot path (STFT -> magnitude -> mel -> per-sample
 min-max -> log, data resident in HBM) over BASELINE.json configs[1]: a batch of
-32 x 10 s mono 16 kHz clips, n_fft 1024, hop 256, 64 mel bands.  With N > 1 the
-driver launches one process per GPU (torch.distributed.run); every rank runs the
-same batch shape on its own clips (independent clips: no data-path collective,
-weak scaling) and the job throughput is the sum.  Rank 0 prints ONE JSON line.
+32 x 10 s mono 16 kHz clips, n_fft 1024, hop 256, 64 mel bands.  Consecutive steps
+rotate through ROTATE distinct batches (inputs AND outputs, > 256 MiB touched per cycle),
+so that every step's waveform comes from HBM and not from the 256 MiB Infinity Cache.
+
+With N > 1 there is one process per GPU: launched by the driver through
+torch.distributed.run, or - when WORLD_SIZE is unset - by this script itself, which starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a fresh child process
+before it touches the GPU and relays the child's JSON line and exit code.  Every rank runs
+the same batch shape on its own clips (independent clips: no data-path collective, weak
+scaling) and the job throughput is the sum.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +34,7 @@ if ROOT not in sys.path:
 
 SR, N_FFT, HOP, N_MEL = 16000, 1024, 256, 64
 BATCH, SECONDS = 32, 10
+ROTATE = 20  # distinct c2 batches per cycle: 20 x (20.5 MB in + 5.1 MB out) = 512 MB > 256 MiB Infinity Cache
 ALGO_BYTES_PER_AUDIO_S = 4 * SR + 4 * N_MEL * SR // HOP  # fp32 wave in + fp32 mel out = 80,000
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
@@ -153,6 +163,93 @@ def side_measurements(dev, rank, world, steps, fence):
     }
 
 
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources: ties a committed PMC traffic figure to the code it was measured on."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "challenge_amd", "csrc")
+    names = sorted(n for n in os.listdir(src) if n.endswith((".h", ".hip")))
+    for n in names:
+        with open(os.path.join(src, n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel_key: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r2/pmc_traffic.json,
+    written by scripts/pmc_summarise.py).  Refused (None + reason) when the kernel sources changed since."""
+    path = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        rec = doc[kernel_key]
+    except (OSError, KeyError, ValueError):
+        return None, "no committed PMC pass for " + kernel_key
+    sha = kernel_source_sha()
+    if doc.get("kernel_src_sha") != sha:
+        return None, f"PMC pass was taken at kernel sources {doc.get('kernel_src_sha')}, this build is {sha}: refused"
+    return rec["hbm_bytes_per_launch"], (f"profiles/r2/pmc_traffic.json (git {doc.get('git_sha')}, kernel sources {sha}; "
+                                         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950)")
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher: start one fresh process per GPU through torch.distributed.run and relay
+    its output.  Runs BEFORE this process touches the GPU (no torch.cuda call, no HIP call): a process that has
+    initialised the GPU must never exec or be replaced, so the ranks are children and we exit with their code."""
+    share = os.environ.get("IRIS_BENCH_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count()  # counts devices without initialising them
+    if not share and n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL needs it on this driver)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stderr.write(proc.stdout)
+    sys.exit(proc.returncode)
+
+
+def batch_sweep(dev, fence, steps):
+    """Fixed vs per-frame cost of the dominant kernel: one launch over B x 10 s for B = 32, 128, 512, each rotating
+    through enough distinct batches to exceed the 256 MiB Infinity Cache (B = 512 touches 410 MB in ONE launch)."""
+    from challenge_amd.frontend import FrontendPlan, normalize
+    length = SECONDS * SR
+    rows = []
+    for b in (32, 128, 512):
+        per_batch = b * (length * 4 + N_MEL * (1 + length // HOP) * 4)
+        copies = max(2, -(-(400 << 20) // per_batch))
+        plan = FrontendPlan(N_FFT, HOP, N_MEL, SR, 1, b, length, dev)
+        gen = torch.Generator(device=dev).manual_seed(77 + b)
+        wavs = [normalize(torch.randn(b, 1, length, generator=gen, device=dev)) for _ in range(copies)]
+        outs = [torch.empty((b, N_MEL, plan.num_frames(length), 1), device=dev) for _ in range(copies)]
+        for i in range(max(3, copies)):
+            plan.wav_to_logmel(wavs[i % copies], out=outs[i % copies])
+        plan.timing_enable(1)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            plan.wav_to_logmel(wavs[i % copies], out=outs[i % copies])
+        fence()
+        dt = (time.perf_counter() - t0) / steps
+        n_ev, k_ms = plan.timing_read()
+        plan.timing_enable(False)
+        algo = ALGO_BYTES_PER_AUDIO_S * b * SECONDS
+        rows.append({"batch": b, "distinct_batches": copies, "bytes_touched_per_cycle": copies * per_batch,
+                     "k1_us": round(1e3 * k_ms, 2), "k1_frac_of_8TBs": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "step_us_with_event_pairs": round(1e6 * dt, 2),
+                     "audio_s_per_s": round(b * SECONDS / dt, 1)})
+        del wavs, outs, plan
+        torch.cuda.empty_cache()
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,19 +260,23 @@ def main():
                     help="do not bracket the dominant kernel with HIP events (roofline.achieved = null)")
     ap.add_argument("--event-every", type=int, default=4, help="event-time every n-th launch of the dominant kernel")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the c3 (frontend + CRNN forward) and c4 (training step, DDP) side measurements")
+                    help="skip the side measurements (batch sweep, cache-resident replay, c3 forward, c4 training step)")
     ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--resident", action="store_true",
+                    help="replay ONE batch every step (Infinity-Cache resident, as round 1 measured) instead of rotating")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])  # never returns
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1 here)", file=sys.stderr)
-        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
     # test hook: IRIS_BENCH_SHARE_GPU=1 lets several ranks share cuda:0 over gloo, to exercise the N > 1
-    # control flow (barriers, max over ranks, DDP) on a one-GPU box; never set in a real run
+    # control flow (self-launch, barriers, max over ranks, DDP) on a one-GPU box; never set in a real run
     share = os.environ.get("IRIS_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
@@ -193,13 +294,17 @@ def main():
 
     length = SECONDS * SR
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    wav = torch.randn(BATCH, 1, length, generator=gen, device=dev, dtype=torch.float32)
-    wav = normalize(wav)  # reference normalisation x / (10 rms), data_utils.py:32-34
+    n_rot = 1 if args.resident else ROTATE
+    # reference normalisation x / (10 rms), data_utils.py:32-34
+    wavs = [normalize(torch.randn(BATCH, 1, length, generator=gen, device=dev, dtype=torch.float32)) for _ in range(n_rot)]
     plan = FrontendPlan(N_FFT, HOP, N_MEL, SR, 1, BATCH, length, dev)
-    out = torch.empty((BATCH, N_MEL, plan.num_frames(length), 1), device=dev)
+    outs = [torch.empty((BATCH, N_MEL, plan.num_frames(length), 1), device=dev) for _ in range(n_rot)]
+    cursor = [0]
 
     def step():
-        plan.wav_to_logmel(wav, minmax=True, log=True, out=out)
+        i = cursor[0] % n_rot
+        cursor[0] += 1
+        plan.wav_to_logmel(wavs[i], minmax=True, log=True, out=outs[i])
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -228,39 +333,59 @@ def main():
     audio_s_per_step = BATCH * SECONDS
     value = world * audio_s_per_step * args.steps / elapsed
     result = {
-        "metric": "audio-seconds/sec (STFT+mel+fwd) @16 kHz",
+        "metric": "audio-seconds/sec @16 kHz, STFT+mel frontend only (STFT+|X|+mel+min-max+log; the CRNN forward is NOT "
+                  "inside `value`: see stft_mel_fwd_audio_s_per_s)",
         "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "c2: batch 32 x 10 s mono 16 kHz per GPU, n_fft 1024 hop 256 n_mel 64; "
-                               "fused STFT+magnitude+mel+min-max+log (frontend only, no collective)",
+                               "fused STFT+magnitude+mel+min-max+log (frontend only, no collective); "
+                               + (f"steps rotate through {n_rot} distinct batches = "
+                                  f"{n_rot * (BATCH * length * 4 + outs[0].numel() * 4) >> 20} MiB per cycle (> 256 MiB "
+                                  "Infinity Cache): inputs come from HBM" if n_rot > 1 else
+                                  "ONE batch replayed every step (Infinity-Cache resident)"),
                    "global_batch": world * BATCH, "parallelism": f"dp{world}"},
+        "stft_mel_fwd_audio_s_per_s": None,
     }
     extras = None
     if not args.no_extras:
         extras = side_measurements(dev, rank, world, args.extra_steps, fence)
+        if world == 1:
+            extras["k1_batch_sweep"] = batch_sweep(dev, fence, max(args.extra_steps, 20))
+            # the round-1 configuration (one batch replayed, Infinity-Cache resident) beside the rotating one
+            plan.timing_enable(1)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                plan.wav_to_logmel(wavs[0], minmax=True, log=True, out=outs[0])
+            fence()
+            dt = (time.perf_counter() - t0) / 50
+            n1, k1 = plan.timing_read()
+            plan.timing_enable(False)
+            extras["c2_cache_resident_replay"] = {"k1_us": round(1e3 * k1, 2), "step_us_with_event_pairs": round(1e6 * dt, 2)}
     if rank == 0:
         if extras:
             result["extra"] = extras
+            result["stft_mel_fwd_audio_s_per_s"] = extras["c3_frontend_specaug_crnn_fwd"]["audio_s_per_s"]
         algo_bytes = ALGO_BYTES_PER_AUDIO_S * audio_s_per_step  # per launch
         achieved = (algo_bytes / (kernel_ms * 1e-3) / 1e9) if n_ev and kernel_ms > 0 else None
-        traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["k_wav_to_mel<10,0,false,false,1>"]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        kernel_key = "k_wav_to_mel<10,0,false,false,1>"
+        traffic, traffic_note = committed_traffic(kernel_key)
+        step_gbs = algo_bytes / (elapsed / args.steps) / 1e9
         result["roofline"] = {
-            "bound": "hbm", "kernel": "k_wav_to_mel<10>",
+            "bound": "hbm", "kernel": kernel_key,
             "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
-            "traffic_source": "profiles/r1/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+            "traffic_source": traffic_note,
             "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_ms": round(kernel_ms, 5) if n_ev else None, "launches_timed": n_ev,
+            # whole step (dominant kernel + min-max/log kernel + the boundary between them) against the same bytes
+            "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+            "event_pair_floor_us": 4.1,  # begin->end of an EMPTY kernel read this way (scripts/microbench/launch_floor.hip)
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(wav.cpu().numpy())
+            result["cpu_baseline"] = cpu_baseline(wavs[0].cpu().numpy())
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

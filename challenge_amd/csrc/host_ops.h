@@ -199,15 +199,15 @@ static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int
 
 // Geometry + grid for the residency the hardware really grants (registers and LDS): start from
 // the register-limited occupancy and go down until the occupancy query agrees.
-static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, int* chunk_frames,
+static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, bool bands, int* chunk_frames,
                         int* chunks_per_clip, int* grid, size_t* lds) {
     for (int per_cu = fused_occ(p->log2n); per_cu >= 1; --per_cu) {
         fused_geometry(p, batch, T, per_cu, chunk_frames, chunks_per_clip);
-        *lds = fused_lds_bytes(p, streams, *chunk_frames);
+        *lds = fused_lds_bytes(p, streams, bands, *chunk_frames);
         if (*lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
         int resident = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
-                                                                    64 * fused_waves(p->log2n, streams), *lds);
+                                                                    64 * fused_waves(p->log2n, streams, bands), *lds);
         if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s",
                                          hipGetErrorString(e));
         if (resident >= per_cu) {
@@ -253,14 +253,14 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     const fused_kernel_t kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams);
     int grid = 0;
     size_t lds = 0;
-    if ((rc = fused_config(p, kernel, batch, a.T, streams, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
+    if ((rc = fused_config(p, kernel, batch, a.T, streams, bands, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
         return rc;
     if ((size_t)p->n_mel * a.T * p->channels * 4 > 0xffffffffull || (size_t)a.T * p->channels * 4 >= (1u << 24))
         return fail(IRIS_E_UNSUPPORTED, "iris_wav_to_logmel: clip too long (%d frames x %d channels)", a.T, p->channels);
     a.n_chunks = batch * a.chunks_per_clip;
     a.chunk_base = a.T / a.chunks_per_clip;
     a.chunk_rem = a.T % a.chunks_per_clip;
-    const int waves = fused_waves(p->log2n, streams);
+    const int waves = fused_waves(p->log2n, streams, bands);
     const int parts_per_chunk = waves;
     const size_t n_partial = 2 * (size_t)a.n_chunks * parts_per_chunk;
     a.partial = p->d_ws;

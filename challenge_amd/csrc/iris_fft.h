@@ -17,11 +17,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// experiment switches (A/B builds only; the defaults are the product)
+#ifndef IRIS_OLD_CMUL
+#define IRIS_OLD_CMUL 0
+#endif
+#ifndef IRIS_SINGLE_READS
+#define IRIS_SINGLE_READS 0
+#endif
+
 namespace iris {
 
 constexpr int kWave = 64;
 
 typedef float cf __attribute__((ext_vector_type(2)));  // (re, im)
+typedef __attribute__((address_space(3))) cf lds_cf;     // the same in LDS, for accesses that must name the address space
 
 __device__ __forceinline__ cf mk(float re, float im) {
     cf r = {re, im};
@@ -36,6 +45,32 @@ __device__ __forceinline__ cf sub_mi(cf a, cf b) { return __builtin_elementwise_
 __device__ __forceinline__ cf cmul(cf a, cf w) {
     const cf t = a.yy * mk(-w.y, w.x);
     return __builtin_elementwise_fma(a.xx, w, t);
+}
+
+// a * w for a per-lane twiddle w that lives in registers across the frame loop.  Written with
+// the VOP3P operand modifiers by hand: in C++ the swapped / negated copy (-w.im, w.re) is loop
+// invariant, so the compiler hoists it into a second register pair per twiddle (36 VGPRs at
+// n_fft 1024 - the difference between 3 and 4 waves per SIMD); op_sel / neg_lo read it out of w.
+//   t = (a.im * -w.im, a.im * w.re);  r = (a.re * w.re + t.re, a.re * w.im + t.im)
+__device__ __forceinline__ cf cmul_tw(cf a, cf w) {
+#if IRIS_OLD_CMUL
+    return cmul(a, w);
+#endif
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// (-i d) * w  with  -i d = (d.im, -d.re): the rotation folds into the modifiers as well.
+//   t = (d.re * w.im, -d.re * w.re);  r = (d.im * w.re + t.re, d.im * w.im + t.im)
+__device__ __forceinline__ cf cmul_mi_tw(cf d, cf w) {
+#if IRIS_OLD_CMUL
+    return cmul(mk(d.y, -d.x), w);
+#endif
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(t) : "v"(d), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(d), "v"(w), "v"(t));
+    return r;
 }
 
 // cos/sin(2 pi k / 16), k = 0..7
@@ -138,7 +173,7 @@ __device__ __forceinline__ void stage_fwd(cf (&x)[P], const cf* tw, cf* lds, int
         for (int t = 0; t < R; ++t) v[t] = x[u + t * U];
         if constexpr (NS > 1) {
 #pragma unroll
-            for (int t = 1; t < R; ++t) v[t] = cmul(v[t], tw[u * (R - 1) + t - 1]);
+            for (int t = 1; t < R; ++t) v[t] = cmul_tw(v[t], tw[u * (R - 1) + t - 1]);
         }
         dft<R>(v);
         if constexpr (LAST) {
@@ -157,8 +192,16 @@ template <int P, int R, int NS>
 __device__ __forceinline__ void stage_load(cf (&x)[P], const cf* lds, int lane) {
     constexpr int PM = stage_pm(NS, R);
     const cf* rp = lds + lds_pad<PM>(lane);
+#if IRIS_SINGLE_READS
+    // volatile: keeps one ds_read_b64 per point (2 LDS cycles per 512 B) instead of the merged
+    // ds_read2_b64 (8 cycles per 1 KiB)
+    const volatile lds_cf* vp = (const volatile lds_cf*)rp;
+#pragma unroll
+    for (int q = 0; q < P; ++q) x[q] = vp[lds_pad<PM>(kWave * q)];
+#else
 #pragma unroll
     for (int q = 0; q < P; ++q) x[q] = rp[lds_pad<PM>(kWave * q)];
+#endif
 }
 
 // The same stage for S streams: all butterflies and writes, one ordering point, all reads.

@@ -31,10 +31,23 @@
 // One workgroup per CU holding every wave of the CU: all waves are of one age class for the issue
 // arbiter (which favours older waves) and share one frame queue.
 constexpr int fused_occ(int log2n) { return 1; }
-// waves per workgroup: 4 per SIMD at n_fft <= 512 (<= 128 VGPRs), 3 at 1024 (<= 168), 2 when a wave
-// keeps two frames in flight or at n_fft 2048 (256 VGPRs)
-constexpr int fused_waves(int log2n, int streams = 1) {
-    return (log2n >= 11 || streams > 1) ? 8 : (log2n <= 9 ? 16 : 12);
+// waves per workgroup: 4 per SIMD at n_fft <= 1024 (<= 128 VGPRs: a twiddle takes one register pair, see
+// cmul_tw) - except the n_fft 1024 variants with bands, which need 134 and stay at 3 per SIMD rather than
+// spill (a kernel with scratch pays ~5 us more per dispatch); 2 when a wave keeps two frames in flight or at
+// n_fft 2048.  (A/B at c2, both HBM-rotating and cache-resident: 16 waves = 12 waves within 0.3 %.)
+#ifndef IRIS_W1024
+#define IRIS_W1024 16
+#endif
+#ifndef IRIS_W2048
+#define IRIS_W2048 8
+#endif
+// frames go global -> registers up to this n_fft (log2); above it through LDS-DMA landing buffers
+#ifndef IRIS_DIRECT_MAX
+#define IRIS_DIRECT_MAX 10
+#endif
+constexpr bool fused_direct(int log2n) { return IRIS_DIRECT_LOAD && log2n <= IRIS_DIRECT_MAX; }
+constexpr int fused_waves(int log2n, int streams = 1, bool bands = false) {
+    return streams > 1 ? 8 : (log2n >= 11 ? IRIS_W2048 : (log2n == 10 ? (bands ? 12 : IRIS_W1024) : 16));
 }
 
 struct FusedArgs {
@@ -139,8 +152,8 @@ __device__ __forceinline__ void dma_frame(const float* clip, int len, int start,
 }
 
 template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S>
-__global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) / 4) void k_wav_to_mel(const FusedArgs a) {
-    constexpr int kFusedWaves = fused_waves(LOG2N, S);
+__global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2N, S, BANDS) / 4) void k_wav_to_mel(const FusedArgs a) {
+    constexpr int kFusedWaves = fused_waves(LOG2N, S, BANDS);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the wave index is uniform: keep it (and everything derived from it) in SGPRs
@@ -149,7 +162,8 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
     // LDS: [waves][S] landing buffers (LDS-DMA targets, N floats) | [waves][S] exchange buffers
     // (also |X|) | frame queue | MELMODE 1 tables.  Nothing is shared between waves but the queue.
     constexpr int kXBufBytes = (lds_padded(NC, FftCfg<LOG2N>::PMMAX) * 8 + 15) & ~15;
-    constexpr int kLandBytes = kFusedWaves * S * N * 4;
+    // landing area: LDS-DMA targets, or - with direct loads - only the staging area of the constant block
+    constexpr int kLandBytes = fused_direct(LOG2N) ? ((ConstLayout<LOG2N>::NV4 * kWave * 16 + 15) & ~15) : kFusedWaves * S * N * 4;
     const float* fbuf[S];
     unsigned fbuf_lds[S];
     cf* lds[S];
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S), fused_waves(LOG2N, S) /
     auto chunk_nt = [&](int chunk, int b) {
         return a.chunk_base + ((chunk - b * a.chunks_per_clip) < a.chunk_rem ? 1 : 0);
     };
-    constexpr bool DIRECT = IRIS_DIRECT_LOAD && LOG2N <= 10;  // n_fft 2048 (16 points per lane) has no registers to spare
+    constexpr bool DIRECT = fused_direct(LOG2N);  // n_fft 2048 (16 points per lane) has no registers to spare
     cf x[S][P];
     // Fetch of wave-frames ff[] (f = tl * C + c) of a chunk: straight into the x registers
     // (IRIS_DIRECT_LOAD), or by LDS-DMA into this wave's landing buffers

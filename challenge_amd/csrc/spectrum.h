@@ -56,12 +56,12 @@ __device__ __forceinline__ void untangle_multi(const cf (&x)[S][FftCfg<LOG2N>::P
             const cf zc = mk(zp.x, -zp.y);  // conj(Z[NC-k])
             cf e = zk + zc;                 // 2 E
             const cf d = zk - zc;           // 2 i O
-            cf o = mk(d.y, -d.x);           // 2 O
+            cf dh = d;                      // 2 i O  (O = -i dh / 2)
             if constexpr (HALF) {
                 e *= 0.5f;
-                o *= 0.5f;
+                dh *= 0.5f;
             }
-            const cf wo = cmul(o, post[q]);
+            const cf wo = cmul_mi_tw(dh, post[q]);
             xlo[s][q] = e + wo;
             if constexpr (HI) {
                 const cf t = e - wo;
@@ -104,8 +104,14 @@ __device__ __forceinline__ void untangle_mag(const cf (&x)[S][FftCfg<LOG2N>::P],
     for (int s = 0; s < S; ++s) {
         const cf* rp = lds[s] + lds_pad<1>(kWave - lane);
         cf zp[P / 2];
+#if IRIS_SINGLE_READS
+        const volatile lds_cf* vp = (const volatile lds_cf*)rp;
+#pragma unroll
+        for (int q = 0; q < P / 2; ++q) zp[q] = vp[lds_pad<1>(kWave * (P - 1 - q))];
+#else
 #pragma unroll
         for (int q = 0; q < P / 2; ++q) zp[q] = rp[lds_pad<1>(kWave * (P - 1 - q))];
+#endif
         if (lane == 0) zp[0] = x[s][0];  // k = 0 pairs with itself
         if constexpr (HI) {
             if (lane == 0) mag[s][NC / 2] = 2.0f * cabs_rn(x[s][P / 2]);  // X[NC/2] = conj(Z[NC/2])
@@ -113,23 +119,24 @@ __device__ __forceinline__ void untangle_mag(const cf (&x)[S][FftCfg<LOG2N>::P],
         // Two bins at a time, then their stores: independent chains interleave (a packed op
         // that consumes the previous packed result costs a wait state on this chip) without
         // keeping the whole spectrum live.
+        constexpr int PAIR = P / 2 >= 2 ? 2 : 1;  // n_fft 256 has one bin pair per lane
 #pragma unroll
-        for (int q0 = 0; q0 < P / 2; q0 += 2) {
-            cf lo[2], hi[2];
+        for (int q0 = 0; q0 < P / 2; q0 += PAIR) {
+            cf lo[PAIR], hi[PAIR];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < PAIR; ++j) {
                 const int q = q0 + j;
                 const cf zk = x[s][q];
                 // zc = conj(Z[NC-k]); e = zk + zc, d = zk - zc as one packed FMA each (the sign pattern
                 // rides on a (+-1, -+1) constant, exact)
                 const cf e = __builtin_elementwise_fma(zp[q], mk(1.0f, -1.0f), zk);  // 2 E
                 const cf d = __builtin_elementwise_fma(zp[q], mk(-1.0f, 1.0f), zk);  // 2 i O
-                const cf wo = cmul(mk(d.y, -d.x), post[q]);
+                const cf wo = cmul_mi_tw(d, post[q]);
                 lo[j] = e + wo;
                 if constexpr (HI) hi[j] = e - wo;
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < PAIR; ++j) {
                 const int q = q0 + j;
                 mag[s][lane + kWave * q] = cabs_rn(lo[j]);
                 if constexpr (HI) mag[s][NC - lane - kWave * q] = cabs_rn(hi[j]);

@@ -16,6 +16,8 @@ from challenge_amd import utils as U
 from challenge_amd.dataset import Dataset
 from oracle import frontend_ref as R
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 # ---- dataset glue -------------------------------------------------------------
 def test_dataset_surface():
@@ -299,3 +301,17 @@ def test_bench_cpu_baseline_leg_runs_without_gpu():
     r = bench.cpu_baseline(wav)
     assert r["kind"] == "port" and r["unit"] == "audio-s/s" and r["value"] > 0 and r["cores"] >= 1
     assert r["value"] == max(r["numpy_1thread"], r["torch_best"])
+
+
+def test_bench_gpus_argument_without_devices():
+    """`bench.py --gpus N` without a launcher starts its own ranks; with fewer devices than N it must say so
+    and exit 2 before touching the GPU (it used to exit 2 for ANY N > 1: VERDICT round 1, missing 3)."""
+    import subprocess
+    import sys as _sys
+    import torch as _torch
+    if _torch.cuda.device_count() >= 2:
+        pytest.skip("needs < 2 visible GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IRIS_BENCH_SHARE_GPU")}
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr, (r.returncode, r.stderr[-300:])
