@@ -93,11 +93,20 @@ def magphase_to_mel(num_mel_bins: int = 80, num_spectrogram_bins: int = 257, sam
                     **kwargs):
     """Closure factory (transforms.py:51-77).  The weight matrix is built once here
     (argument errors surface at creation, as in the reference); the closure maps
-    [B, F, T, 2C] -> [B, M, T, C] or [F, T, 2C] -> [M, T, C]."""
+    [B, F, T, 2C] -> [B, M, T, C] or [F, T, 2C] -> [M, T, C].
+
+    Extension: `mel_matrix=W` ([F, M] float32) replaces the built-in recipe - pass the matrix your TensorFlow build
+    returns from tf.signal.linear_to_mel_weight_matrix for bit-exact weights."""
+    external = kwargs.pop("mel_matrix", None)
     unknown = set(kwargs) - {"lower_edge_hertz", "upper_edge_hertz"}
     if unknown:
         raise TypeError(f"unexpected keyword arguments {sorted(unknown)}")
-    mel_matrix = _fe.mel_weight_matrix(num_mel_bins, num_spectrogram_bins, sample_rate, **kwargs)
+    if external is not None:
+        mel_matrix = np.ascontiguousarray(external, np.float32)
+        if mel_matrix.shape != (num_spectrogram_bins, num_mel_bins):
+            raise ValueError(f"mel_matrix must be [{num_spectrogram_bins}, {num_mel_bins}], got {mel_matrix.shape}")
+    else:
+        mel_matrix = _fe.mel_weight_matrix(num_mel_bins, num_spectrogram_bins, sample_rate, **kwargs)
     n_fft = 2 * (num_spectrogram_bins - 1)
     fft_ok = n_fft in (256, 512, 1024, 2048)
     plans = {}

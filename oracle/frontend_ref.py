@@ -394,6 +394,32 @@ def label_downsample(resolution: int = 32, ref_batch_slice: bool = False):
     return _label_downsample
 
 
+def preprocess_labels(multiplier):
+    """trainer.py:86-94: five passes of tf.nn.avg_pool1d(y, 2, strides=2, 'SAME') * 2 on [B, T, K] (a sum-pool by
+    2 whose ragged tail window is averaged over its ONE valid entry and doubled), then * multiplier."""
+    def _preprocess(x, y):
+        y = np.asarray(y)
+        for _ in range(5):
+            y = avg_pool1d_same(y, 2) * y.dtype.type(2)
+        return x, y * y.dtype.type(multiplier)
+    return _preprocess
+
+
+def to_density_labels(x, y):
+    """trainer.py:97-104: [..., V, T, K] -> every voice scaled to unit mass (safe_div, utils.py:114-116), summed
+    over the voices axis."""
+    y = np.asarray(y)
+    y = safe_div(y, np.sum(y, axis=(-2, -1), keepdims=True))
+    return x, np.sum(y, axis=-3)
+
+
+def multiply_label(multiplier):
+    """data_utils.py:120-123."""
+    def _multiply(x, y):
+        return x, y * multiplier
+    return _multiply
+
+
 # --------------------------------------------------------------------------
 # remaining transforms.py signatures                    transforms.py:137-195
 # --------------------------------------------------------------------------

@@ -361,10 +361,17 @@ def test_workgroups_looping_over_several_chunks(dev, monkeypatch):
         small = FE().FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
         monkeypatch.delenv("IRIS_CHUNK_FRAMES")
         x = torch.from_numpy(wav).to(dev)
+        from oracle.torch_cpu_ref import wav_to_logmel_cpu
+        w32 = torch.from_numpy(R.linear_to_mel_weight_matrix(m, n_f, 16000))
+        engine = wav_to_logmel_cpu(torch.from_numpy(wav), w32, n_fft, hop, False, False).numpy()
+        engine_err = rel_err(engine, R.wav_to_mel(wav, n_fft, hop, m, 16000, dtype=np.float64))
         for kw in ({}, {"t_bands": tb}, {"t_bands": tb, "f_bands": fb}, {"f_bands": fb}):
             raw = small.wav_to_logmel(x, minmax=False, log=False, **kw)
             assert torch.equal(raw, ref_plan.wav_to_logmel(x, minmax=False, log=False, **kw))
-            # (narrow low bands are ~100x below the spectrum's peak here: two fp32 FFTs differ by a few 1e-5 of them)
-            assert rel_err(raw.cpu().numpy(), R.wav_to_mel(wav, n_fft, hop, m, 16000, **kw)) <= 4e-5
+            # Against the fp64 oracle, at north_star's 1e-5 - or, where the reference's own fp32 engine (torch.stft +
+            # fp32 matmul, oracle/torch_cpu_ref.py) misses 1e-5 on this very input (narrow low bands ~1000x below
+            # the spectrum's peak: an fp32 FFT's error scales with the peak), at the error that engine makes.
+            ref64 = R.wav_to_mel(wav, n_fft, hop, m, 16000, dtype=np.float64, **kw)
+            assert rel_err(raw.cpu().numpy(), ref64) <= max(1e-5, engine_err)
             full = small.wav_to_logmel(x, **kw)
             assert torch.equal(full, ref_plan.wav_to_logmel(x, **kw))

@@ -81,6 +81,17 @@ def test_magphase_to_mel(dev, kats):
     f = T.magphase_to_mel(12, 100, 8000, lower_edge_hertz=50.0, upper_edge_hertz=3900.0)
     ref = R.magphase_to_mel(12, 100, 8000, lower_edge_hertz=50.0, upper_edge_hertz=3900.0)(x)
     assert np.abs(f(torch.from_numpy(x).to(dev)).cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    # external matrix (the route to exact TensorFlow parity): here a perturbed triangular W
+    # and a dense one; the closure must use exactly the matrix it was given
+    w = R.linear_to_mel_weight_matrix(80, 257, 16000)
+    x = np.abs(rng.standard_normal((3, 257, 9, 4))).astype(np.float32)
+    for ext in (w * (1 + 1e-3 * rng.standard_normal(w.shape).astype(np.float32)), np.abs(rng.standard_normal(w.shape)).astype(np.float32)):
+        g = T.magphase_to_mel(80, 257, 16000, mel_matrix=ext)
+        assert np.array_equal(g.mel_matrix, ext)
+        ref = np.einsum("bftc,fm->bmtc", x[..., :2].astype(np.float64), ext.astype(np.float64))
+        assert np.abs(g(torch.from_numpy(x).to(dev)).cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    with pytest.raises(ValueError):
+        T.magphase_to_mel(80, 257, 16000, mel_matrix=w[:100])
 
 
 def test_log_magphase(dev, kats):
@@ -400,3 +411,130 @@ def test_drop_in_merge_on_device_matches_oracle(dev):
                                             None if noises is None else torch.from_numpy(noises), d, n_frame=12,
                                             n_classes=5)
         assert np.array_equal(c.numpy(), b) and np.array_equal(lc.numpy(), lb)
+
+
+# ---------------------------------------------------------------------------
+# round 2: value tests on the device for the rows that only had shape / CPU coverage
+# ---------------------------------------------------------------------------
+def test_label_helpers_on_device_match_oracle(dev):
+    """R9 on the device against the oracle (data_utils.py:64-70, :85-97, :120-123; trainer.py:86-104)."""
+    _, D, _ = mods()
+    from challenge_amd import trainer as TR
+    rng = np.random.default_rng(31)
+    y4 = (rng.random((5, 4, 70, 3)) > 0.7).astype(np.float32)          # [B, voices, frames, classes]
+    yd = torch.from_numpy(y4).to(dev)
+    frame = D.to_frame_labels(None, yd)[1]
+    assert frame.is_cuda and np.array_equal(frame.cpu().numpy(), R.to_frame_labels(None, y4)[1])
+    y3 = R.to_frame_labels(None, y4)[1]                                # [B, frames, classes], ragged tail (70 = 2*32 + 6)
+    for res in (32, 8, 7):
+        got = D.label_downsample(res)(None, torch.from_numpy(y3).to(dev))[1]
+        assert got.is_cuda and np.array_equal(got.cpu().numpy(), R.label_downsample(res)(None, y3)[1])
+    ylong = (rng.random((64, 512, 3)) > 0.5).astype(np.float32)        # c3 / c4: batch 64 keeps all 64 rows
+    got = D.label_downsample(32)(None, torch.from_numpy(ylong).to(dev))[1].cpu().numpy()
+    assert got.shape == (64, 16, 3) and np.array_equal(got, R.label_downsample(32)(None, ylong)[1])
+    for mult in (1, 10):
+        got = TR.preprocess_labels(mult)(None, torch.from_numpy(y3).to(dev))[1].cpu().numpy()
+        ref = R.preprocess_labels(mult)(None, y3)[1]
+        assert got.shape == ref.shape == (5, 3, 3) and np.allclose(got, ref, rtol=1e-6, atol=0)
+    dens = TR.to_density_labels(None, yd)[1].cpu().numpy()
+    assert np.allclose(dens, R.to_density_labels(None, y4)[1], rtol=1e-6, atol=1e-9)
+    zero = torch.zeros(2, 3, 8, 3, device=dev)                         # a silent voice: safe_div keeps it at 0
+    assert float(TR.to_density_labels(None, zero)[1].abs().max()) == 0.0
+    assert np.array_equal(D.multiply_label(3)(None, yd)[1].cpu().numpy(), R.multiply_label(3)(None, y4)[1])
+
+
+def test_phase_vocoder_values_on_device(dev, kats):
+    """transforms.py:137-195 on the device, values (not only shapes): fp64 against the oracle at the rates of
+    transforms_test.py:98-108; the fp32 run carries the accumulated-phase noise (~1e3 rad) the reference has too."""
+    T, _, _ = mods()
+    k = kats["phase_vocoder_shapes"]
+    rng = np.random.default_rng(41)
+    spec = rng.standard_normal((k["n_freq"], k["time"], k["chan2"]))
+    sd = torch.from_numpy(spec).to(dev)
+    assert T.phase_vocoder(sd, 1.0) is sd
+    for rate in k["rates"]:
+        got = T.phase_vocoder(sd, rate=rate)
+        ref = R.phase_vocoder(spec, rate)
+        assert got.is_cuda and got.dtype == torch.float64
+        assert list(got.shape) == list(ref.shape) == [k["n_freq"], int(np.ceil(k["time"] / rate)), k["chan2"]]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
+        got32 = T.phase_vocoder(sd.float(), rate=rate).cpu().numpy()
+        # fp32: the accumulated phase reaches ~7e4 rad here (257 bins x ~100 steps), so fp32 rounding alone is worth
+        # ~1e-2 rad per element - in the reference's fp32 TF graph too; the fp64 run above checks the algorithm
+        assert got32.dtype == np.float32 and np.abs(got32 - ref).max() <= 5e-2 * np.abs(ref).max()
+    # the two magnitude-phase helpers that stay torch ops: values on the device against the oracle
+    mp = rng.standard_normal((5, 10, 7, 4))
+    assert np.allclose(T.minmax_norm_magphase(torch.from_numpy(mp).to(dev)).cpu().numpy(), R.minmax_norm_magphase(mp),
+                       rtol=1e-12, atol=1e-12)
+    lm = np.abs(rng.standard_normal((6, 9, 6)))
+    assert np.allclose(T.log_magphase(torch.from_numpy(lm).to(dev), n_chan=3).cpu().numpy(), R.log_magphase(lm, n_chan=3),
+                       rtol=1e-12, atol=1e-12)
+
+
+def test_c3_batch64_device_bands_match_oracle(dev):
+    """BASELINE configs[2] at its full size: batch 64 x 130,816 samples (T = 512), SpecAugment bands drawn on the
+    device (6 time + 1 frequency band per clip) plus stft_filter(3), through the fused kernel; a sample of clips is
+    checked against the fp64 oracle (mel before min-max: north_star's 1e-5) and the fp32 oracle (after min-max / log)."""
+    _, _, S = mods()
+    b, length, n_t = 64, 130816, 512
+    fe = S.WaveFrontend(1024, 256, 64, 16000, 1, b, length, dev, training=True, device_draw=True, filter_bins=3, seed=3)
+    gen = torch.Generator(device=dev).manual_seed(17)
+    wav = torch.randn(b, 1, length, generator=gen, device=dev) * 0.1
+    tb, fb = fe.draw_bands_device(b, n_t)
+    fb = torch.cat([fb, torch.tensor([[[1, 3]]], dtype=torch.int32, device=dev).expand(b, 1, 2)], dim=1)
+    raw = fe.plan.wav_to_logmel(wav, minmax=False, log=False, t_bands=tb, f_bands=fb)
+    out = fe.plan.wav_to_logmel(wav, t_bands=tb, f_bands=fb)
+    assert tuple(out.shape) == (b, 64, n_t, 1) and torch.isfinite(out).all()
+    idx = [0, 21, 42, 63]
+    w, tbn, fbn = wav[idx].cpu().numpy(), tb[idx].cpu().numpy(), fb[idx].cpu().numpy()
+    ref64 = R.wav_to_mel(w, 1024, 256, 64, 16000, t_bands=tbn, f_bands=fbn, dtype=np.float64)
+    got = raw[idx].cpu().numpy()
+    assert float((np.abs(got - ref64) / np.maximum(np.abs(ref64), 1e-3)).max()) <= 1e-5
+    # masked frames / bins are exactly zero columns; the per-clip minimum is therefore 0 wherever a time band has size > 0
+    for j, i in enumerate(idx):
+        for off, size in tbn[j]:
+            assert not got[j, :, off:off + size].any()
+    ref = R.wav_to_logmel(w, 1024, 256, 64, 16000, t_bands=tbn, f_bands=fbn)
+    assert np.abs(np.exp(out[idx].cpu().numpy()) - np.exp(ref)).max() <= 5e-6
+    # the same call through the WaveFrontend object (its own draws): shape and range only
+    x = fe(wav)
+    assert tuple(x.shape) == (b, 64, n_t, 1) and float(x.max()) <= 1e-6 and float(x.min()) >= math.log(1e-8) - 1e-4
+
+
+def test_sj_train_main_two_epochs(dev, tmp_path, monkeypatch):
+    """sj_train.main on synthetic sources for two epochs (sj_train.py:406-525): CSV log with one row per epoch
+    (:490), best-val checkpoint (:492), SWA weights (:491, :521), the run-name encoding (:416-429)."""
+    import csv
+    _, _, S = mods()
+    monkeypatch.chdir(tmp_path)
+    S.main(['--synthetic', '--epochs', '2', '--steps_per_epoch', '3', '--validation_steps', '1', '--batch_size', '8',
+            '--n_frame', '128', '--v', '9', '--n_mels', '32', '--name', 'pytest'])
+    stem = 'pytest_vad_v9_lr0.001_batch8_opt_adam_mel32_chan2_BCE_framelen128'
+    with open(tmp_path / (stem + '.csv')) as f:
+        rows = list(csv.DictReader(f))
+    assert [int(r['epoch']) for r in rows] == [0, 1]
+    assert all(math.isfinite(float(r['loss'])) and math.isfinite(float(r['val_loss'])) and float(r['lr']) > 0 for r in rows)
+    ckpt = torch.load(tmp_path / (stem + '.pt'), map_location='cpu')
+    swa = torch.load(tmp_path / (stem + '_SWA.pt'), map_location='cpu')
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '32', '--n_frame', '128'])
+    model = S.get_model(cfg)
+    model.load_state_dict(ckpt)
+    model.load_state_dict(swa)
+    assert set(ckpt) == set(swa) == set(model.state_dict())
+
+
+def test_bench_self_launch_two_ranks(dev):
+    """`python bench.py --gpus 2` without a launcher starts its own ranks (torch.distributed.run children) before it
+    touches the GPU; IRIS_BENCH_SHARE_GPU=1 lets both ranks use cuda:0 over gloo so this runs on a one-GPU box."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["IRIS_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["steps"] == 5 and res["value"] > 0 and res["config"]["global_batch"] == 64
+    assert res["roofline"]["frac"] is not None and res["scaling"] == "weak"
