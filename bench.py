@@ -353,6 +353,11 @@ def main():
         extras = side_measurements(dev, rank, world, args.extra_steps, fence)
         if world == 1:
             extras["k1_batch_sweep"] = batch_sweep(dev, fence, max(args.extra_steps, 20))
+            # BASELINE configs[4]: 22.05 kHz stereo, n_fft 2048, 128 mel - banded fp32 (default) vs fp16 MFMA variant
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import gpu_c5
+            extras["c5_stereo_2048_128mel"] = {"fp32_banded_default": gpu_c5.run("fp32", 40), "fp16_mfma": gpu_c5.run("fp16_mfma", 40),
+                                               "default": "fp32 (the fp16 variant is faster but its 2e-3 misses north_star's 1e-5)"}
             # the round-1 configuration (one batch replayed, Infinity-Cache resident) beside the rotating one
             plan.timing_enable(1)
             fence()

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IRIS_LIB") or os.path.join(_HERE, "csrc", "libiris_frontend.so")
 
 IRIS_F_MINMAX, IRIS_F_LOG, IRIS_F_NORMALIZE = 1, 2, 4
+IRIS_MEL_F32, IRIS_MEL_F16_MFMA = 0, 1
 
 # every symbol include/iris_frontend.h declares, with (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -24,6 +25,7 @@ SIGNATURES = {
     "iris_mel_weight_matrix": (_i, [_i, _i, _f, _f, _f, _fp]),
     "iris_plan_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _fp]),
     "iris_plan_destroy": (_i, [_vp]),
+    "iris_plan_set_mel_precision": (_i, [_vp, _i]),
     "iris_plan_get_mel": (_i, [_vp, _fp]),
     "iris_plan_num_frames": (_i, [_vp, _i]),
     "iris_normalize_workspace": (_sz, [_i, _sz]),

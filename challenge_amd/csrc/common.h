@@ -80,6 +80,10 @@ struct iris_plan {
     int* d_fband_lo;  // [M] fused kernel: first bin read, clamped so lo + rows <= limit
     float* d_wband;   // [rows][M] fused kernel: 0.5 * W[lo + i][m]
     int rows, need_hi, mel_mode;
+    // fp16-MFMA mel variant: availability, device tables, staged bins, selected precision (0 fp32, 1 fp16 MFMA)
+    int mfma_ok, mfma_kb, mel_precision;
+    void* d_wfrag;
+    int* d_tile_ks;
     float* d_ws;  // workspace
     unsigned long long* d_dbg;  // diagnostic stamps (IRIS_DIAG builds only; nullptr otherwise)
     int ablate;                 // IRIS_DIAG builds: IRIS_ABLATE bits, read once at plan creation

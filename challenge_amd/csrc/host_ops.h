@@ -249,18 +249,26 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     a.ablate = p->ablate;  // 0 unless this is an IRIS_DIAG build
     a.dbg = p->d_dbg;
     const bool bands = (n_tb > 0) || (n_fb > 0);
-    const int streams = plan_streams(p);
-    const fused_kernel_t kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams);
+    const bool mfma = p->mel_precision == 1 && !bands;  // calls with bands always take the fp32 kernel
+    const int streams = mfma ? 1 : plan_streams(p);
+    const fused_kernel_t kernel = mfma ? mfma_kernel(p->log2n) : fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams);
     int grid = 0;
     size_t lds = 0;
-    if ((rc = fused_config(p, kernel, batch, a.T, streams, bands, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
+    a.wfrag = p->d_wfrag;
+    a.tile_ks = p->d_tile_ks;
+    a.kb = p->mfma_kb;
+    if (mfma) {
+        fused_geometry(p, batch, a.T, 1, &a.chunk_frames, &a.chunks_per_clip);
+        lds = mfma_lds_bytes(p);
+        grid = std::min(batch * a.chunks_per_clip, p->num_cu);
+    } else if ((rc = fused_config(p, kernel, batch, a.T, streams, bands, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
         return rc;
     if ((size_t)p->n_mel * a.T * p->channels * 4 > 0xffffffffull || (size_t)a.T * p->channels * 4 >= (1u << 24))
         return fail(IRIS_E_UNSUPPORTED, "iris_wav_to_logmel: clip too long (%d frames x %d channels)", a.T, p->channels);
     a.n_chunks = batch * a.chunks_per_clip;
     a.chunk_base = a.T / a.chunks_per_clip;
     a.chunk_rem = a.T % a.chunks_per_clip;
-    const int waves = fused_waves(p->log2n, streams, bands);
+    const int waves = mfma ? kMfmaWaves : fused_waves(p->log2n, streams, bands);
     const int parts_per_chunk = waves;
     const size_t n_partial = 2 * (size_t)a.n_chunks * parts_per_chunk;
     a.partial = p->d_ws;

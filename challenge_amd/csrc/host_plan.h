@@ -196,6 +196,20 @@ static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands,
         default: return fused_kernel_m<8>(mel_mode, hi, bands, streams);
     }
 }
+static fused_kernel_t mfma_kernel(int log2n) {
+    switch (log2n) {
+        case 11: return k_wav_to_mel_mfma<11>;
+        case 10: return k_wav_to_mel_mfma<10>;
+        default: return k_wav_to_mel_mfma<9>;
+    }
+}
+// LDS of the MFMA variant: landing + exchange buffers of its 8 waves, two fp16 magnitude tiles
+static size_t mfma_lds_bytes(const iris_plan* p) {
+    const size_t xbuf = (wave_buf_bytes(p->log2n) + 15) & ~(size_t)15;
+    const size_t kb_pad = ((size_t)p->mfma_kb + 63) & ~(size_t)63;
+    return (size_t)kMfmaWaves * p->n_fft * 4 + std::max((size_t)kMfmaWaves * xbuf, (size_t)const_nv4(p->log2n) * 64 * 16) +
+           2 * (size_t)kMfmaGroup * (kb_pad + 8) * 2;
+}
 static const void* stft_kernel(int log2n) {
     switch (log2n) {
         case 11: return (const void*)k_stft<11>;
@@ -214,6 +228,10 @@ static hipError_t allow_big_lds(const iris_plan* p) {
         if (streams == 2 && p->log2n != 9 && p->log2n != 10) continue;
         e = hipFuncSetAttribute((const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, (v & 1) != 0, streams),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+        if (e != hipSuccess) return e;
+    }
+    if (p->mfma_ok) {
+        e = hipFuncSetAttribute((const void*)mfma_kernel(p->log2n), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
         if (e != hipSuccess) return e;
     }
     return hipFuncSetAttribute(stft_kernel(p->log2n), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
@@ -267,6 +285,9 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->d_bin_band = nullptr;
     p->d_bin_w = nullptr;
     p->d_wband = p->d_mel = p->d_ws = nullptr;
+    p->d_wfrag = nullptr;
+    p->d_tile_ks = nullptr;
+    p->mfma_ok = p->mfma_kb = p->mel_precision = 0;
     p->d_dbg = nullptr;
     p->ablate = 0;
     p->streams = 1;
@@ -371,6 +392,43 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
         }
     }
 
+    // fp16-MFMA mel variant (k_fused_mfma.h): per tile of 16 bands the k-steps (32 bins) that hold one of its
+    // non-zeros, and the A fragments 0.5 W^T in the lane layout of v_mfma_f32_16x16x32_f16:
+    // lane l, element e = 0.5 W[32 ks + 8 (l >> 4) + e][16 tile + (l & 15)]
+    std::vector<_Float16> wfrag;
+    std::vector<int> tile_ks;
+    if (!mel_only && log2n >= 9 && log2n <= 11 && !p->need_hi && n_mel <= 16 * kMfmaWaves) {
+        const int n_tiles = (n_mel + 15) / 16;
+        p->mfma_ok = 1;
+        tile_ks.assign(2 * kMfmaWaves, 0);
+        wfrag.assign((size_t)kMfmaWaves * kMfmaKsMax * 64 * 8, (_Float16)0.f);
+        for (int t = 0; t < n_tiles && p->mfma_ok; ++t) {
+            int b_lo = n_bins, b_hi = 0;
+            for (int m = 16 * t; m < std::min(16 * t + 16, n_mel); ++m)
+                if (len[m] > 0) {
+                    b_lo = std::min(b_lo, lo[m]);
+                    b_hi = std::max(b_hi, lo[m] + len[m]);
+                }
+            if (b_hi <= b_lo) continue;  // an all-zero tile: no k-steps
+            const int ks_lo = b_lo / 32, ks_hi = (b_hi + 31) / 32;
+            if (ks_hi - ks_lo > kMfmaKsMax || ks_hi * 32 > NC / 2) {
+                p->mfma_ok = 0;
+                break;
+            }
+            tile_ks[2 * t] = ks_lo;
+            tile_ks[2 * t + 1] = ks_hi - ks_lo;
+            p->mfma_kb = std::max(p->mfma_kb, ks_hi * 32);
+            for (int j = 0; j < ks_hi - ks_lo; ++j)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const int f = 32 * (ks_lo + j) + 8 * (l >> 4) + e, m = 16 * t + (l & 15);
+                        const float w = (f < n_bins && m < n_mel) ? 0.5f * p->mel[(size_t)f * n_mel + m] : 0.f;
+                        wfrag[(((size_t)t * kMfmaKsMax + j) * 64 + l) * 8 + e] = (_Float16)w;
+                    }
+        }
+        if (p->mfma_kb == 0) p->mfma_ok = 0;
+    }
+
     DeviceGuard guard(device);
     if (!guard.ok) {
         delete p;
@@ -420,7 +478,8 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
         (rc = upload(&p->d_band_lo, lo)) || (rc = upload(&p->d_band_len, len)) ||
         (rc = upload(&p->d_fband_lo, flo)) || (rc = upload(&p->d_wband, wband)) ||
         (rc = upload(&p->d_bin_band, bin_band)) || (rc = upload(&p->d_bin_w, bin_w)) ||
-        (rc = upload(&p->d_mel, p->mel))) {
+        (rc = upload(&p->d_mel, p->mel)) ||
+        (p->mfma_ok && ((rc = upload((_Float16**)&p->d_wfrag, wfrag)) || (rc = upload(&p->d_tile_ks, tile_ks))))) {
         iris_plan_destroy(p);
         return rc;
     }
@@ -536,8 +595,24 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
     (void)hipFree(p->d_bin_w);
     (void)hipFree(p->d_wband);
     (void)hipFree(p->d_mel);
+    (void)hipFree(p->d_wfrag);
+    (void)hipFree(p->d_tile_ks);
     (void)hipFree(p->d_ws);
     delete p;
+    return IRIS_OK;
+}
+
+extern "C" int iris_plan_set_mel_precision(iris_plan* p, int precision) {
+    if (!p) return fail(IRIS_E_INVALID, "iris_plan_set_mel_precision: NULL plan");
+    if (precision == IRIS_MEL_F32) {
+        p->mel_precision = 0;
+        return IRIS_OK;
+    }
+    if (precision != IRIS_MEL_F16_MFMA) return fail(IRIS_E_INVALID, "iris_plan_set_mel_precision: unknown precision %d", precision);
+    if (!p->mfma_ok || mfma_lds_bytes(p) > 160 * 1024)
+        return fail(IRIS_E_UNSUPPORTED, "fp16 MFMA mel needs n_fft 512/1024/2048, n_mel <= 128, bands inside the lower half "
+                                        "of the spectrum and <= 256 bins per 16 bands");
+    p->mel_precision = 1;
     return IRIS_OK;
 }
 

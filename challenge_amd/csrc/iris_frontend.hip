@@ -8,6 +8,7 @@
 //   iris_fft.h       the wave-per-frame FFT core (registers + private LDS exchanges)
 //   spectrum.h       frame loads, untangle (+ magnitude), the per-lane constant block
 //   k_fused.h        K1: waveform -> mel magnitudes (the hot path)
+//   k_fused_mfma.h   K1m: the same with the mel contraction on the matrix cores (fp16 MFMA variant)
 //   k_stft.h         STFT in the reference layout
 //   k_magmel.h       spectrum -> mel
 //   k_elementwise.h  min-max / log, normalize, magnitude-phase, mask, adaptive gradient clipping
@@ -17,6 +18,7 @@
 #include "common.h"
 #include "spectrum.h"
 #include "k_fused.h"
+#include "k_fused_mfma.h"
 #include "k_stft.h"
 #include "k_magmel.h"
 #include "k_elementwise.h"

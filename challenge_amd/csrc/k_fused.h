@@ -67,6 +67,11 @@ struct FusedArgs {
     int B, C, L, T, hop, M;
     int chunk_frames, chunks_per_clip, n_chunks;
     int chunk_base, chunk_rem;  // T = chunks_per_clip * chunk_base + chunk_rem; the first chunk_rem chunks take one more
+    // fp16-MFMA mel variant (k_fused_mfma.h): A fragments [tiles][8 k-steps][64 lanes][8 halfs], per tile
+    // (first k-step, k-step count), bins staged per frame (multiple of 32)
+    const void* wfrag;
+    const int* tile_ks;
+    int kb;
     int ablate;  // diagnostic only (IRIS_ABLATE): skip phases, results are wrong when non-zero
     unsigned long long* dbg;  // diagnostic only: [4] shader-clock / 100 MHz stamps of workgroup 0
 };

@@ -114,6 +114,11 @@ def augment_draw(n_time: int, n_freq: int, rng: Optional[np.random.Generator] = 
     return _tr.mask_draw(n_time, 24, 6, rng), _tr.mask_draw(n_freq, 16, 1, rng)
 
 
+def augment_draw_batch(batch: int, n_time: int, n_freq: int, rng: Optional[np.random.Generator] = None):
+    """The draws of `augment` for a whole batch, vectorised: (t_bands [B, 6, 2], f_bands [B, 1, 2])."""
+    return _tr.mask_draw_batch(batch, n_time, 24, 6, rng), _tr.mask_draw_batch(batch, n_freq, 16, 1, rng)
+
+
 def to_frame_labels(x, y):
     """[..., n_voices, n_frames, n_classes] -> [..., n_frames, n_classes] (data_utils.py:64-70)."""
     return x, torch.sum(y, dim=-3)

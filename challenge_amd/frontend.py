@@ -98,6 +98,7 @@ class FrontendPlan:
         N.check(rc, "iris_plan_create")
         self._handle = handle
         self._lock = threading.Lock()
+        self.mel_precision = "fp32"
 
     @classmethod
     def mel_only(cls, n_mel: int, n_bins: int, channels: int, max_batch: int, device,
@@ -122,6 +123,14 @@ class FrontendPlan:
         self._handle = handle
         self._lock = threading.Lock()
         return self
+
+    def set_mel_precision(self, precision: str = "fp32") -> None:
+        """'fp32' (default): banded fp32 mel reduction, 1e-5.  'fp16_mfma': |X| and W in fp16 on the matrix cores
+        (v_mfma_f32_16x16x32_f16, fp32 accumulate; BASELINE configs[4]), 2e-3; raises ValueError when the plan's
+        shape / filterbank cannot use it.  Calls that carry SpecAugment bands always run fp32."""
+        code = {"fp32": N.IRIS_MEL_F32, "fp16_mfma": N.IRIS_MEL_F16_MFMA}[precision]
+        N.check(N.lib().iris_plan_set_mel_precision(self._handle, code), "iris_plan_set_mel_precision")
+        self.mel_precision = precision
 
     def close(self) -> None:
         if self._handle is not None:

@@ -39,14 +39,62 @@ class _Stream:
         self._perm = np.empty(0, np.int64)
         self._pos = 0
 
-    def take(self, k: int) -> List[int]:
-        out = []
-        while len(out) < k:
+    def take(self, k: int) -> np.ndarray:
+        out = np.empty(k, np.int64)
+        got = 0
+        while got < k:
             if self._pos >= len(self._perm):
                 self._perm, self._pos = self.rng.permutation(self.n), 0
-            out.append(int(self._perm[self._pos]))
-            self._pos += 1
+            m = min(k - got, len(self._perm) - self._pos)
+            out[got:got + m] = self._perm[self._pos:self._pos + m]
+            got, self._pos = got + m, self._pos + m
         return out
+
+
+class BatchDraw:
+    """The random decisions of one batch as arrays (B samples, V = max_voices, N = max_noises):
+    bg [B], bg_offset [B], voices [B, V], v_len [B], n_voices [B], v_gain [B, V] f32, v_offset [B, V],
+    noises [B, N] | None, n_len [B], n_noises [B], n_gain [B, N] f32, n_offset [B, N]."""
+    __slots__ = ("bg", "bg_offset", "voices", "v_len", "n_voices", "v_gain", "v_offset", "noises", "n_len", "n_noises",
+                 "n_gain", "n_offset")
+
+    def __len__(self):
+        return int(self.bg.shape[0])
+
+    def as_dicts(self) -> List[dict]:
+        """Per-sample dicts in the layout of `pipeline.merge_draw` (what the oracle's apply takes)."""
+        out = []
+        for i in range(len(self)):
+            nv, nn = int(self.n_voices[i]), int(self.n_noises[i])
+            out.append({"bg": int(self.bg[i]), "bg_offset": int(self.bg_offset[i]), "voices": [int(v) for v in self.voices[i]],
+                        "v_len": int(self.v_len[i]), "n_voices": nv, "v_gain": [float(g) for g in self.v_gain[i, :nv]],
+                        "v_offset": [int(o) for o in self.v_offset[i, :nv]],
+                        "noises": None if self.noises is None else [int(n) for n in self.noises[i]],
+                        "n_len": int(self.n_len[i]), "n_noises": nn, "n_gain": [float(g) for g in self.n_gain[i, :nn]],
+                        "n_offset": [int(o) for o in self.n_offset[i, :nn]]})
+        return out
+
+    @classmethod
+    def from_dicts(cls, draws: List[dict], max_voices: int, max_noises: int) -> "BatchDraw":
+        b = len(draws)
+        d = cls()
+        d.bg = np.array([x["bg"] for x in draws], np.int64)
+        d.bg_offset = np.array([x["bg_offset"] for x in draws], np.int64)
+        d.voices = np.array([x["voices"] for x in draws], np.int64).reshape(b, max_voices)
+        d.v_len = np.array([x["v_len"] for x in draws], np.int64)
+        d.n_voices = np.array([x["n_voices"] for x in draws], np.int64)
+        d.v_gain, d.v_offset = np.zeros((b, max_voices), np.float32), np.zeros((b, max_voices), np.int64)
+        has_noise = b > 0 and draws[0]["noises"] is not None
+        d.noises = np.array([x["noises"] for x in draws], np.int64).reshape(b, max_noises) if has_noise else None
+        d.n_len = np.array([x["n_len"] for x in draws], np.int64)
+        d.n_noises = np.array([x["n_noises"] for x in draws], np.int64)
+        nn = max_noises if has_noise else 0
+        d.n_gain, d.n_offset = np.zeros((b, nn), np.float32), np.zeros((b, nn), np.int64)
+        for i, x in enumerate(draws):
+            d.v_gain[i, :x["n_voices"]], d.v_offset[i, :x["n_voices"]] = x["v_gain"], x["v_offset"]
+            if has_noise:
+                d.n_gain[i, :x["n_noises"]], d.n_offset[i, :x["n_noises"]] = x["n_gain"], x["n_offset"]
+        return d
 
 
 class DeviceMixer:
@@ -60,6 +108,8 @@ class DeviceMixer:
     reference's dataset graph: one background, the next `max_voices` voices and the next
     `max_noises` noises of shuffled, repeated streams; each group is zero-padded to its longest
     member (`padded_batch`), of which `merge_complex_specs` uses the first n_voices / n_noises.
+    The host side of a batch is a handful of vectorised NumPy draws and one structured-array fill
+    (no per-sample Python loop): ~0.1 ms for a batch of 64.
     """
 
     def __init__(self, backgrounds: Sequence, voices: Sequence, labels, noises: Optional[Sequence] = None,
@@ -107,57 +157,93 @@ class DeviceMixer:
                 N.check(N.lib().iris_mix_frame_active(v.data_ptr(), self.n_bins, int(v.shape[1]), self.chan2,
                                                       act.data_ptr(), stream), "iris_mix_frame_active")
                 self.voice_active.append(act)
-        # (pointer, frames) of every source, looked up per record when a batch's table is built
-        self._bg_rec = [(t.data_ptr(), int(t.shape[1])) for t in self.backgrounds]
-        self._v_rec = [(t.data_ptr(), a.data_ptr(), int(t.shape[1])) for t, a in zip(self.voices, self.voice_active)]
-        self._n_rec = [(t.data_ptr(), int(t.shape[1])) for t in self.noises] if self.noises is not None else []
+        # pointer / frame-count lookup tables of every source, indexed per batch when its table is built
+        self._bg_ptr = np.array([t.data_ptr() for t in self.backgrounds], np.uint64)
+        self._bg_T = np.array([int(t.shape[1]) for t in self.backgrounds], np.int64)
+        self._v_ptr = np.array([t.data_ptr() for t in self.voices], np.uint64)
+        self._v_act = np.array([a.data_ptr() for a in self.voice_active], np.uint64)
+        self._v_T = np.array([int(t.shape[1]) for t in self.voices], np.int64)
+        self._n_ptr = np.array([t.data_ptr() for t in self.noises], np.uint64) if self.noises is not None else None
+        self._n_T = np.array([int(t.shape[1]) for t in self.noises], np.int64) if self.noises is not None else None
         self._b = _Stream(len(self.backgrounds), self.rng)
         self._v = _Stream(len(self.voices), self.rng)
         self._n = _Stream(len(self.noises), self.rng) if self.noises is not None else None
 
     # -- random half ------------------------------------------------------------------
+    @staticmethod
+    def _padded_len(frames: np.ndarray, ratio: float, n_frame: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(pad, padded length) of a source of `frames` frames: pad = n_frame - int(ratio * frames) on both sides
+        when positive (pipeline.py:59-66, :95-101; the product is an fp32 one, truncated)."""
+        pad = n_frame - (np.float32(ratio) * frames.astype(np.float32)).astype(np.int64)
+        return pad, np.where(pad > 0, frames + 2 * pad, frames)
+
+    def draw_arrays(self, batch: int) -> BatchDraw:
+        """Which sources (dataset graph, pipeline.py:147-174) and the draws of merge_complex_specs
+        (`pipeline.merge_draw`, pipeline.py:29-106) for a whole batch, vectorised: the same distributions,
+        every sample independent.  Draws beyond a sample's n_voices / n_noises are made and ignored."""
+        rng, nf, V, Nn = self.rng, self.n_frame, self.max_voices, self.max_noises
+        d = BatchDraw()
+        d.bg = self._b.take(batch)
+        d.voices = self._v.take(batch * V).reshape(batch, V)
+        d.noises = self._n.take(batch * Nn).reshape(batch, Nn) if self._n is not None else None
+        d.v_len = self._v_T[d.voices].max(axis=1) if V else np.zeros(batch, np.int64)   # padded_batch: longest of the group
+        d.n_len = self._n_T[d.noises].max(axis=1) if (d.noises is not None and Nn) else np.zeros(batch, np.int64)
+        bg_T = self._bg_T[d.bg]
+        reps = (nf + bg_T - 1) // bg_T
+        d.bg_offset = rng.integers(0, reps * bg_T - nf + 1)                               # tf.image.random_crop, :35
+        d.n_voices = rng.integers(1, V, size=batch) if V > 1 else np.ones(batch, np.int64)  # :42-46
+        d.v_gain = np.power(np.float32(10.0), (-rng.uniform(0, -self.snr / 10, size=(batch, V))).astype(np.float32))  # :50
+        _, length = self._padded_len(d.v_len, self.min_ratio, nf)
+        maxval = (length - nf)[:, None]                                                   # :68-69
+        d.v_offset = np.where(maxval > 0, rng.integers(0, np.maximum(maxval, 1), size=(batch, V)), 0)
+        if d.noises is not None:
+            d.n_noises = rng.integers(0, Nn, size=batch) if Nn > 0 else np.zeros(batch, np.int64)  # :87-88
+            d.n_gain = np.power(np.float32(10.0), (-rng.uniform(0, 2, size=(batch, Nn))).astype(np.float32))  # :94
+            _, length = self._padded_len(d.n_len, self.min_noise_ratio, nf)
+            d.n_offset = rng.integers(0, (np.maximum(length - nf, 0) + 1)[:, None], size=(batch, Nn))  # :103
+        else:
+            d.n_noises = np.zeros(batch, np.int64)
+            d.n_gain, d.n_offset = np.zeros((batch, 0), np.float32), np.zeros((batch, 0), np.int64)
+        return d
+
     def draw(self, batch: int) -> List[dict]:
-        """Per sample: which sources (dataset graph, pipeline.py:147-174) and the draws of
-        merge_complex_specs (`pipeline.merge_draw`, pipeline.py:29-106)."""
-        out = []
-        for _ in range(batch):
-            bg = self._b.take(1)[0]
-            vs = self._v.take(self.max_voices)
-            ns = self._n.take(self.max_noises) if self._n is not None else None
-            v_len = max(self._v_rec[i][2] for i in vs)       # padded_batch: longest of the group
-            n_len = max(self._n_rec[i][1] for i in ns) if ns else 0
-            d = _pl.merge_draw(self._bg_rec[bg][1], [v_len] * len(vs),
-                               [n_len] * len(ns) if ns is not None else None, self.n_frame, self.min_ratio,
-                               self.min_noise_ratio, self.snr, rng=self.rng)
-            d.update(bg=bg, voices=vs, noises=ns, v_len=v_len, n_len=n_len)
-            out.append(d)
-        return out
+        """`draw_arrays` as per-sample dicts (the layout of `pipeline.merge_draw`)."""
+        return self.draw_arrays(batch).as_dicts()
 
     # -- deterministic half ----------------------------------------------------------
-    def table(self, draws: List[dict]) -> Tuple[np.ndarray, np.ndarray]:
-        """Source table (iris_mix_src records) and the per-sample ranges for a list of draws."""
-        recs, first = [], [0]
-        for d in draws:
-            ptr, frames = self._bg_rec[d["bg"]]
-            recs.append((ptr, 0, frames, 0, int(d["bg_offset"]), 1.0, KIND_BACKGROUND, 0, 0, 0))
-            pad = self.n_frame - int(np.float32(self.min_ratio) * np.float32(d["v_len"]))
-            for v in range(d["n_voices"]):
-                ptr, act, frames = self._v_rec[d["voices"][v]]
-                recs.append((ptr, act, frames, max(pad, 0), int(d["v_offset"][v]), np.float32(d["v_gain"][v]),
-                             KIND_VOICE, v, d["voices"][v], 0))
-            if d["noises"] is not None:
-                pad = self.n_frame - int(np.float32(self.min_noise_ratio) * np.float32(d["n_len"]))
-                for n in range(d["n_noises"]):
-                    ptr, frames = self._n_rec[d["noises"][n]]
-                    recs.append((ptr, 0, frames, max(pad, 0), int(d["n_offset"][n]), np.float32(d["n_gain"][n]),
-                                 KIND_NOISE, 0, 0, 0))
-            first.append(len(recs))
-        return np.array(recs, dtype=MIX_SRC), np.asarray(first, np.int32)
+    def table(self, draws) -> Tuple[np.ndarray, np.ndarray]:
+        """Source table (iris_mix_src records, sample-major: background, voices, noises) and the per-sample
+        ranges for a BatchDraw (or a list of per-sample dicts)."""
+        d = draws if isinstance(draws, BatchDraw) else BatchDraw.from_dicts(draws, self.max_voices, self.max_noises)
+        b, V = len(d), self.max_voices
+        Nn = self.max_noises if d.noises is not None else 0
+        cols = 1 + V + Nn
+        use = np.zeros((b, cols), bool)
+        use[:, 0] = True
+        use[:, 1:1 + V] = np.arange(V)[None, :] < d.n_voices[:, None]
+        if Nn:
+            use[:, 1 + V:] = np.arange(Nn)[None, :] < d.n_noises[:, None]
+        full = np.zeros((b, cols), MIX_SRC)
+        full["src"][:, 0], full["T"][:, 0], full["off"][:, 0] = self._bg_ptr[d.bg], self._bg_T[d.bg], d.bg_offset
+        full["gain"][:, 0], full["kind"][:, 0] = 1.0, KIND_BACKGROUND
+        pad_v, _ = self._padded_len(d.v_len, self.min_ratio, self.n_frame)
+        v = full[:, 1:1 + V]
+        v["src"], v["active"], v["T"] = self._v_ptr[d.voices], self._v_act[d.voices], self._v_T[d.voices]
+        v["pad"], v["off"], v["gain"] = np.maximum(pad_v, 0)[:, None], d.v_offset, d.v_gain
+        v["kind"], v["slot"], v["label_row"] = KIND_VOICE, np.arange(V)[None, :], d.voices
+        if Nn:
+            pad_n, _ = self._padded_len(d.n_len, self.min_noise_ratio, self.n_frame)
+            n = full[:, 1 + V:]
+            n["src"], n["T"] = self._n_ptr[d.noises], self._n_T[d.noises]
+            n["pad"], n["off"], n["gain"], n["kind"] = np.maximum(pad_n, 0)[:, None], d.n_offset, d.n_gain, KIND_NOISE
+        first = np.concatenate([[0], np.cumsum(use.sum(axis=1))]).astype(np.int32)
+        return np.ascontiguousarray(full[use]), first
 
-    def mix(self, batch: int, draws: Optional[List[dict]] = None):
+    def mix(self, batch: int, draws=None):
         """One batch of (complex spectrogram [B, F, n_frame, 2C], labels [B, max_voices, n_frame,
-        n_classes]) - `merge_complex_specs` (pipeline.py:6-110) for every sample, two launches."""
-        draws = self.draw(batch) if draws is None else draws
+        n_classes]) - `merge_complex_specs` (pipeline.py:6-110) for every sample, two launches.
+        draws: a BatchDraw or a list of per-sample dicts (default: a fresh `draw_arrays(batch)`)."""
+        draws = self.draw_arrays(batch) if draws is None else draws
         batch = len(draws)
         table, first = self.table(draws)
         n_srcs = int(table.shape[0])

@@ -245,8 +245,7 @@ def make_device_dataset(config, training=True, n_classes=3, sources=None, device
             b = int(x.shape[0])
             tb = fb = None
             if training:  # `augment` (data_utils.py:58-61): 6 time masks, 1 frequency mask per sample
-                draws = [_du.augment_draw(config.n_frame, mixer.n_bins, rng) for _ in range(b)]
-                tb, fb = np.stack([d[0] for d in draws]), np.stack([d[1] for d in draws])
+                tb, fb = _du.augment_draw_batch(b, config.n_frame, mixer.n_bins, rng)
             if filter_bins:  # stft_filter (data_utils.py:126-136): bins 1..k
                 flt = np.tile(np.array([[[1, filter_bins]]], np.int32), (b, 1, 1))
                 fb = flt if fb is None else np.concatenate([fb, flt], axis=1)
@@ -274,9 +273,7 @@ class WaveFrontend:
 
     def draw_bands(self, batch: int, n_time: int):
         """Host draw (NumPy Generator): exact integer distributions of transforms.py:25-26."""
-        tb = np.stack([_du.augment_draw(n_time, self.plan.n_bins, self.rng)[0] for _ in range(batch)])
-        fb = np.stack([_du.augment_draw(n_time, self.plan.n_bins, self.rng)[1] for _ in range(batch)])
-        return tb, fb
+        return _du.augment_draw_batch(batch, n_time, self.plan.n_bins, self.rng)
 
     def draw_bands_device(self, batch: int, n_time: int):
         """Device draw, no host round trip: size ~ U{0..max-1}, offset = floor(U[0,1) * (total - size))

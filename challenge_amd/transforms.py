@@ -60,6 +60,22 @@ def mask_draw(total: int, max_mask_size: Optional[int] = None, n_mask: int = 1,
     return bands
 
 
+def mask_draw_batch(batch: int, total: int, max_mask_size: Optional[int] = None, n_mask: int = 1,
+                    rng: Optional[np.random.Generator] = None) -> np.ndarray:
+    """`mask_draw` for a whole batch in two vectorised draws: int32 [batch, n_mask, 2] of (offset, size), every
+    (sample, mask) pair independent with the distributions of transforms.py:25-26."""
+    rng = _rng if rng is None else rng
+    if max_mask_size is None:
+        max_mask_size = total
+    if max_mask_size <= 0:
+        raise ValueError("mask: max_mask_size must be positive")
+    size = rng.integers(0, max_mask_size, size=(batch, n_mask))
+    if batch * n_mask and int(size.max()) >= total:
+        raise ValueError("mask: maxval must be > 0 (mask of size %d on an axis of %d)" % (int(size.max()), total))
+    off = rng.integers(0, total - size)  # array `high`: one independent draw per element
+    return np.stack([off, size], axis=-1).astype(np.int32)
+
+
 def mask_apply(specs: torch.Tensor, axis: int, bands) -> torch.Tensor:
     """specs with the bands [offset, offset+size) zeroed along `axis`, in specs.dtype."""
     return _fe.mask_apply(specs, axis, bands)

@@ -95,6 +95,18 @@ int iris_plan_create(iris_plan** out, int device, int n_fft, int hop, int n_mel,
                      int channels, int max_batch, int max_len, const float* mel_host);
 int iris_plan_destroy(iris_plan* plan);
 
+/*
+ * Precision of the mel contraction of iris_wav_to_logmel (transforms.py:65, tf.tensordot over the bin axis):
+ *   IRIS_MEL_F32       (default) banded fp32 reduction on the vector units, 1e-5 relative;
+ *   IRIS_MEL_F16_MFMA  |X| and W in fp16, v_mfma_f32_16x16x32_f16 with fp32 accumulation (BASELINE configs[4]);
+ *                      2e-3 relative.  Needs n_fft 512/1024/2048, n_mel <= 128, every band inside the lower
+ *                      half of the spectrum and <= 256 bins per group of 16 bands, else IRIS_E_UNSUPPORTED
+ *                      (the plan keeps its previous setting).  Calls with SpecAugment bands always run fp32.
+ */
+#define IRIS_MEL_F32 0
+#define IRIS_MEL_F16_MFMA 1
+int iris_plan_set_mel_precision(iris_plan* plan, int precision);
+
 /* Copy the plan's mel matrix [n_bins*n_mel] to HOST memory. */
 int iris_plan_get_mel(const iris_plan* plan, float* out_host);
 /* Frames for a clip of `len` samples: 1 + len / hop. */

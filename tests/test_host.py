@@ -315,3 +315,23 @@ def test_bench_gpus_argument_without_devices():
     r = subprocess.run([_sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2 and "GPU(s) visible" in r.stderr, (r.returncode, r.stderr[-300:])
+
+
+def test_batched_mask_draws_support_and_distribution():
+    """mask_draw_batch / augment_draw_batch: same support and marginals as the per-sample draw (transforms.py:25-26):
+    size ~ U{0..max-1}, offset ~ U{0..total-size-1}, hence offset + size <= total - 1 whenever size > 0."""
+    rng = np.random.default_rng(0)
+    b = T.mask_draw_batch(20000, 50, 24, 6, rng)
+    assert b.shape == (20000, 6, 2) and b.dtype == np.int32
+    off, size = b[..., 0], b[..., 1]
+    assert size.min() == 0 and size.max() == 23 and off.min() == 0 and np.all(off + size <= 49 + (size == 0) * 0)
+    assert np.all(off <= 50 - size - 1)
+    assert abs(size.mean() - 11.5) < 0.05                       # uniform on 0..23
+    full = off[size == 0]
+    assert full.max() == 49 and abs(full.mean() - 24.5) < 0.5    # uniform on 0..49 when size == 0
+    tb, fb = D.augment_draw_batch(7, 512, 257, rng)
+    assert tb.shape == (7, 6, 2) and fb.shape == (7, 1, 2) and fb[..., 1].max() < 16 and tb[..., 1].max() < 24
+    with pytest.raises(ValueError):
+        for _ in range(200):
+            T.mask_draw_batch(8, 4, 16, 1, rng)
+    assert T.mask_draw_batch(0, 10, 4, 2, rng).shape == (0, 2, 2)

@@ -204,9 +204,11 @@ def test_wave_frontend_matches_oracle(dev):
     fe = S.WaveFrontend(1024, 256, 64, 16000, 1, 4, 16000, dev, training=True, filter_bins=3)
     fe.rng = np.random.default_rng(9)
     out = fe(torch.from_numpy(wav).to(dev)).cpu().numpy()
-    check = np.random.default_rng(9)                # replay the draws
-    tb = np.stack([S._du.augment_draw(63, 513, check)[0] for _ in range(4)])
-    fb = np.stack([S._du.augment_draw(63, 513, check)[1] for _ in range(4)])
+    # replay the draws: ONE set per sample (6 time bands, then 1 frequency band, batch-vectorised) and nothing else
+    check = np.random.default_rng(9)
+    tb, fb = S._du.augment_draw_batch(4, 63, 513, check)
+    assert tb.shape == (4, 6, 2) and fb.shape == (4, 1, 2)
+    assert fe.rng.bit_generator.state == check.bit_generator.state  # the frontend consumed exactly these draws (round 1 drew twice)
     fb = np.concatenate([fb, np.tile(np.array([[[1, 3]]], np.int32), (4, 1, 1))], axis=1)
     ref = R.wav_to_logmel(wav, 1024, 256, 64, 16000, t_bands=tb, f_bands=fb)
     assert out.shape == ref.shape == (4, 64, 63, 1)
