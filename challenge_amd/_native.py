@@ -65,6 +65,11 @@ def lib() -> C.CDLL:
                         f"{LIB_PATH} is missing: the HIP frontend is not built "
                         "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
                         "`make -C challenge_amd/csrc`).  There is no CPU fallback.")
+                # torch first: its wheel bundles its own libamdhip64.so.7 + HSA runtime.  If this
+                # library were loaded before torch it would pull /opt/rocm's runtime in by
+                # RUNPATH, torch would then be bound to that one by soname but to its bundled
+                # HSA, and hipSetDevice fails.  One HIP runtime per process: torch's.
+                import torch  # noqa: F401
                 handle = C.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(handle, name)  # AttributeError if the symbol is absent
