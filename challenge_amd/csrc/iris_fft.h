@@ -21,8 +21,11 @@
 #ifndef IRIS_OLD_CMUL
 #define IRIS_OLD_CMUL 0
 #endif
-#ifndef IRIS_SINGLE_READS
-#define IRIS_SINGLE_READS 0
+// one ds_read_b64 per point (256 B/clk) instead of the merged ds_read2_b64 (128 B/clk) in the exchanges of
+// this n_fft (log2; 0 = none).  Measured per shape (scripts/gpu_shapes.py): n_fft 1024 -2.5 % (c2 17.9 -> 17.3 us),
+// every other size 1-5 % slower (twice the DS instructions to issue, fewer waves to hide them at 2048)
+#ifndef IRIS_SINGLE_READS_LOG2N
+#define IRIS_SINGLE_READS_LOG2N 10
 #endif
 
 namespace iris {
@@ -188,31 +191,36 @@ __device__ __forceinline__ void stage_fwd(cf (&x)[P], const cf* tw, cf* lds, int
     }
 }
 
-template <int P, int R, int NS>
+template <int P, int R, int NS, bool SINGLE = false>
 __device__ __forceinline__ void stage_load(cf (&x)[P], const cf* lds, int lane) {
     constexpr int PM = stage_pm(NS, R);
     const cf* rp = lds + lds_pad<PM>(lane);
-#if IRIS_SINGLE_READS
-    // volatile: keeps one ds_read_b64 per point (2 LDS cycles per 512 B) instead of the merged
-    // ds_read2_b64 (8 cycles per 1 KiB)
-    const volatile lds_cf* vp = (const volatile lds_cf*)rp;
+    if constexpr (SINGLE) {
+        // volatile: keeps one ds_read_b64 per point (2 LDS cycles per 512 B) instead of the merged
+        // ds_read2_b64 (8 cycles per 1 KiB)
+        const volatile lds_cf* vp = (const volatile lds_cf*)rp;
 #pragma unroll
-    for (int q = 0; q < P; ++q) x[q] = vp[lds_pad<PM>(kWave * q)];
-#else
+        for (int q = 0; q < P; ++q) x[q] = vp[lds_pad<PM>(kWave * q)];
+    } else {
 #pragma unroll
-    for (int q = 0; q < P; ++q) x[q] = rp[lds_pad<PM>(kWave * q)];
-#endif
+        for (int q = 0; q < P; ++q) x[q] = rp[lds_pad<PM>(kWave * q)];
+    }
 }
 
 // The same stage for S streams: all butterflies and writes, one ordering point, all reads.
-template <int S, int P, int R, int NS, bool LAST>
+// timing experiment only (results are wrong): every stage keeps its outputs in registers, no LDS exchange
+#ifndef IRIS_NO_EXCHANGE
+#define IRIS_NO_EXCHANGE 0
+#endif
+template <int S, int P, int R, int NS, bool LAST_, bool SINGLE = false>
 __device__ __forceinline__ void stage_multi(cf (&x)[S][P], const cf* tw, cf* const (&lds)[S], int lane) {
+    constexpr bool LAST = LAST_ || (IRIS_NO_EXCHANGE != 0);
 #pragma unroll
     for (int s = 0; s < S; ++s) stage_fwd<P, R, NS, LAST>(x[s], tw, lds[s], lane);
     if constexpr (!LAST) {
         wave_sync_lds();
 #pragma unroll
-        for (int s = 0; s < S; ++s) stage_load<P, R, NS>(x[s], lds[s], lane);
+        for (int s = 0; s < S; ++s) stage_load<P, R, NS, SINGLE>(x[s], lds[s], lane);
         wave_sync_lds();
     }
 }
@@ -240,30 +248,31 @@ struct FftCfg<8> {  // n_fft 256: NC 128 = 2^7
 
 // Complex FFT of S frames held by one wave (S = 1: one frame; S = 2: two frames in flight, so
 // that the LDS round trip of one hides behind the butterflies of the other).
-template <int LOG2N, int S>
+// SINGLE: one ds_read_b64 per point in the exchanges (see IRIS_SINGLE_READS_LOG2N; the fused kernel asks for it)
+template <int LOG2N, int S, bool SINGLE = false>
 __device__ __forceinline__ void fft_frames(cf (&x)[S][FftCfg<LOG2N>::P], const cf* tw, cf* const (&lds)[S],
                                            int lane) {
     if constexpr (LOG2N == 11) {
-        stage_multi<S, 16, 16, 1, false>(x, nullptr, lds, lane);
-        stage_multi<S, 16, 16, 16, false>(x, tw, lds, lane);
-        stage_multi<S, 16, 4, 256, true>(x, tw + 15, lds, lane);
+        stage_multi<S, 16, 16, 1, false, SINGLE>(x, nullptr, lds, lane);
+        stage_multi<S, 16, 16, 16, false, SINGLE>(x, tw, lds, lane);
+        stage_multi<S, 16, 4, 256, true, SINGLE>(x, tw + 15, lds, lane);
     } else if constexpr (LOG2N == 10) {
-        stage_multi<S, 8, 8, 1, false>(x, nullptr, lds, lane);
-        stage_multi<S, 8, 8, 8, false>(x, tw, lds, lane);
-        stage_multi<S, 8, 8, 64, true>(x, tw + 7, lds, lane);
+        stage_multi<S, 8, 8, 1, false, SINGLE>(x, nullptr, lds, lane);
+        stage_multi<S, 8, 8, 8, false, SINGLE>(x, tw, lds, lane);
+        stage_multi<S, 8, 8, 64, true, SINGLE>(x, tw + 7, lds, lane);
     } else if constexpr (LOG2N == 9) {
-        stage_multi<S, 4, 4, 1, false>(x, nullptr, lds, lane);
-        stage_multi<S, 4, 4, 4, false>(x, tw, lds, lane);
-        stage_multi<S, 4, 4, 16, false>(x, tw + 3, lds, lane);
-        stage_multi<S, 4, 4, 64, true>(x, tw + 6, lds, lane);
+        stage_multi<S, 4, 4, 1, false, SINGLE>(x, nullptr, lds, lane);
+        stage_multi<S, 4, 4, 4, false, SINGLE>(x, tw, lds, lane);
+        stage_multi<S, 4, 4, 16, false, SINGLE>(x, tw + 3, lds, lane);
+        stage_multi<S, 4, 4, 64, true, SINGLE>(x, tw + 6, lds, lane);
     } else {
-        stage_multi<S, 2, 2, 1, false>(x, nullptr, lds, lane);
-        stage_multi<S, 2, 2, 2, false>(x, tw + 0, lds, lane);
-        stage_multi<S, 2, 2, 4, false>(x, tw + 1, lds, lane);
-        stage_multi<S, 2, 2, 8, false>(x, tw + 2, lds, lane);
-        stage_multi<S, 2, 2, 16, false>(x, tw + 3, lds, lane);
-        stage_multi<S, 2, 2, 32, false>(x, tw + 4, lds, lane);
-        stage_multi<S, 2, 2, 64, true>(x, tw + 5, lds, lane);
+        stage_multi<S, 2, 2, 1, false, SINGLE>(x, nullptr, lds, lane);
+        stage_multi<S, 2, 2, 2, false, SINGLE>(x, tw + 0, lds, lane);
+        stage_multi<S, 2, 2, 4, false, SINGLE>(x, tw + 1, lds, lane);
+        stage_multi<S, 2, 2, 8, false, SINGLE>(x, tw + 2, lds, lane);
+        stage_multi<S, 2, 2, 16, false, SINGLE>(x, tw + 3, lds, lane);
+        stage_multi<S, 2, 2, 32, false, SINGLE>(x, tw + 4, lds, lane);
+        stage_multi<S, 2, 2, 64, true, SINGLE>(x, tw + 5, lds, lane);
     }
 }
 

@@ -41,6 +41,15 @@ constexpr int fused_occ(int log2n) { return 1; }
 #ifndef IRIS_W2048
 #define IRIS_W2048 8
 #endif
+// experiment switches: constants requested before the first frames (they are L2 hits and must not
+// queue behind the HBM misses of the frame loads: loads return in order); one touch load per wave
+// that pulls the chunk's whole waveform segment into this XCD's L2 at chunk start
+#ifndef IRIS_CONSTS_FIRST
+#define IRIS_CONSTS_FIRST 0
+#endif
+#ifndef IRIS_TOUCH
+#define IRIS_TOUCH 0
+#endif
 // frames go global -> registers up to this n_fft (log2); above it through LDS-DMA landing buffers
 #ifndef IRIS_DIRECT_MAX
 #define IRIS_DIRECT_MAX 10
@@ -251,11 +260,40 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
             }
     };
     int f[S], fn[S];  // frames in registers / frames in flight to the landing buffers
+    // One load per lane and cache line over the chunk's waveform segment (all channels): the lines start
+    // their way from HBM into this XCD's L2 now, at the full rate of the memory system, instead of one
+    // frame per wave and HBM round trip; the frame loads that follow hit the L2.  The loaded words are
+    // consumed (an empty asm) after the next frame's samples have arrived - loads return in order.
+    float touched[2] = {0.f, 0.f};  // at most two loads per wave and chunk (128 KiB of waveform per chunk)
+    auto touch_chunk = [&](int b, int t0, int nt) {
+        if constexpr (IRIS_TOUCH != 0) {
+            const int s0 = max(t0 * a.hop - N / 2, 0) & ~15, s1 = min((t0 + nt - 1) * a.hop + N / 2, a.L);
+            const int lines = (s1 - s0 + 15) >> 4, total = lines * a.C;
+            const float* seg = a.wav + (size_t)b * a.C * a.L + s0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int li = min((wv + i * kFusedWaves) * kWave + lane, total - 1);
+                const int c = (a.C == 1) ? 0 : li / lines, l = li - c * lines;
+                touched[i] = seg[(size_t)c * a.L + min(l * 16, s1 - s0 - 1)];
+            }
+        }
+    };
+    constexpr int kStageN = ConstLayout<LOG2N>::NV4 * kWave, kStagePer = (kStageN + 64 * kFusedWaves - 1) / (64 * kFusedWaves);
+    constexpr bool kConstsFirst = IRIS_CONSTS_FIRST != 0 && kStagePer <= 2;  // (n_fft 2048 would spill)
+    float4 cstage[kStagePer];
+    if constexpr (kConstsFirst) {
+        const float4* g = reinterpret_cast<const float4*>(a.consts);
+#pragma unroll
+        for (int i = 0; i < kStagePer; ++i) {
+            cstage[i] = g[min((int)threadIdx.x + i * 64 * kFusedWaves, kStageN - 1)];
+        }
+    }
     if (g0 < a.n_chunks) {  // first frames of the first chunk: in flight while the constants are fetched
         const int b = chunk_clip(g0);
 #pragma unroll
         for (int st = 0; st < S; ++st) f[st] = wv * S + st;
         issue_dma(f, b, chunk_t0(g0, b), chunk_nt(g0, b) * a.C);
+        touch_chunk(b, chunk_t0(g0, b), chunk_nt(g0, b));
     }
     {
         // The constant block is the same for every wave: fetch it from global once per workgroup.
@@ -266,7 +304,14 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
         static_assert(!DIRECT || kLandBytes >= kStageBytes, "constant block does not fit the landing area");
         float4* stage = reinterpret_cast<float4*>(DIRECT ? smem : xbuf0);
         const float4* g = reinterpret_cast<const float4*>(a.consts);
-        for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
+        if constexpr (kConstsFirst) {
+            (void)g;
+#pragma unroll
+            for (int i = 0; i < kStagePer; ++i)
+                if ((int)threadIdx.x + i * 64 * kFusedWaves < kStageN) stage[threadIdx.x + i * 64 * kFusedWaves] = cstage[i];
+        } else {
+            for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
+        }
         if (threadIdx.x == 0) *next_frame = 2 * kFusedWaves * S;
         if constexpr (BANDS) {
             if (a.t_bands && g0 < a.n_chunks) {
@@ -314,7 +359,10 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
             f[st] = wv * S + st;
             fn[st] = (kFusedWaves + wv) * S + st;  // second round is static too: the queue starts at 2 * waves * S
         }
-        if (chunk != g0) issue_dma(f, b, t0, nwf);
+        if (chunk != g0) {
+            issue_dma(f, b, t0, nwf);
+            touch_chunk(b, t0, nt);
+        }
         bool mbit[S];             // the frames in f[] lie in a time band (wave-uniform)
 #pragma unroll
         for (int st = 0; st < S; ++st) mbit[st] = false;
@@ -477,7 +525,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
             for (int st = 0; st < S; ++st)
 #pragma unroll
                 for (int q = 0; q < P; ++q) x[st][q] *= win[q];
-            if (!ABL(1)) fft_frames<LOG2N, S>(x, tw, lds, lane);
+            if (!ABL(1)) fft_frames<LOG2N, S, LOG2N == IRIS_SINGLE_READS_LOG2N>(x, tw, lds, lane);
             PH_MARK(3);
             // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)
             if (!ABL(2)) untangle_mag<LOG2N, HI, S>(x, post, lds, magbuf, lane);
@@ -578,6 +626,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
             if ABL(4096) ph[7] += 1;
         }
         PH_BEGIN();
+        if constexpr (IRIS_TOUCH != 0) asm volatile("" ::"v"(touched[0]), "v"(touched[1]));
         // every wave leaves its own (min, max) partial for k_minmax_log_apply
         mn = wave_min(mn);
         mx = wave_max(mx);

@@ -88,11 +88,16 @@ __device__ __forceinline__ float cabs_rn(cf v) { return __builtin_amdgcn_sqrtf(f
 // its exchange buffer: the partner rows P/2.. live above byte 8 * lds_pad(NC/2) > 4 * (NC + 1),
 // so magnitudes can land while partner reads are still queued - a wave's DS ops run in order).
 // No complex outputs are kept: each bin's registers die as soon as its magnitude is stored.
+// timing experiment only (results are wrong): partners taken from the lane's own registers, no LDS exchange
+#ifndef IRIS_NO_UNTANGLE_X
+#define IRIS_NO_UNTANGLE_X 0
+#endif
 template <int LOG2N, bool HI, int S>
 __device__ __forceinline__ void untangle_mag(const cf (&x)[S][FftCfg<LOG2N>::P], const cf* post, cf* const (&lds)[S],
                                              float* const (&mag)[S], int lane) {
     constexpr int P = FftCfg<LOG2N>::P, NC = (1 << LOG2N) / 2;
     static_assert(8 * lds_pad<1>(NC / 2) >= 4 * (NC + 1), "magnitudes would overwrite partner rows");
+#if !IRIS_NO_UNTANGLE_X
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         cf* wp = lds[s] + lds_pad<1>(lane);
@@ -100,17 +105,24 @@ __device__ __forceinline__ void untangle_mag(const cf (&x)[S][FftCfg<LOG2N>::P],
         for (int q = P / 2; q < P; ++q) wp[lds_pad<1>(kWave * q)] = x[s][q];
     }
     wave_sync_lds();
+#endif
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const cf* rp = lds[s] + lds_pad<1>(kWave - lane);
         cf zp[P / 2];
-#if IRIS_SINGLE_READS
-        const volatile lds_cf* vp = (const volatile lds_cf*)rp;
+#if IRIS_NO_UNTANGLE_X
+        (void)rp;
 #pragma unroll
-        for (int q = 0; q < P / 2; ++q) zp[q] = vp[lds_pad<1>(kWave * (P - 1 - q))];
+        for (int q = 0; q < P / 2; ++q) zp[q] = x[s][P - 1 - q];
 #else
+        if constexpr (LOG2N == IRIS_SINGLE_READS_LOG2N) {
+            const volatile lds_cf* vp = (const volatile lds_cf*)rp;
 #pragma unroll
-        for (int q = 0; q < P / 2; ++q) zp[q] = rp[lds_pad<1>(kWave * (P - 1 - q))];
+            for (int q = 0; q < P / 2; ++q) zp[q] = vp[lds_pad<1>(kWave * (P - 1 - q))];
+        } else {
+#pragma unroll
+            for (int q = 0; q < P / 2; ++q) zp[q] = rp[lds_pad<1>(kWave * (P - 1 - q))];
+        }
 #endif
         if (lane == 0) zp[0] = x[s][0];  // k = 0 pairs with itself
         if constexpr (HI) {
