@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (batch sweep, cache-resident replay, c3 forward, c4 training step)")
     ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--only-sweep", action="store_true", help="of the side measurements, run only the K1 batch sweep (A/B runs)")
     ap.add_argument("--resident", action="store_true",
                     help="replay ONE batch every step (Infinity-Cache resident, as round 1 measured) instead of rotating")
     args = ap.parse_args()
@@ -349,7 +350,9 @@ def main():
         "stft_mel_fwd_audio_s_per_s": None,
     }
     extras = None
-    if not args.no_extras:
+    if args.only_sweep and world == 1:
+        extras = {"k1_batch_sweep": batch_sweep(dev, fence, max(args.extra_steps, 20))}
+    elif not args.no_extras:
         extras = side_measurements(dev, rank, world, args.extra_steps, fence)
         if world == 1:
             extras["k1_batch_sweep"] = batch_sweep(dev, fence, max(args.extra_steps, 20))
@@ -372,7 +375,8 @@ def main():
     if rank == 0:
         if extras:
             result["extra"] = extras
-            result["stft_mel_fwd_audio_s_per_s"] = extras["c3_frontend_specaug_crnn_fwd"]["audio_s_per_s"]
+            if "c3_frontend_specaug_crnn_fwd" in extras:
+                result["stft_mel_fwd_audio_s_per_s"] = extras["c3_frontend_specaug_crnn_fwd"]["audio_s_per_s"]
         algo_bytes = ALGO_BYTES_PER_AUDIO_S * audio_s_per_step  # per launch
         achieved = (algo_bytes / (kernel_ms * 1e-3) / 1e9) if n_ev and kernel_ms > 0 else None
         kernel_key = "k_wav_to_mel<10,0,false,false,1>"

@@ -41,6 +41,9 @@ constexpr int fused_occ(int log2n) { return 1; }
 #ifndef IRIS_W2048
 #define IRIS_W2048 8
 #endif
+#ifndef IRIS_S2_WAVES
+#define IRIS_S2_WAVES 8
+#endif
 // experiment switches: constants requested before the first frames (they are L2 hits and must not
 // queue behind the HBM misses of the frame loads: loads return in order); one touch load per wave
 // that pulls the chunk's whole waveform segment into this XCD's L2 at chunk start
@@ -56,7 +59,7 @@ constexpr int fused_occ(int log2n) { return 1; }
 #endif
 constexpr bool fused_direct(int log2n) { return IRIS_DIRECT_LOAD && log2n <= IRIS_DIRECT_MAX; }
 constexpr int fused_waves(int log2n, int streams = 1, bool bands = false) {
-    return streams > 1 ? 8 : (log2n >= 11 ? IRIS_W2048 : (log2n == 10 ? (bands ? 12 : IRIS_W1024) : 16));
+    return streams > 1 ? IRIS_S2_WAVES : (log2n >= 11 ? IRIS_W2048 : (log2n == 10 ? (bands ? 12 : IRIS_W1024) : 16));
 }
 
 struct FusedArgs {
