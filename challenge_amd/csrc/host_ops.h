@@ -51,7 +51,8 @@ extern "C" int iris_stft(iris_plan* p, const float* wav, float* spec, int batch,
     // tile = as many frames as the LDS left by the waves' exchange buffers holds (one workgroup per
     // CU owns the whole 160 KiB); at least the constant block must fit (it is staged through the tile)
     const size_t xbufs = (size_t)waves * ((wave_buf_bytes(p->log2n) + 15) & ~(size_t)15);
-    const size_t room = 160 * 1024 - 1024 - xbufs;
+    const int wgs = stft_wgs(p->log2n);  // workgroups per CU
+    const size_t room = (160 * 1024 - 1024) / wgs - xbufs;
     auto tile_bytes = [&](int t) { return (size_t)F * ((size_t)t * C2 + 1) * 4; };
     int tf = 1;
     while (tf < 256 && tile_bytes(tf + 1) <= room) ++tf;
@@ -61,13 +62,13 @@ extern "C" int iris_stft(iris_plan* p, const float* wav, float* spec, int batch,
     if (tf > per_round) tf -= tf % per_round;
     a.tile_frames = tf;
     int chunk_frames = 0;
-    fused_geometry(p, batch, a.T, 1, &chunk_frames, &a.chunks_per_clip);  // K1's balanced chunks, one per CU
+    fused_geometry(p, batch, a.T, wgs, &chunk_frames, &a.chunks_per_clip);  // K1's balanced chunks, one per workgroup
     a.chunk_base = a.T / a.chunks_per_clip;
     a.chunk_rem = a.T % a.chunks_per_clip;
     a.n_chunks = batch * a.chunks_per_clip;
     const size_t lds = xbufs + std::max(tile_bytes(tf), (size_t)const_nv4(p->log2n) * 64 * 16);
     if (lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_stft: %zu B of LDS", lds);
-    const int grid = std::min(a.n_chunks, p->num_cu);
+    const int grid = std::min(a.n_chunks, p->num_cu * wgs);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     switch (p->log2n) {

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
     // consumed (an empty asm) after the next frame's samples have arrived - loads return in order.
     float touched[2] = {0.f, 0.f};  // at most two loads per wave and chunk (128 KiB of waveform per chunk)
     auto touch_chunk = [&](int b, int t0, int nt) {
-        if constexpr (IRIS_TOUCH != 0) {
+        if constexpr (IRIS_TOUCH == 1) {
             const int s0 = max(t0 * a.hop - N / 2, 0) & ~15, s1 = min((t0 + nt - 1) * a.hop + N / 2, a.L);
             const int lines = (s1 - s0 + 15) >> 4, total = lines * a.C;
             const float* seg = a.wav + (size_t)b * a.C * a.L + s0;
@@ -446,6 +446,10 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
             issue_dma(fn, b, t0, nwf);
         }
         PH_MARK(8);
+        if constexpr (IRIS_TOUCH == 2 && DIRECT && S == 1) {  // both edges into the loop arrive with the samples waited for
+#pragma unroll
+            for (int q = 0; q < P; ++q) asm volatile("" : "+v"(x[0][q]));
+        }
         while (f[0] < nwf) {
             PH_BEGIN();
             int fcur[S];
@@ -497,6 +501,24 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
 #pragma unroll
                     for (int st = 0; st < S; ++st) fn[st] = claimed + st;
                     if constexpr (!DIRECT) issue_dma(fn, b, t0, nwf);
+                }
+                if constexpr (IRIS_TOUCH == 2 && DIRECT && S == 1) {
+                    // rolling L2 touch: the frame just claimed is loaded one iteration from now and used two
+                    // from now; its newest hop (the only part no earlier frame has fetched) starts its way
+                    // from HBM now - one lane per 64-byte line.  The word loaded a whole iteration ago is
+                    // consumed first (it has long returned; loads return in order, so the counted wait for
+                    // the frame samples at the loop top leaves this one in flight).
+                    asm volatile("" ::"v"(touched[0]));
+                    // the next frame's samples are waited for HERE (the iteration is over anyway), so that the
+                    // loop top needs no wait and the touch issued below stays in flight across it
+#pragma unroll
+                    for (int q = 0; q < P; ++q) asm volatile("" : "+v"(x[0][q]));
+                    if (more && fn[0] < nwf) {
+                        const int tl = (a.C == 1) ? fn[0] : fn[0] / a.C, c = fn[0] - tl * a.C;
+                        const int nl = a.hop >> 4;
+                        const int smp = min((t0 + tl) * a.hop + N / 2 - a.hop + min(lane, nl - 1) * 16, a.L - 1);
+                        touched[0] = a.wav[((size_t)b * a.C + c) * a.L + smp];
+                    }
                 }
             };
             bool masked[S];

@@ -24,10 +24,24 @@ struct StftArgs {
 };
 
 // (n_fft 2048 keeps 16 points per lane and both spectrum halves: it needs more than 256 registers)
-constexpr int stft_waves(int log2n) { return log2n >= 11 ? 4 : (log2n <= 9 ? 16 : 12); }
+// Workgroups per CU: with two half-size workgroups the transform phase of one overlaps the write-out phase of
+// the other (inside a workgroup the two phases are separated by barriers, so all its waves are in the same one).
+#ifndef IRIS_STFT_NT
+#define IRIS_STFT_NT 0
+#endif
+#if IRIS_STFT_NT
+#define STFT_ST "global_store_dword %0, %1, %2 nt"
+#else
+#define STFT_ST "global_store_dword %0, %1, %2"
+#endif
+#ifndef IRIS_STFT_WGS
+#define IRIS_STFT_WGS 1
+#endif
+constexpr int stft_wgs(int log2n) { return log2n >= 11 ? 1 : IRIS_STFT_WGS; }
+constexpr int stft_waves(int log2n) { return (log2n >= 11 ? 4 : (log2n <= 9 ? 16 : 12)) / stft_wgs(log2n); }
 
 template <int LOG2N>
-__global__ __launch_bounds__(64 * stft_waves(LOG2N), stft_waves(LOG2N) / 4) void k_stft(const StftArgs a) {
+__global__ __launch_bounds__(64 * stft_waves(LOG2N), stft_waves(LOG2N) * stft_wgs(LOG2N) / 4) void k_stft(const StftArgs a) {
     constexpr int W = stft_waves(LOG2N);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
     constexpr int F = NC + 1;
@@ -123,13 +137,13 @@ __global__ __launch_bounds__(64 * stft_waves(LOG2N), stft_waves(LOG2N) / 4) void
                     for (int j = 0; j < 4; ++j) v[j] = tile_out[(k + j * W) * row + r];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v[j]),
+                        asm volatile(STFT_ST ::"v"(off), "v"(v[j]),
                                      "s"(out0 + (size_t)(k + j * W) * pitch)
                                      : "memory");
                 }
                 for (; k < F; k += W) {
                     const float v = tile_out[k * row + r];
-                    asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(out0 + (size_t)k * pitch)
+                    asm volatile(STFT_ST ::"v"(off), "v"(v), "s"(out0 + (size_t)k * pitch)
                                  : "memory");
                 }
             }

@@ -5,7 +5,7 @@
 #        python scripts/pmc_summarise.py   (-> profiles/r2/pmc_traffic.json)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${PMC_OUT:-pmc}
 rm -rf $OUT; mkdir -p $OUT
 i=0
 for grp in "$@"; do
