@@ -61,11 +61,12 @@ def merge_draw(bg_frame: int, voice_frames, noise_frames=None, n_frame: int = 30
 def merge_complex_specs_apply(background, voices, labels, noises, draws, n_frame=300, n_classes=3,
                               min_ratio=2 / 3, min_noise_ratio=1 / 2, seperate_noise_voice=False):
     """Deterministic part of merge_complex_specs (t_axis = 1).  Device tensors take the HIP path
-    (`iris_mix_specs`, a handful of launches instead of ~15 torch ops per voice); CPU tensors and
-    `seperate_noise_voice` use the op-by-op torch form below.  Both equal the oracle bit for bit."""
-    if background.is_cuda and not seperate_noise_voice and voices.is_cuda and (noises is None or noises.is_cuda):
+    (`iris_mix_specs`, a handful of launches instead of ~15 torch ops per voice; with
+    `seperate_noise_voice` the same kernels run over three source tables: everything, the voices alone,
+    background + noises); CPU tensors use the op-by-op torch form below.  Both equal the oracle bit for bit."""
+    if background.is_cuda and voices.is_cuda and (noises is None or noises.is_cuda):
         return _merge_apply_hip(background, voices, labels, noises, draws, n_frame, n_classes, min_ratio,
-                                min_noise_ratio)
+                                min_noise_ratio, seperate_noise_voice)
     bg_frame = background.shape[1]
     reps = (n_frame + bg_frame - 1) // bg_frame
     tiled = background.repeat(1, reps, 1)
@@ -114,8 +115,12 @@ def merge_complex_specs_apply(background, voices, labels, noises, draws, n_frame
     return complex_spec, label
 
 
-def _merge_apply_hip(background, voices, labels, noises, draws, n_frame, n_classes, min_ratio, min_noise_ratio):
-    """One sample through the batched synthesis kernels (include/iris_frontend.h: iris_mix_specs)."""
+def _merge_apply_hip(background, voices, labels, noises, draws, n_frame, n_classes, min_ratio, min_noise_ratio,
+                     seperate_noise_voice=False):
+    """One sample through the batched synthesis kernels (include/iris_frontend.h: iris_mix_specs).
+    `seperate_noise_voice` (pipeline.py:38-39, :80-81, :104-108): only_voice is the sum over a table holding the
+    voices alone (accepted by the same label rule; 0 + x is exact), only_noise the sum over background + noises -
+    each the same op-by-op order as the reference's running sums."""
     import ctypes as C
 
     from . import _native as N
@@ -148,19 +153,29 @@ def _merge_apply_hip(background, voices, labels, noises, draws, n_frame, n_class
             for n in range(draws["n_noises"]):
                 recs.append((noises[n].data_ptr(), 0, ns_frame, max(pad, 0), int(draws["n_offset"][n]),
                              np.float32(draws["n_gain"][n]), KIND_NOISE, 0, 0, 0))
-        table = np.array(recs, dtype=MIX_SRC)
-        table_d = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(dev)
-        first_d = torch.tensor([0, len(recs)], dtype=torch.int32, device=dev)
-        spec = torch.empty((1, n_bins, n_frame, chan2), device=dev, dtype=torch.float32)
-        label = torch.empty((1, max_voices, n_frame, n_classes), device=dev, dtype=torch.float32)
-        ws_floats = int(lib.iris_mix_workspace(len(recs), n_frame))
-        ws = torch.empty(max(ws_floats, 1), device=dev, dtype=torch.float32)
-        N.check(lib.iris_mix_specs(table_d.data_ptr(), len(recs), first_d.data_ptr(), label_vecs.data_ptr(),
-                                   spec.data_ptr(), label.data_ptr(), 1, n_bins, n_frame, chan2, max_voices, n_classes,
-                                   ws.data_ptr(), ws_floats, stream), "iris_mix_specs")
-        for t in keep + [table_d, first_d, ws]:
+
+        def mix(rows):
+            table = np.array(rows, dtype=MIX_SRC)
+            table_d = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(dev)
+            first_d = torch.tensor([0, len(rows)], dtype=torch.int32, device=dev)
+            spec = torch.empty((1, n_bins, n_frame, chan2), device=dev, dtype=torch.float32)
+            label = torch.empty((1, max_voices, n_frame, n_classes), device=dev, dtype=torch.float32)
+            ws_floats = int(lib.iris_mix_workspace(len(rows), n_frame))
+            ws = torch.empty(max(ws_floats, 1), device=dev, dtype=torch.float32)
+            N.check(lib.iris_mix_specs(table_d.data_ptr(), len(rows), first_d.data_ptr(), label_vecs.data_ptr(),
+                                       spec.data_ptr(), label.data_ptr(), 1, n_bins, n_frame, chan2, max_voices,
+                                       n_classes, ws.data_ptr(), ws_floats, stream), "iris_mix_specs")
+            keep.extend([table_d, first_d, ws])
+            return spec[0], label[0]
+
+        spec, label = mix(recs)
+        if seperate_noise_voice:
+            only_voice, _ = mix([r for r in recs if r[6] == KIND_VOICE])
+            only_noise, _ = mix([r for r in recs if r[6] != KIND_VOICE])
+            label = (label, only_voice, only_noise)
+        for t in keep:
             t.record_stream(torch.cuda.current_stream(dev))
-    return spec[0], label[0]
+    return spec, label
 
 
 def merge_complex_specs(background, voices_and_labels, noises=None, n_frame=300, n_classes=3, t_axis=1,

@@ -461,18 +461,22 @@ def phase_vocoder(complex_spec: np.ndarray, rate: float = 1.0) -> np.ndarray:
 # --------------------------------------------------------------------------
 def merge_complex_specs_apply(background, voices, labels, noises, draws,
                               n_frame=300, n_classes=3, min_ratio=2 / 3,
-                              min_noise_ratio=1 / 2):
+                              min_noise_ratio=1 / 2, seperate_noise_voice=False):
     """pipeline.py:6-110 (t_axis=1) with every random draw supplied in `draws`:
     {'bg_offset': int, 'n_voices': int, 'v_gain': [..], 'v_offset': [..],
      'n_noises': int, 'n_gain': [..], 'n_offset': [..]}.
     voices: list/array of [F, t_v, 2C]; labels [V, K]; noises list or None.
-    Returns (spec [F, n_frame, 2C], label [V, n_frame, K])."""
+    Returns (spec [F, n_frame, 2C], label [V, n_frame, K]); with
+    seperate_noise_voice (pipeline.py:38-39, :80-81, :104-108) the label is
+    (label, only_voice, only_noise): the accepted voices alone (from zeros) and
+    the background crop plus the noises."""
     background = np.asarray(background, np.float32)
     bg_frame = background.shape[1]
     reps = (n_frame + bg_frame - 1) // bg_frame
     tiled = np.tile(background, (1, reps, 1))
     o = draws['bg_offset']
     spec = tiled[:, o:o + n_frame].copy()
+    only_voice, only_noise = np.zeros_like(spec), spec.copy()
     max_voices = len(voices)
     label = np.zeros((max_voices, n_frame, n_classes), np.float32)
     for v in range(draws['n_voices']):
@@ -492,6 +496,8 @@ def merge_complex_specs_apply(background, voices, labels, noises, draws,
         l3[v] = l
         no_overlap = np.float32((label + l3).sum(axis=0).max() < 2)
         spec += np.float32(draws['v_gain'][v]) * voice * no_overlap
+        if seperate_noise_voice:
+            only_voice += np.float32(draws['v_gain'][v]) * voice * no_overlap
         label += l3 * no_overlap
     if noises is not None:
         for n in range(draws['n_noises']):
@@ -501,7 +507,11 @@ def merge_complex_specs_apply(background, voices, labels, noises, draws,
             if pad > 0:
                 noise = np.pad(noise, [(0, 0), (pad, pad), (0, 0)])
             off = draws['n_offset'][n]
+            if seperate_noise_voice:
+                only_noise += np.float32(draws['n_gain'][n]) * noise[:, off:off + n_frame]
             spec += np.float32(draws['n_gain'][n]) * noise[:, off:off + n_frame]
+    if seperate_noise_voice:
+        return spec, (label, only_voice, only_noise)
     return spec, label
 
 

@@ -65,6 +65,15 @@ def test_merge_apply_matches_oracle():
         b, lb = R.merge_complex_specs_apply(bg, voices, labels, noises, d, n_frame=12, n_classes=5)
         assert np.allclose(a.numpy(), b, atol=1e-6) and np.array_equal(la.numpy(), lb)
         assert la.sum(0).max() <= 1  # overlapping classes are rejected (pipeline.py:78-84)
+        # seperate_noise_voice (pipeline.py:38-39, :80-81, :104-108): torch op-by-op form == oracle
+        a2, (la2, ov, on) = P.merge_complex_specs_apply(torch.from_numpy(bg), torch.from_numpy(voices),
+                                                        torch.from_numpy(labels), torch.from_numpy(noises), d,
+                                                        n_frame=12, n_classes=5, seperate_noise_voice=True)
+        b2, (lb2, bov, bon) = R.merge_complex_specs_apply(bg, voices, labels, noises, d, n_frame=12, n_classes=5,
+                                                          seperate_noise_voice=True)
+        assert np.array_equal(b2, b) and np.array_equal(lb2, lb) and np.array_equal(a2.numpy(), a.numpy())
+        assert np.allclose(ov.numpy(), bov, atol=1e-6) and np.allclose(on.numpy(), bon, atol=1e-6)
+        assert np.allclose(bov + bon, b, atol=1e-5)
 
 
 def test_merge_draw_distributions():

@@ -413,6 +413,13 @@ def test_drop_in_merge_on_device_matches_oracle(dev):
                                             None if noises is None else torch.from_numpy(noises), d, n_frame=12,
                                             n_classes=5)
         assert np.array_equal(c.numpy(), b) and np.array_equal(lc.numpy(), lb)
+        # seperate_noise_voice (pipeline.py:38-39, :80-81, :104-108): the same kernels over three source tables
+        a, (la, ov, on) = P.merge_complex_specs_apply(t(bg), t(voices), t(labels), t(noises), d, n_frame=12,
+                                                      n_classes=5, seperate_noise_voice=True)
+        b, (lb, bov, bon) = R.merge_complex_specs_apply(bg, voices, labels, noises, d, n_frame=12, n_classes=5,
+                                                        seperate_noise_voice=True)
+        assert ov.is_cuda and np.array_equal(a.cpu().numpy(), b) and np.array_equal(la.cpu().numpy(), lb)
+        assert np.array_equal(ov.cpu().numpy(), bov) and np.array_equal(on.cpu().numpy(), bon)
 
 
 # ---------------------------------------------------------------------------
