@@ -44,15 +44,6 @@ constexpr int fused_occ(int log2n) { return 1; }
 #ifndef IRIS_S2_WAVES
 #define IRIS_S2_WAVES 8
 #endif
-// experiment switches: constants requested before the first frames (they are L2 hits and must not
-// queue behind the HBM misses of the frame loads: loads return in order); one touch load per wave
-// that pulls the chunk's whole waveform segment into this XCD's L2 at chunk start
-#ifndef IRIS_CONSTS_FIRST
-#define IRIS_CONSTS_FIRST 0
-#endif
-#ifndef IRIS_TOUCH
-#define IRIS_TOUCH 0
-#endif
 // frames go global -> registers up to this n_fft (log2); above it through LDS-DMA landing buffers
 #ifndef IRIS_DIRECT_MAX
 #define IRIS_DIRECT_MAX 10
@@ -263,40 +254,11 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
             }
     };
     int f[S], fn[S];  // frames in registers / frames in flight to the landing buffers
-    // One load per lane and cache line over the chunk's waveform segment (all channels): the lines start
-    // their way from HBM into this XCD's L2 now, at the full rate of the memory system, instead of one
-    // frame per wave and HBM round trip; the frame loads that follow hit the L2.  The loaded words are
-    // consumed (an empty asm) after the next frame's samples have arrived - loads return in order.
-    float touched[2] = {0.f, 0.f};  // at most two loads per wave and chunk (128 KiB of waveform per chunk)
-    auto touch_chunk = [&](int b, int t0, int nt) {
-        if constexpr (IRIS_TOUCH == 1) {
-            const int s0 = max(t0 * a.hop - N / 2, 0) & ~15, s1 = min((t0 + nt - 1) * a.hop + N / 2, a.L);
-            const int lines = (s1 - s0 + 15) >> 4, total = lines * a.C;
-            const float* seg = a.wav + (size_t)b * a.C * a.L + s0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int li = min((wv + i * kFusedWaves) * kWave + lane, total - 1);
-                const int c = (a.C == 1) ? 0 : li / lines, l = li - c * lines;
-                touched[i] = seg[(size_t)c * a.L + min(l * 16, s1 - s0 - 1)];
-            }
-        }
-    };
-    constexpr int kStageN = ConstLayout<LOG2N>::NV4 * kWave, kStagePer = (kStageN + 64 * kFusedWaves - 1) / (64 * kFusedWaves);
-    constexpr bool kConstsFirst = IRIS_CONSTS_FIRST != 0 && kStagePer <= 2;  // (n_fft 2048 would spill)
-    float4 cstage[kStagePer];
-    if constexpr (kConstsFirst) {
-        const float4* g = reinterpret_cast<const float4*>(a.consts);
-#pragma unroll
-        for (int i = 0; i < kStagePer; ++i) {
-            cstage[i] = g[min((int)threadIdx.x + i * 64 * kFusedWaves, kStageN - 1)];
-        }
-    }
     if (g0 < a.n_chunks) {  // first frames of the first chunk: in flight while the constants are fetched
         const int b = chunk_clip(g0);
 #pragma unroll
         for (int st = 0; st < S; ++st) f[st] = wv * S + st;
         issue_dma(f, b, chunk_t0(g0, b), chunk_nt(g0, b) * a.C);
-        touch_chunk(b, chunk_t0(g0, b), chunk_nt(g0, b));
     }
     {
         // The constant block is the same for every wave: fetch it from global once per workgroup.
@@ -307,14 +269,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
         static_assert(!DIRECT || kLandBytes >= kStageBytes, "constant block does not fit the landing area");
         float4* stage = reinterpret_cast<float4*>(DIRECT ? smem : xbuf0);
         const float4* g = reinterpret_cast<const float4*>(a.consts);
-        if constexpr (kConstsFirst) {
-            (void)g;
-#pragma unroll
-            for (int i = 0; i < kStagePer; ++i)
-                if ((int)threadIdx.x + i * 64 * kFusedWaves < kStageN) stage[threadIdx.x + i * 64 * kFusedWaves] = cstage[i];
-        } else {
-            for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
-        }
+        for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
         if (threadIdx.x == 0) *next_frame = 2 * kFusedWaves * S;
         if constexpr (BANDS) {
             if (a.t_bands && g0 < a.n_chunks) {
@@ -362,10 +317,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
             f[st] = wv * S + st;
             fn[st] = (kFusedWaves + wv) * S + st;  // second round is static too: the queue starts at 2 * waves * S
         }
-        if (chunk != g0) {
-            issue_dma(f, b, t0, nwf);
-            touch_chunk(b, t0, nt);
-        }
+        if (chunk != g0) issue_dma(f, b, t0, nwf);
         bool mbit[S];             // the frames in f[] lie in a time band (wave-uniform)
 #pragma unroll
         for (int st = 0; st < S; ++st) mbit[st] = false;
@@ -446,10 +398,6 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
             issue_dma(fn, b, t0, nwf);
         }
         PH_MARK(8);
-        if constexpr (IRIS_TOUCH == 2 && DIRECT && S == 1) {  // both edges into the loop arrive with the samples waited for
-#pragma unroll
-            for (int q = 0; q < P; ++q) asm volatile("" : "+v"(x[0][q]));
-        }
         while (f[0] < nwf) {
             PH_BEGIN();
             int fcur[S];
@@ -501,24 +449,6 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
 #pragma unroll
                     for (int st = 0; st < S; ++st) fn[st] = claimed + st;
                     if constexpr (!DIRECT) issue_dma(fn, b, t0, nwf);
-                }
-                if constexpr (IRIS_TOUCH == 2 && DIRECT && S == 1) {
-                    // rolling L2 touch: the frame just claimed is loaded one iteration from now and used two
-                    // from now; its newest hop (the only part no earlier frame has fetched) starts its way
-                    // from HBM now - one lane per 64-byte line.  The word loaded a whole iteration ago is
-                    // consumed first (it has long returned; loads return in order, so the counted wait for
-                    // the frame samples at the loop top leaves this one in flight).
-                    asm volatile("" ::"v"(touched[0]));
-                    // the next frame's samples are waited for HERE (the iteration is over anyway), so that the
-                    // loop top needs no wait and the touch issued below stays in flight across it
-#pragma unroll
-                    for (int q = 0; q < P; ++q) asm volatile("" : "+v"(x[0][q]));
-                    if (more && fn[0] < nwf) {
-                        const int tl = (a.C == 1) ? fn[0] : fn[0] / a.C, c = fn[0] - tl * a.C;
-                        const int nl = a.hop >> 4;
-                        const int smp = min((t0 + tl) * a.hop + N / 2 - a.hop + min(lane, nl - 1) * 16, a.L - 1);
-                        touched[0] = a.wav[((size_t)b * a.C + c) * a.L + smp];
-                    }
                 }
             };
             bool masked[S];
@@ -651,7 +581,6 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
             if ABL(4096) ph[7] += 1;
         }
         PH_BEGIN();
-        if constexpr (IRIS_TOUCH != 0) asm volatile("" ::"v"(touched[0]), "v"(touched[1]));
         // every wave leaves its own (min, max) partial for k_minmax_log_apply
         mn = wave_min(mn);
         mx = wave_max(mx);
