@@ -172,6 +172,10 @@ int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minmax, int do_
  * The fused hot path: [normalize ->] STFT -> magnitude -> band masks -> mel
  * [-> min-max] [-> log] without materialising the spectrum
  * (load_wav data_utils.py:22-23 + sj_train.py:108-123).  flags = IRIS_F_*.
+ * Two launches on `stream` (the fused kernel, then min-max / log over its per-wave partials); the partials live in
+ * the plan's own workspace, so calls on ONE plan must be ordered on one stream (or otherwise serialised) - create one
+ * plan per stream to run batches concurrently.  Safe under hipGraph capture and replay (no per-call host state, no
+ * atomics to reset).
  */
 int iris_wav_to_logmel(iris_plan* plan, const float* wav, float* out, int batch, int len,
                        int flags, const int32_t* t_bands, int n_t_bands,
