@@ -208,7 +208,7 @@ static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, in
         if (*lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
         int resident = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
-                                                                    64 * fused_waves(p->log2n, streams, bands), *lds);
+                                                                    64 * fused_waves(p->log2n, streams, bands, p->need_hi != 0), *lds);
         if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s",
                                          hipGetErrorString(e));
         if (resident >= per_cu) {
@@ -269,7 +269,7 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     a.n_chunks = batch * a.chunks_per_clip;
     a.chunk_base = a.T / a.chunks_per_clip;
     a.chunk_rem = a.T % a.chunks_per_clip;
-    const int waves = mfma ? kMfmaWaves : fused_waves(p->log2n, streams, bands);
+    const int waves = mfma ? kMfmaWaves : fused_waves(p->log2n, streams, bands, p->need_hi != 0);
     const int parts_per_chunk = waves;
     const size_t n_partial = 2 * (size_t)a.n_chunks * parts_per_chunk;
     a.partial = p->d_ws;

@@ -39,18 +39,24 @@ constexpr int fused_occ(int log2n) { return 1; }
 #define IRIS_W1024 16
 #endif
 #ifndef IRIS_W2048
-#define IRIS_W2048 8
+#define IRIS_W2048 0  // 0 = automatic: 12 where the registers allow it (see fused_waves), else 8
 #endif
 #ifndef IRIS_S2_WAVES
 #define IRIS_S2_WAVES 8
 #endif
-// frames go global -> registers up to this n_fft (log2); above it through LDS-DMA landing buffers
+// frames go global -> registers up to this n_fft (log2); above it through LDS-DMA landing buffers.  Round 2: n_fft
+// 2048 too - the prefetch targets the sample registers themselves (dead during the mel phase), so it costs no
+// registers, frees 8 KB of landing buffer per wave, and the variant without bands and without the upper spectrum half
+// then fits 168 VGPRs = 12 waves per CU (c5: 34.3 us LDS-DMA / 8 waves -> 32.5 direct / 8 -> 30.7 direct / 12).
 #ifndef IRIS_DIRECT_MAX
-#define IRIS_DIRECT_MAX 10
+#define IRIS_DIRECT_MAX 11
 #endif
 constexpr bool fused_direct(int log2n) { return IRIS_DIRECT_LOAD && log2n <= IRIS_DIRECT_MAX; }
-constexpr int fused_waves(int log2n, int streams = 1, bool bands = false) {
-    return streams > 1 ? IRIS_S2_WAVES : (log2n >= 11 ? IRIS_W2048 : (log2n == 10 ? (bands ? 12 : IRIS_W1024) : 16));
+// hi: the variant computes both halves of the untangle (n_fft 2048: 12 waves would spill, so 8)
+constexpr int fused_waves(int log2n, int streams = 1, bool bands = false, bool hi = false) {
+    return streams > 1 ? IRIS_S2_WAVES
+                       : (log2n >= 11 ? ((IRIS_W2048 == 0 && fused_direct(11) && !bands && !hi) ? 12 : (IRIS_W2048 ? IRIS_W2048 : 8))
+                                      : (log2n == 10 ? (bands ? 12 : IRIS_W1024) : 16));
 }
 
 struct FusedArgs {
@@ -160,8 +166,8 @@ __device__ __forceinline__ void dma_frame(const float* clip, int len, int start,
 }
 
 template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S>
-__global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2N, S, BANDS) / 4) void k_wav_to_mel(const FusedArgs a) {
-    constexpr int kFusedWaves = fused_waves(LOG2N, S, BANDS);
+__global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(LOG2N, S, BANDS, HI) / 4) void k_wav_to_mel(const FusedArgs a) {
+    constexpr int kFusedWaves = fused_waves(LOG2N, S, BANDS, HI);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the wave index is uniform: keep it (and everything derived from it) in SGPRs
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS), fused_waves(LOG2
     auto chunk_nt = [&](int chunk, int b) {
         return a.chunk_base + ((chunk - b * a.chunks_per_clip) < a.chunk_rem ? 1 : 0);
     };
-    constexpr bool DIRECT = fused_direct(LOG2N);  // n_fft 2048 (16 points per lane) has no registers to spare
+    constexpr bool DIRECT = fused_direct(LOG2N);
     cf x[S][P];
     // Fetch of wave-frames ff[] (f = tl * C + c) of a chunk: straight into the x registers
     // (IRIS_DIRECT_LOAD), or by LDS-DMA into this wave's landing buffers

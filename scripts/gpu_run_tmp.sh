@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2r; mkdir -p $O
-timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "magmel or magphase_to_mel or unfused or data_utils or dataset or mixer or eval" 2>&1 | tail -3
-for e in "" "IRIS_MAGMEL_FPL1=1"; do echo "== $e"; env $e python3 scripts/gpu_shapes.py 2>&1 | grep -o "^.\{42\}\|magmel.*" | paste - - ; done 2>&1 | tee $O/magmel.log
+O=gpurun_out/r2u; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu.log
+timeout -k 10 600 python scripts/gpu_fuzz.py 200 11 > $O/fuzz.log 2>&1; echo "fuzz rc $?"; tail -1 $O/fuzz.log
+timeout -k 10 600 python scripts/gpu_stress.py > $O/stress.log 2>&1; echo "stress rc $?"; tail -1 $O/stress.log
+python3 scripts/gpu_c5.py both 60 2>&1 | tail -2 | cut -c1-220
+python3 scripts/gpu_shapes.py 2>&1 | grep c5
