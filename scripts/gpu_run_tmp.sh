@@ -1,5 +1,10 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2w; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_frontend_gpu.py -x -q -m gpu 2>&1 | tail -5
-bash scripts/gpu_ab.sh prod notile 2>&1 | tee $O/ab.log
-BENCH_ARGS="--resident" bash scripts/gpu_ab.sh prod notile 2>&1 | tee $O/ab_res.log
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r2x; rm -rf $O; mkdir -p $O
+bash scripts/gpu_pmc.sh "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" > $O/pmc.log 2>&1; tail -3 $O/pmc.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $O/prof_stdout.log 2>&1; echo "prof rc $?"
+for f in $(find $O/prof -name "*kernel_stats.csv"); do cut -c1-150 $f | head -4; done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_res -o bench -- python3 bench.py --resident --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $O/prof_res_stdout.log 2>&1; echo "prof_res rc $?"
+for f in $(find $O/prof_res -name "*kernel_stats.csv"); do cut -c1-150 $f | head -3; done
+find $O -name "*kernel_trace.csv" -delete
+python3 scripts/gpu_shapes.py > $O/shapes.log 2>&1; tail -6 $O/shapes.log | cut -c1-250
