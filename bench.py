@@ -138,10 +138,17 @@ def side_measurements(dev, rank, world, steps, fence):
         with torch.no_grad():
             model(fe(wav))
 
+    folded = S.fold_batchnorm(model)  # inference copy: eval-mode BatchNorm folded into the conv / dense in front of it
+
+    def fwd_folded():
+        with torch.no_grad():
+            folded(fe(wav))
+
     def train():
         model.train_step((fe(wav), y))
 
     t_fwd = timed(fwd, steps)
+    t_fwd_folded = timed(fwd_folded, steps)
     t_train = timed(train, steps)
 
     # input side of the reference's own training loop (spectra in, sj_train.py:74-130) at its default
@@ -156,7 +163,9 @@ def side_measurements(dev, rank, world, steps, fence):
                            "audio_s_per_s": round(world * batch * 512 * HOP / SR / t_data, 1),
                            "shape": "spectra [257, T_i, 4] resident in HBM -> log-mel [64, 80, 512, 2] + labels"},
         "c3_frontend_specaug_crnn_fwd": {"audio_s_per_s": round(world * audio_s / t_fwd, 1),
-                                         "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch},
+                                         "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch,
+                                         "bn_folded_for_inference": {"audio_s_per_s": round(world * audio_s / t_fwd_folded, 1),
+                                                                     "ms_per_step": round(1e3 * t_fwd_folded, 3)}},
         "c4_train_step": {"audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3),
                           "batch_per_gpu": batch, "n_gpus": world, "params": sum(p.numel() for p in model.parameters()),
                           "grad_allreduce": "DDP/RCCL" if world > 1 else "none"},

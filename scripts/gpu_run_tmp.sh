@@ -1,10 +1,6 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r2x; rm -rf $O; mkdir -p $O
-bash scripts/gpu_pmc.sh "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" > $O/pmc.log 2>&1; tail -3 $O/pmc.log
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $O/prof_stdout.log 2>&1; echo "prof rc $?"
-for f in $(find $O/prof -name "*kernel_stats.csv"); do cut -c1-150 $f | head -4; done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_res -o bench -- python3 bench.py --resident --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $O/prof_res_stdout.log 2>&1; echo "prof_res rc $?"
-for f in $(find $O/prof_res -name "*kernel_stats.csv"); do cut -c1-150 $f | head -3; done
-find $O -name "*kernel_trace.csv" -delete
-python3 scripts/gpu_shapes.py > $O/shapes.log 2>&1; tail -6 $O/shapes.log | cut -c1-250
+O=gpurun_out/r2y; mkdir -p $O
+timeout -k 10 400 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
+python3 -c "
+import json;d=json.load(open('$O/bench.json'));print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['traffic']); print(d['extra']['c3_frontend_specaug_crnn_fwd']); print(d['extra']['c4_train_step'])"
+tail -3 $O/bench.err

@@ -219,6 +219,26 @@ def test_model_parameter_counts_and_shapes():
     assert S.run_name(full) == 'vad_v9_lr0.001_batch12_opt_adam_mel80_chan2_BCE_framelen512.h5'
 
 
+def test_fold_batchnorm_is_the_same_function():
+    """Inference copy with BN folded into the conv / dense in front of it == the eval-mode model (fp32 rounding)."""
+    torch.manual_seed(3)
+    for v in (9, 1, 7):
+        cfg = _small_cfg(v)
+        m = S.get_model(cfg)
+        m.compile(S.make_optimizer(cfg, m.parameters()), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+        x = torch.randn(4, 32, 64, 1)
+        for _ in range(3):                      # non-trivial running statistics and affine parameters
+            m.train_step((x + torch.randn_like(x), (torch.rand(4, 2, 3) > 0.7).float()))
+        f = S.fold_batchnorm(m)
+        assert not any(isinstance(k, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)) for k in f.modules())
+        assert m.optimizer is not None and f.optimizer is None      # training state stays with the original
+        with torch.no_grad():
+            ref = m.eval()(x)
+            got = f(x)
+        assert float((ref - got).abs().max()) <= 1e-5, float((ref - got).abs().max())
+        assert any(isinstance(k, torch.nn.BatchNorm2d) for k in m.modules())   # the original is untouched
+
+
 def test_train_step_decreases_loss_cpu():
     torch.manual_seed(0)
     cfg = _small_cfg()
