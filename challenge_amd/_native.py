@@ -42,6 +42,8 @@ SIGNATURES = {
     "iris_mix_frame_active": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "iris_mix_workspace": (_sz, [_i, _i]),
     "iris_mix_specs": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "iris_mix_wave_frame_active": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "iris_mix_waves": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "iris_timing_enable": (_i, [_vp, _i]),
     "iris_timing_read": (_i, [_vp, C.POINTER(_i), _fp]),
 }

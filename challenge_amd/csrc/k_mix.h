@@ -155,3 +155,83 @@ extern "C" int iris_mix_specs(const iris_mix_src* srcs_dev, int n_srcs, const in
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
+
+// ---------------------------------------------------------------------------
+// waveform-domain variant: same table, same label kernel, sources are [C, len]
+// waveforms (len in `reserved`), T / pad / off in frames of `hop` samples
+// ---------------------------------------------------------------------------
+// active[t] = 1 when any sample under the support of frame t's periodic-Hann window is non-zero in any channel
+__global__ __launch_bounds__(256) void k_mix_wave_frame_active(const float* wav, int channels, int len, int n_fft,
+                                                               int hop, int n_frames, float* active) {
+    const int t = blockIdx.x;  // one block per frame: the window is n_fft - 1 samples long
+    const int lo = max(t * hop - n_fft / 2 + 1, 0), hi = min(t * hop + n_fft / 2 - 1, len - 1);
+    int any = 0;
+    for (int c = 0; c < channels; ++c)
+        for (int i = lo + (int)threadIdx.x; i <= hi; i += blockDim.x) any |= wav[(size_t)c * len + i] != 0.f;
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0 && t < n_frames) active[t] = any ? 1.f : 0.f;
+}
+
+// wav_out[b, c, s] = background + accepted voices + noises, table order, separately rounded multiply and add
+__global__ __launch_bounds__(256) void k_mix_wave_sum(const iris_mix_src* srcs, const int32_t* first, const float* flags,
+                                                      float* out, int channels, int hop, int out_len) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.z, c = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= out_len) return;
+    float acc = 0.f;
+    for (int si = first[b]; si < first[b + 1]; ++si) {
+        const iris_mix_src r = srcs[si];  // uniform
+        const int len = r.reserved;
+        const float* row = r.src + (size_t)c * len;
+        if (r.kind == 0) {
+            acc = row[(int)(((long long)r.off * hop + s) % len)];
+            continue;
+        }
+        const float keep = r.kind == 1 ? flags[si] : 1.f;
+        const long long ss = (long long)s + (long long)(r.off - r.pad) * hop;
+        if (ss < 0 || ss >= len || keep == 0.f) continue;  // adds exactly zero
+        const float scaled = r.gain * row[ss];
+        acc = acc + scaled;
+    }
+    out[((size_t)b * channels + c) * out_len + s] = acc;
+}
+
+extern "C" int iris_mix_wave_frame_active(const float* wav, int channels, int len, int n_fft, int hop, float* active_out,
+                                          void* stream) {
+    if (!wav || !active_out) return fail(IRIS_E_INVALID, "iris_mix_wave_frame_active: NULL argument");
+    if (channels <= 0 || len <= 0 || n_fft <= 1 || hop <= 0)
+        return fail(IRIS_E_INVALID, "iris_mix_wave_frame_active: bad sizes (%d channels, %d samples, n_fft %d, hop %d)",
+                    channels, len, n_fft, hop);
+    const int n_frames = 1 + len / hop;
+    k_mix_wave_frame_active<<<n_frames, 256, 0, (hipStream_t)stream>>>(wav, channels, len, n_fft, hop, n_frames, active_out);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_mix_waves(const iris_mix_src* srcs_dev, int n_srcs, const int32_t* first_dev,
+                              const float* label_vecs_dev, float* wav_out, float* labels_out, int batch, int channels,
+                              int hop, int n_frame, int max_voices, int n_classes, float* workspace,
+                              size_t workspace_floats, void* stream) {
+    if (!srcs_dev || !first_dev || !label_vecs_dev || !wav_out || !labels_out || !workspace)
+        return fail(IRIS_E_INVALID, "iris_mix_waves: NULL argument");
+    if (batch <= 0 || n_srcs < batch || channels <= 0 || hop <= 0 || n_frame <= 1 || max_voices <= 0 || n_classes <= 0)
+        return fail(IRIS_E_INVALID, "iris_mix_waves: bad sizes (batch %d, %d sources, %d channels, hop %d, %d frames)",
+                    batch, n_srcs, channels, hop, n_frame);
+    if (batch > 65535 || channels > 65535 || n_srcs > 65535)
+        return fail(IRIS_E_UNSUPPORTED, "iris_mix_waves: batch / channels / sources above 65535");
+    if ((long long)(n_frame - 1) * hop > 0x7fffffffLL) return fail(IRIS_E_UNSUPPORTED, "iris_mix_waves: output too long");
+    if (workspace_floats < iris_mix_workspace(n_srcs, n_frame))
+        return fail(IRIS_E_CAPACITY, "iris_mix_waves: workspace %zu floats < %zu", workspace_floats,
+                    iris_mix_workspace(n_srcs, n_frame));
+    const size_t lds = (size_t)n_frame * n_classes * sizeof(float);
+    if (lds > 64 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_mix_waves: n_frame x n_classes too large for the LDS");
+    hipStream_t s = (hipStream_t)stream;
+    float* flags = workspace;  // [n_srcs]
+    const int out_len = (n_frame - 1) * hop;
+    k_mix_labels<<<batch, 256, lds, s>>>(srcs_dev, first_dev, label_vecs_dev, flags, labels_out, n_frame, max_voices,
+                                         n_classes);
+    k_mix_wave_sum<<<dim3((unsigned)((out_len + 255) / 256), channels, batch), 256, 0, s>>>(srcs_dev, first_dev, flags,
+                                                                                          wav_out, channels, hop, out_len);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}

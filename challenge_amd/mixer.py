@@ -236,6 +236,11 @@ class DeviceMixer:
             n = full[:, 1 + V:]
             n["src"], n["T"] = self._n_ptr[d.noises], self._n_T[d.noises]
             n["pad"], n["off"], n["gain"], n["kind"] = np.maximum(pad_n, 0)[:, None], d.n_offset, d.n_gain, KIND_NOISE
+        if getattr(self, "_bg_L", None) is not None:  # waveform sources (WaveMixer): samples per channel
+            full["reserved"][:, 0] = self._bg_L[d.bg]
+            full["reserved"][:, 1:1 + V] = self._v_L[d.voices]
+            if Nn:
+                full["reserved"][:, 1 + V:] = self._n_L[d.noises]
         first = np.concatenate([[0], np.cumsum(use.sum(axis=1))]).astype(np.int32)
         return np.ascontiguousarray(full[use]), first
 
@@ -267,3 +272,100 @@ class DeviceMixer:
 
     def __iter__(self):
         raise TypeError("DeviceMixer yields whole batches: call mix(batch)")
+
+
+class WaveMixer(DeviceMixer):
+    """`DeviceMixer` in the waveform domain (second half): the corpus stays
+    resident as waveforms [C, L_i] - a quarter of the bytes of its spectrograms at n_fft 1024 / hop 256 - and a
+    batch is mixed before the STFT, which is linear:
+
+        mixer = WaveMixer(backgrounds, voices, labels, noises, n_frame=512, n_fft=1024, hop=256, ...)
+        wav, label = mixer.mix(batch)      # [B, C, (n_frame - 1) * hop], [B, max_voices, n_frame, n_classes]
+        logmel = WaveFrontend(...)(wav)    # fused kernel: no spectrum is ever materialised
+
+    Same draws (in frames: a source of L samples has 1 + L // hop of them), same label rule and the same table as
+    the spectrum-domain mixer; every frame quantity is multiplied by `hop`.  STFT(wav) equals `DeviceMixer`'s output
+    for the sources' STFTs on every frame whose window crosses no crop / pad / tiling boundary
+    (`iris_mix_waves`, include/iris_frontend.h; oracle: `mix_waves_apply`)."""
+
+    def __init__(self, backgrounds: Sequence, voices: Sequence, labels, noises: Optional[Sequence] = None,
+                 n_frame: int = 300, n_fft: int = 1024, hop: int = 256, max_voices: int = 10, max_noises: int = 10,
+                 n_classes: int = 3, device=None, min_ratio: float = 2 / 3, min_noise_ratio: float = 1 / 2,
+                 snr: float = -20, seed=None):
+        labels = np.asarray(labels, np.float32)
+        assert len(np.asarray(backgrounds[0]).shape) == 2, 'each waveform must be [chan, samples]'
+        assert len(voices) == len(labels)
+        assert labels.ndim == 2 and labels.shape[1] == n_classes, \
+            'labels must be in the form of [n_samples, n_classes]'
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("WaveMixer needs a ROCm device (no CPU fallback)")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("WaveMixer needs a ROCm device (no CPU fallback)")
+        N.lib()
+        self.n_frame, self.max_voices, self.max_noises, self.n_classes = n_frame, max_voices, max_noises, n_classes
+        self.n_fft, self.hop = n_fft, hop
+        self.min_ratio, self.min_noise_ratio, self.snr = min_ratio, min_noise_ratio, snr
+        self.rng = np.random.default_rng(seed)
+
+        def upload(items):
+            out = [torch.as_tensor(np.ascontiguousarray(np.asarray(x, np.float32))).to(self.device) for x in items]
+            for t in out:
+                if t.dim() != 2 or t.shape[0] != out[0].shape[0] or t.shape[1] < 1:
+                    raise ValueError("sources must be [chan, samples] with equal chan")
+            return out
+
+        self.backgrounds, self.voices = upload(backgrounds), upload(voices)
+        self.noises = upload(noises) if noises is not None else None
+        self.channels = int(self.backgrounds[0].shape[0])
+        for group in (self.voices, self.noises or []):
+            for t in group:
+                if t.shape[0] != self.channels:
+                    raise ValueError("voices / noises must have the backgrounds' channel count")
+        self.label_vecs = torch.from_numpy(labels).to(self.device)
+        frames = lambda t: 1 + int(t.shape[1]) // hop  # noqa: E731
+        self.voice_active = []
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            for v in self.voices:
+                act = torch.empty(frames(v), device=self.device, dtype=torch.float32)
+                N.check(N.lib().iris_mix_wave_frame_active(v.data_ptr(), self.channels, int(v.shape[1]), n_fft, hop,
+                                                           act.data_ptr(), stream), "iris_mix_wave_frame_active")
+                self.voice_active.append(act)
+        ptrs = lambda ts: np.array([t.data_ptr() for t in ts], np.uint64)  # noqa: E731
+        lens = lambda ts: np.array([int(t.shape[1]) for t in ts], np.int64)  # noqa: E731
+        self._bg_ptr, self._bg_L = ptrs(self.backgrounds), lens(self.backgrounds)
+        self._v_ptr, self._v_L = ptrs(self.voices), lens(self.voices)
+        self._v_act = ptrs(self.voice_active)
+        self._n_ptr = ptrs(self.noises) if self.noises is not None else None
+        self._n_L = lens(self.noises) if self.noises is not None else None
+        self._bg_T, self._v_T = 1 + self._bg_L // hop, 1 + self._v_L // hop
+        self._n_T = 1 + self._n_L // hop if self.noises is not None else None
+        self._b = _Stream(len(self.backgrounds), self.rng)
+        self._v = _Stream(len(self.voices), self.rng)
+        self._n = _Stream(len(self.noises), self.rng) if self.noises is not None else None
+
+    def mix(self, batch: int, draws=None):
+        """One batch of (waveforms [B, C, (n_frame - 1) * hop], labels [B, max_voices, n_frame, n_classes])."""
+        draws = self.draw_arrays(batch) if draws is None else draws
+        batch = len(draws)
+        table, first = self.table(draws)
+        n_srcs = int(table.shape[0])
+        dev = self.device
+        table_d = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(dev, non_blocking=True)
+        first_d = torch.from_numpy(first).to(dev, non_blocking=True)
+        wav = torch.empty((batch, self.channels, (self.n_frame - 1) * self.hop), device=dev, dtype=torch.float32)
+        label = torch.empty((batch, self.max_voices, self.n_frame, self.n_classes), device=dev, dtype=torch.float32)
+        ws_floats = int(N.lib().iris_mix_workspace(n_srcs, self.n_frame))
+        ws = torch.empty(max(ws_floats, 1), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = N.lib().iris_mix_waves(table_d.data_ptr(), n_srcs, first_d.data_ptr(), self.label_vecs.data_ptr(),
+                                        wav.data_ptr(), label.data_ptr(), batch, self.channels, self.hop, self.n_frame,
+                                        self.max_voices, self.n_classes, ws.data_ptr(), ws_floats,
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        N.check(rc, "iris_mix_waves")
+        for t in (table_d, first_d, ws):
+            t.record_stream(torch.cuda.current_stream(dev))
+        return wav, label

@@ -84,7 +84,8 @@ class ARGS:
         # not in the reference
         a('--synthetic', action='store_true', help='synthetic sources instead of the pickled datasets')
         a('--online_stft', action='store_true',
-          help='generate waveforms and run the fused HIP frontend (STFT on line) instead of mixing spectra')
+          help='keep (synthetic) waveform corpora on the device, mix them before the STFT (WaveMixer) and run the '
+               'fused HIP frontend on line instead of mixing pre-computed spectra (make_wave_dataset)')
         a('--per_sample_pipeline', action='store_true',
           help='build samples one at a time with the tf.data-shaped graph (make_dataset) instead of the '
                'batched on-device synthesis (make_device_dataset), which is the default on a GPU')
@@ -254,6 +255,77 @@ def make_device_dataset(config, training=True, n_classes=3, sources=None, device
             yield to_mel(x, y, t_bands=tb, f_bands=fb)
 
     return _label_tail(Dataset.from_generator(gen), config)
+
+
+def synthetic_wave_sources(n_chan: int = 2, n_classes: int = 3, hop: int = 256, n_bg: int = 8, n_voice: int = 24,
+                           n_noise: int = 12, seed: int = 0):
+    """Waveform stand-ins of the same shape statistics as `synthetic_sources` (frame counts x hop samples):
+    lists of [chan, L_i] float32 waveforms and integer class labels."""
+    rng = np.random.default_rng(seed)
+    backgrounds = [rng.standard_normal((n_chan, hop * int(rng.integers(300, 900)))).astype(np.float32) * 0.1
+                   for _ in range(n_bg)]
+    voices = []
+    for _ in range(n_voice):
+        t = int(rng.integers(40, 200))
+        v = rng.standard_normal((n_chan, hop * t)).astype(np.float32) * 0.3
+        v[:, hop * int(t * 0.8):] = 0  # trailing silence, as padded voices have
+        voices.append(v)
+    labels = rng.integers(0, n_classes, size=n_voice)
+    noises = [rng.standard_normal((n_chan, hop * int(rng.integers(20, 120)))).astype(np.float32) * 0.3
+              for _ in range(n_noise)]
+    return backgrounds, voices, labels, noises
+
+
+def make_wave_dataset(config, training=True, n_classes=3, sources=None, device=None, seed=None, n_fft=512, hop=256,
+                      sample_rate=16000):
+    """`make_device_dataset` from WAVEFORMS (waveform-domain variant): the corpora
+    stay resident in HBM as [chan, L_i] waveforms, `WaveMixer` mixes a batch before the STFT (which is linear), and
+    the fused kernel takes it from there - STFT, SpecAugment / `stft_filter` bands, mel, min-max, log in one pass;
+    no spectrum is ever materialised.  Same stages and outputs as sj_train.py:74-130 otherwise; `sources` =
+    (background waveforms, voice waveforms, labels, noise waveforms).  The channel maps act on the waveform
+    (`mono_chan` is a sum of the two channels, linear like the STFT; the augmenting maps of n_chan > 2 mix
+    spectra with per-bin factors and are not available here).  n_fft defaults to the reference's 512 (F = 257)."""
+    from .mixer import WaveMixer
+    if sources is None:
+        sources = synthetic_wave_sources(2, n_classes, hop, seed=0 if training else 1)
+    backgrounds, voices, labels, noises = sources
+    labels = np.eye(n_classes, dtype='float32')[np.asarray(labels)]
+    if config.model_type == 'se' and config.v == 9:
+        raise NotImplementedError("model_type 'se' is outside the accelerated path (SURVEY.md section 2)")
+    if config.n_chan not in (1, 2):
+        raise NotImplementedError("make_wave_dataset: n_chan 1 (mono sum) or 2; the augmenting channel maps mix spectra")
+    mixer = WaveMixer(backgrounds, voices, labels, noises, n_frame=config.n_frame, n_fft=n_fft, hop=hop,
+                      max_voices=config.max_voices, max_noises=config.max_noises, n_classes=n_classes, device=device,
+                      snr=config.snr, min_ratio=1, seed=seed)
+    rng = np.random.default_rng(None if seed is None else seed + 1)
+    length = (config.n_frame - 1) * hop
+    plan = _fe.FrontendPlan(n_fft, hop, config.n_mels, sample_rate, config.n_chan, config.batch_size, length, mixer.device)
+    filter_bins = int(round(200 / (16000 / 256))) if 'filter' in config.name else 0
+    do_minmax = 'nominmax' not in config.name
+
+    def gen():
+        while True:
+            wav, y = mixer.mix(config.batch_size)
+            _, y = to_frame_labels(None, y)
+            if config.n_chan == 1 and wav.shape[1] == 2:
+                wav = wav[:, :1] + wav[:, 1:]            # mono_chan on the waveform (data_utils.py:73-76 is linear)
+            b = int(wav.shape[0])
+            tb = fb = None
+            if training:
+                tb, fb = _du.augment_draw_batch(b, config.n_frame, plan.n_bins, rng)
+            if filter_bins:
+                flt = np.tile(np.array([[[1, filter_bins]]], np.int32), (b, 1, 1))
+                fb = flt if fb is None else np.concatenate([fb, flt], axis=1)
+            yield plan.wav_to_logmel(wav.contiguous(), t_bands=tb, f_bands=fb, minmax=do_minmax, log=True), y
+
+    pipeline = Dataset.from_generator(gen)
+    if config.v in label_downsample_model:
+        pipeline = pipeline.map(label_downsample(32))
+    elif config.v == 5:
+        pipeline = pipeline.map(label_downsample(config.n_frame // (config.n_frame * 256 // 16000)))
+    if config.loss.upper() in ('MSE', 'MAE'):
+        pipeline = pipeline.map(multiply_label(config.mse_multiplier))
+    return pipeline.prefetch(AUTOTUNE)
 
 
 class WaveFrontend:
@@ -764,7 +836,12 @@ def main(argv=None):
         print(NAME, sum(p.numel() for p in model.parameters()), 'parameters')
     if config.pretrain and os.path.exists(NAME.replace('.h5', '.pt')):
         model.load_state_dict(torch.load(NAME.replace('.h5', '.pt'), map_location=device))
-    if device.type == 'cuda' and not config.per_sample_pipeline:
+    if device.type == 'cuda' and config.online_stft:
+        # corpora resident in HBM as WAVEFORMS, mixed before the STFT, fused frontend on line (synthetic sources:
+        # the reference's pickles hold spectra, not waveforms)
+        train_set = make_wave_dataset(config, training=True, device=device, seed=1000 + rank)
+        test_set = make_wave_dataset(config, training=False, device=device, seed=2000 + rank)
+    elif device.type == 'cuda' and not config.per_sample_pipeline:
         # corpora resident in HBM, whole batches synthesised on the device (each rank draws its own stream)
         train_set = make_device_dataset(config, training=True, device=device, seed=1000 + rank)
         test_set = make_device_dataset(config, training=False, device=device, seed=2000 + rank)

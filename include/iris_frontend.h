@@ -255,6 +255,29 @@ int iris_mix_specs(const iris_mix_src* srcs_dev, int n_srcs, const int32_t* firs
                    float* workspace, size_t workspace_floats, void* stream);
 
 /*
+ * Waveform-domain variant of the batched merge_complex_specs (the STFT is linear, so
+ * mixing before it equals mixing after it up to frame-granular cropping - output frames whose window straddles a crop,
+ * pad or tiling boundary differ, all others agree to fp32 rounding).  The corpus stays resident as waveforms (a
+ * quarter of the bytes of its spectrograms at n_fft 1024 / hop 256) and the mixed batch goes straight into
+ * iris_wav_to_logmel; no spectrum is ever materialised.
+ * Same source table and the same label rule as iris_mix_specs, with these readings of the record:
+ *   src      DEVICE [C, len] fp32 waveform;  reserved = len (samples per channel)
+ *   T, pad, off   in FRAMES, as for spectrograms (T = 1 + len / hop); a frame is `hop` samples:
+ *            voice / noise sample s of the output reads source sample s + (off - pad) * hop (zero outside [0, len)),
+ *            background sample s reads (off * hop + s) mod len
+ *   active   [T] flags from iris_mix_wave_frame_active: frame t is active when any sample under the support of its
+ *            periodic-Hann window, [t*hop - n_fft/2 + 1, t*hop + n_fft/2 - 1] clipped to the clip, is non-zero in any
+ *            channel (a non-zero windowed frame has a spectrum with some positive component, pipeline.py:57)
+ * wav_out: DEVICE [B, C, out_len] with out_len = (n_frame - 1) * hop, i.e. n_frame STFT frames (center=True).
+ */
+int iris_mix_wave_frame_active(const float* wav, int channels, int len, int n_fft, int hop, float* active_out,
+                               void* stream);
+int iris_mix_waves(const iris_mix_src* srcs_dev, int n_srcs, const int32_t* first_dev,
+                   const float* label_vecs_dev, float* wav_out, float* labels_out, int batch,
+                   int channels, int hop, int n_frame, int max_voices, int n_classes,
+                   float* workspace, size_t workspace_floats, void* stream);
+
+/*
  * Per-kernel timing for bench.py: with enable = n > 0 every n-th launch of the
  * dominant kernel of iris_wav_to_logmel carries a start/stop hipEvent pair on
  * the launch stream (n = 1: every launch; an event pair costs a few

@@ -515,6 +515,69 @@ def merge_complex_specs_apply(background, voices, labels, noises, draws,
     return spec, label
 
 
+def wave_frame_active(wav, n_fft, hop):
+    """Frame activity of a waveform source [C, L] (waveform-domain twin of pipeline.py:57): frame t is active when
+    any sample under the support of its periodic-Hann window, [t*hop - n_fft/2 + 1, t*hop + n_fft/2 - 1] clipped to
+    the clip, is non-zero in any channel."""
+    wav = np.asarray(wav, np.float32)
+    length = wav.shape[1]
+    nz = np.concatenate([[0], np.cumsum((wav != 0).any(axis=0))])
+    out = np.zeros(1 + length // hop, np.float32)
+    for t in range(out.shape[0]):
+        lo, hi = max(t * hop - n_fft // 2 + 1, 0), min(t * hop + n_fft // 2 - 1, length - 1)
+        out[t] = 1.0 if hi >= lo and nz[hi + 1] - nz[lo] > 0 else 0.0
+    return out
+
+
+def mix_waves_apply(background, voices, labels, noises, draws, n_frame=300, n_classes=3, hop=256, n_fft=1024,
+                    min_ratio=2 / 3, min_noise_ratio=1 / 2):
+    """Waveform-domain merge_complex_specs (pipeline.py:6-110 with every frame
+    quantity multiplied by `hop`): sources are [C, L_i] waveforms, a source of L samples has T = 1 + L // hop frames,
+    groups are padded to their longest member as `padded_batch` does.  Returns (wav [C, (n_frame - 1) * hop],
+    label [V, n_frame, K]); STFT(wav) equals the spectrum-domain mix of the sources' STFTs on every frame whose
+    window crosses no crop / pad / tiling boundary (linearity)."""
+    background = np.asarray(background, np.float32)
+    out_len = (n_frame - 1) * hop
+    lb = background.shape[1]
+    idx = (np.int64(draws['bg_offset']) * hop + np.arange(out_len)) % lb
+    wav = background[:, idx].copy()
+    max_voices = len(voices)
+    frames = lambda x: 1 + np.asarray(x).shape[1] // hop  # noqa: E731
+    label = np.zeros((max_voices, n_frame, n_classes), np.float32)
+
+    def crop(src, pad, off):
+        src = np.asarray(src, np.float32)
+        start = (off - pad) * hop
+        s = np.arange(out_len) + start
+        ok = (s >= 0) & (s < src.shape[1])
+        res = np.zeros((src.shape[0], out_len), np.float32)
+        res[:, ok] = src[:, s[ok]]
+        return res
+
+    v_len = max(frames(v) for v in voices)
+    for v in range(draws['n_voices']):
+        t_v = frames(voices[v])
+        active = wave_frame_active(voices[v], n_fft, hop)
+        pad = max(n_frame - int(np.float32(min_ratio) * np.float32(v_len)), 0)
+        off = draws['v_offset'][v]
+        l = np.zeros((n_frame, n_classes), np.float32)
+        for t in range(n_frame):
+            fr = off + t - pad
+            if 0 <= fr < t_v:
+                l[t] = np.asarray(labels[v], np.float32) * active[fr]
+        l3 = np.zeros_like(label)
+        l3[v] = l
+        no_overlap = np.float32((label + l3).sum(axis=0).max() < 2)
+        wav += np.float32(draws['v_gain'][v]) * crop(voices[v], pad, off) * no_overlap
+        label += l3 * no_overlap
+    if noises is not None and len(noises):
+        n_len = max(frames(n) for n in noises)
+        for n in range(draws['n_noises']):
+            pad = max(n_frame - int(np.float32(min_noise_ratio) * np.float32(n_len)), 0)
+            wav += np.float32(draws['n_gain'][n]) * crop(noises[n], pad, draws['n_offset'][n])
+    return wav, label
+
+
 # --------------------------------------------------------------------------
 # the fused chain the HIP kernel implements
 # --------------------------------------------------------------------------

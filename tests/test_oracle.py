@@ -308,3 +308,44 @@ def test_mel_recipe_sensitivity_on_c1(golden_dir):
         return (x - x.min()) / max(x.max() - x.min(), 1e-8)
     assert np.abs(mm(mel_a) - mm(mel_b)).max() <= 5e-6                          # measured 2.7e-6 on the [0, 1] value
     assert np.abs(np.log(mm(mel_a) + 1e-8) - np.log(mm(mel_b) + 1e-8)).max() <= 2e-5  # measured 1.1e-5 (ln amplifies near 0)
+
+
+def test_waveform_domain_mix_equals_spectrum_domain_mix_on_interior_frames():
+    """SURVEY.md section 8 (f) rank 1, waveform-domain variant: the STFT is linear, so STFT(mix of waveforms) ==
+    merge_complex_specs of the sources' STFTs on every output frame whose window crosses no crop / pad boundary
+    (here: at least 2 frames = n_fft / (2 hop) away from one), and the frame labels agree everywhere."""
+    rng = np.random.default_rng(0)
+    hop, n_fft, n_frame, C = 64, 256, 40, 2
+    bg = rng.standard_normal((C, hop * 70)).astype(np.float32)             # longer than the crop: no tiling seam
+    voices = [rng.standard_normal((C, hop * k)).astype(np.float32) for k in (24, 24, 24)]
+    voices[1][:, hop * 9:] = 0                                               # a silent tail: inactive frames
+    labels = np.eye(3, dtype=np.float32)[[0, 1, 2]]
+    noises = [rng.standard_normal((C, hop * k)).astype(np.float32) for k in (30, 30)]
+    to_spec = lambda w: R.to_ref_layout(R.stft(w, n_fft, hop))               # noqa: E731  [F, T, 2C]
+    for seed in range(6):
+        d = {"bg_offset": int(rng.integers(0, 20)), "n_voices": 2, "v_gain": [0.5, 0.25],
+             "v_offset": [int(rng.integers(0, 10)), int(rng.integers(0, 10))], "n_noises": 1, "n_gain": [0.1],
+             "n_offset": [int(rng.integers(0, 10))]}
+        wav, lw = R.mix_waves_apply(bg, voices, labels, noises, d, n_frame=n_frame, n_classes=3, hop=hop, n_fft=n_fft,
+                                    min_ratio=1, min_noise_ratio=1)
+        assert wav.shape == (C, (n_frame - 1) * hop)
+        spec, ls = R.merge_complex_specs_apply(to_spec(bg), [to_spec(v) for v in voices], labels,
+                                               [to_spec(n) for n in noises], d, n_frame=n_frame, n_classes=3,
+                                               min_ratio=1, min_noise_ratio=1)
+        assert np.array_equal(lw, ls)                                        # same activity, same overlap rule
+        got = to_spec(wav)
+        assert got.shape == spec.shape
+        # boundaries in output-frame coordinates: the output's own edges and each used source's start / end
+        t_src = 1 + voices[0].shape[1] // hop
+        pad_v = max(n_frame - t_src, 0)
+        t_n = 1 + noises[0].shape[1] // hop
+        pad_n = max(n_frame - t_n, 0)
+        edges = [0, n_frame - 1]
+        for v in range(2):
+            edges += [pad_v - d["v_offset"][v], pad_v - d["v_offset"][v] + t_src - 1]
+        edges += [pad_n - d["n_offset"][0], pad_n - d["n_offset"][0] + t_n - 1]
+        interior = np.array([all(abs(t - e) > 2 for e in edges) for t in range(n_frame)])
+        assert interior.sum() >= 8
+        scale = np.abs(spec).max()
+        assert np.abs(got[:, interior] - spec[:, interior]).max() <= 2e-5 * scale
+        assert np.abs(got[:, ~interior] - spec[:, ~interior]).max() > 1e-3 * scale   # ... and the boundary frames do differ

@@ -230,6 +230,11 @@ def test_train_step_on_gpu(dev):
     for _ in range(10):
         last = float(model.train_step((x, y))['loss'])
     assert math.isfinite(last) and last < first
+    # inference copy with the BatchNorms folded in: the same function on the device (MIOpen convolutions, channels_last)
+    folded = S.fold_batchnorm(model)
+    with torch.no_grad():
+        ref, got = model.eval()(x), folded(x)
+    assert got.is_cuda and float((ref - got).abs().max()) <= 1e-4, float((ref - got).abs().max())
 
 
 def test_wave_frontend_device_draw(dev):
@@ -392,6 +397,106 @@ def test_device_dataset_equals_per_sample_stages(dev, n_chan, name):
             assert float(bx.max()) <= 1e-6 and float(bx.min()) >= np.log(1e-8) - 1e-3
 
 
+def test_wave_mixer_matches_oracle_and_the_spectrum_domain_mixer(dev):
+    """Waveform-domain batched synthesis (iris_mix_waves; SURVEY.md section 8 (f) rank 1, second half):
+    bit-exact against the oracle's waveform-domain restatement (ragged sources, padded groups, tiled
+    backgrounds, silent tails, dropped voices), and - the STFT being linear - equal to the spectrum-domain
+    mixer run on the sources' STFTs on every frame whose window crosses no crop / pad / tiling boundary."""
+    from challenge_amd.mixer import DeviceMixer, WaveMixer
+    FE = __import__("challenge_amd.frontend", fromlist=["FrontendPlan"])
+    rng = np.random.default_rng(13)
+    C, hop, n_fft, n_frame, n_classes = 2, 64, 256, 48, 3
+
+    def clip(n, silent_from=None):
+        x = (rng.standard_normal((C, n)) * 0.3).astype(np.float32)
+        if silent_from is not None:
+            x[:, silent_from:] = 0
+        return x
+    backgrounds = [clip(n) for n in (hop * 20 + 7, hop * 90, hop * 48 + 33)]
+    voices = [clip(n, s) for n, s in ((hop * 30, hop * 20), (hop * 55 + 5, None), (hop * 41, hop * 5), (hop * 64, hop * 50),
+                                      (hop * 25 + 60, None), (hop * 48, hop * 30), (hop * 36, None))]
+    labels = np.eye(n_classes, dtype=np.float32)[rng.integers(0, n_classes, len(voices))]
+    noises = [clip(n) for n in (hop * 18, hop * 90 + 9, hop * 40, hop * 52)]
+    mixer = WaveMixer(backgrounds, voices, labels, noises, n_frame=n_frame, n_fft=n_fft, hop=hop, max_voices=4,
+                      max_noises=3, n_classes=n_classes, device=dev, min_ratio=1, seed=5)
+    draws = mixer.draw(16)
+    wav, lab = mixer.mix(16, draws)
+    assert wav.shape == (16, C, (n_frame - 1) * hop) and lab.shape == (16, 4, n_frame, n_classes)
+    wav_h, lab_h = wav.cpu().numpy(), lab.cpu().numpy()
+    dropped = 0
+    for i, d in enumerate(draws):
+        ref_wav, ref_lab = R.mix_waves_apply(backgrounds[d["bg"]], [voices[k] for k in d["voices"]], labels[d["voices"]],
+                                             [noises[k] for k in d["noises"]], d, n_frame=n_frame, n_classes=n_classes,
+                                             hop=hop, n_fft=n_fft, min_ratio=1)
+        assert np.array_equal(wav_h[i], ref_wav), i
+        assert np.array_equal(lab_h[i], ref_lab), i
+        dropped += int(d["n_voices"] - (ref_lab.max(axis=(1, 2)) > 0).sum())
+    assert dropped > 0
+    # activity flags of the waveform sources == the oracle's
+    for v, act in zip(voices, mixer.voice_active):
+        assert np.array_equal(act.cpu().numpy(), R.wave_frame_active(v, n_fft, hop))
+    # linearity: the same draws through the spectrum-domain mixer on the sources' STFTs (frame counts agree: 1 + L // hop)
+    to_spec = lambda w: R.to_ref_layout(R.stft(w, n_fft, hop))  # noqa: E731
+    smix = DeviceMixer([to_spec(b) for b in backgrounds], [to_spec(v) for v in voices], labels,
+                       [to_spec(n) for n in noises], n_frame=n_frame, max_voices=4, max_noises=3, n_classes=n_classes,
+                       device=dev, min_ratio=1, seed=5)
+    spec, slab = smix.mix(16, draws)
+    assert torch.equal(slab, lab)                      # same labels: same activity, same overlap rule
+    plan = FE.FrontendPlan(n_fft, hop, 20, 16000, C, 16, (n_frame - 1) * hop, dev)
+    got = plan.stft(wav).cpu().numpy()                 # [B, F, n_frame, 2C]
+    spec = spec.cpu().numpy()
+    checked = 0
+    for i, d in enumerate(draws):
+        t_bg = 1 + backgrounds[d["bg"]].shape[1] // hop
+        edges = [0, n_frame - 1] + [k * t_bg - d["bg_offset"] for k in range(1, 6)] + [k * t_bg - d["bg_offset"] - 1 for k in range(1, 6)]
+        pad_v = max(n_frame - int(d["v_len"]), 0)
+        for j in range(d["n_voices"]):
+            tv = 1 + voices[d["voices"][j]].shape[1] // hop
+            edges += [pad_v - d["v_offset"][j], pad_v - d["v_offset"][j] + tv - 1]
+        pad_n = max(n_frame - int(np.float32(0.5) * np.float32(d["n_len"])), 0)
+        for j in range(d["n_noises"]):
+            tn = 1 + noises[d["noises"][j]].shape[1] // hop
+            edges += [pad_n - d["n_offset"][j], pad_n - d["n_offset"][j] + tn - 1]
+        interior = np.array([all(abs(t - e) > 2 for e in edges) for t in range(n_frame)])
+        if t_bg < n_frame + d["bg_offset"]:            # a tiled background drifts (period t_bg frames vs L samples): skip
+            continue
+        checked += int(interior.sum())
+        scale = np.abs(spec[i]).max()
+        assert np.abs(got[i][:, interior] - spec[i][:, interior]).max() <= 3e-5 * scale, i
+    assert checked >= 40
+
+
+def test_make_wave_dataset_matches_oracle_chain(dev):
+    """sj_train.make_wave_dataset: waveforms resident on the device -> WaveMixer -> fused kernel with SpecAugment /
+    filter bands -> log-mel, against the oracle chain (mix_waves_apply is checked above; here mixer output ->
+    wav_to_logmel with the same bands), for the stereo and the mono-sum configurations."""
+    T, D, S = mods()
+    from challenge_amd.mixer import WaveMixer
+    for n_chan, name in ((2, ''), (1, 'filter')):
+        cfg = S.ARGS().get(['--v', '9', '--n_mels', '40', '--n_frame', '64', '--n_chan', str(n_chan), '--batch_size', '5',
+                            '--max_voices', '4', '--max_noises', '3', '--name', name])
+        src = S.synthetic_wave_sources(2, 3, 256, n_bg=3, n_voice=7, n_noise=4, seed=3)
+        ds = iter(S.make_wave_dataset(cfg, training=True, sources=src, device=dev, seed=9))
+        x, y = next(ds)
+        assert tuple(x.shape) == (5, 40, 64, n_chan) and tuple(y.shape) == (5, 2, 3) and x.is_cuda
+        # replay: same seeds -> same mix and the same band draws
+        onehot = np.eye(3, dtype=np.float32)[np.asarray(src[2])]
+        mixer = WaveMixer(src[0], src[1], onehot, src[3], n_frame=64, n_fft=512, hop=256, max_voices=4, max_noises=3,
+                          n_classes=3, device=dev, min_ratio=1, seed=9)
+        wav, lab = mixer.mix(5)
+        wav = wav.cpu().numpy()
+        if n_chan == 1:
+            wav = wav[:, :1] + wav[:, 1:]
+        tb, fb = D.augment_draw_batch(5, 64, 257, np.random.default_rng(10))
+        if name == 'filter':
+            k = int(round(200 / (16000 / 256)))
+            fb = np.concatenate([fb, np.tile(np.array([[[1, k]]], np.int32), (5, 1, 1))], axis=1)
+        ref = R.wav_to_logmel(wav, 512, 256, 40, 16000, t_bands=tb, f_bands=fb)
+        assert np.abs(np.exp(x.cpu().numpy()) - np.exp(ref)).max() <= 5e-6
+        ref_y = R.label_downsample(32)(None, R.to_frame_labels(None, lab.cpu().numpy())[1])[1]
+        assert np.array_equal(y.cpu().numpy(), ref_y)
+
+
 def test_drop_in_merge_on_device_matches_oracle(dev):
     """The per-sample drop-in `merge_complex_specs_apply` on device tensors (HIP path) == the oracle,
     bit for bit, and == its own op-by-op torch form on the CPU."""
@@ -530,6 +635,12 @@ def test_sj_train_main_two_epochs(dev, tmp_path, monkeypatch):
     model.load_state_dict(ckpt)
     model.load_state_dict(swa)
     assert set(ckpt) == set(swa) == set(model.state_dict())
+    # the same entry point fed from waveform corpora mixed before the STFT (make_wave_dataset): one epoch
+    S.main(['--online_stft', '--epochs', '1', '--steps_per_epoch', '2', '--validation_steps', '1', '--batch_size', '8',
+            '--n_frame', '128', '--v', '9', '--n_mels', '32', '--name', 'pywave'])
+    with open(tmp_path / 'pywave_vad_v9_lr0.001_batch8_opt_adam_mel32_chan2_BCE_framelen128.csv') as f:
+        rows = list(csv.DictReader(f))
+    assert len(rows) == 1 and math.isfinite(float(rows[0]['loss'])) and math.isfinite(float(rows[0]['val_loss']))
 
 
 def test_bench_self_launch_two_ranks(dev):
