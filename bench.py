@@ -158,10 +158,18 @@ def side_measurements(dev, rank, world, steps, fence):
                                     device=dev, seed=rank))
     t_data = timed(lambda: next(ds), steps)
     del ds
+    # the same from WAVEFORM corpora: mixed before the STFT (iris_mix_waves), then the fused kernel with bands
+    wds = iter(S.make_wave_dataset(dcfg, True, sources=S.synthetic_wave_sources(2, 3, HOP, n_bg=16, n_voice=64, n_noise=32,
+                                                                              seed=rank), device=dev, seed=rank))
+    t_wdata = timed(lambda: next(wds), steps)
+    del wds
     return {
         "device_dataset": {"ms_per_batch": round(1e3 * t_data, 3), "batch_per_gpu": batch,
                            "audio_s_per_s": round(world * batch * 512 * HOP / SR / t_data, 1),
                            "shape": "spectra [257, T_i, 4] resident in HBM -> log-mel [64, 80, 512, 2] + labels"},
+        "wave_dataset": {"ms_per_batch": round(1e3 * t_wdata, 3), "batch_per_gpu": batch,
+                         "audio_s_per_s": round(world * batch * 511 * HOP / SR / t_wdata, 1),
+                         "shape": "waveforms [2, L_i] resident in HBM -> mixed [64, 2, 130816] -> log-mel [64, 80, 512, 2] + labels"},
         "c3_frontend_specaug_crnn_fwd": {"audio_s_per_s": round(world * audio_s / t_fwd, 1),
                                          "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch,
                                          "bn_folded_for_inference": {"audio_s_per_s": round(world * audio_s / t_fwd_folded, 1),
