@@ -250,7 +250,11 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
     auto issue_dma = [&](const int (&ff)[S], int b, int t0, int nwf) {
         const float* clip0 = a.wav + (size_t)b * a.C * a.L;
 #pragma unroll
-        for (int st = 0; st < S; ++st)
+        for (int st = 0; st < S; ++st) {
+            if (ff[st] < nwf && ABL(8) && ABL(64)) {  // diag: the frame comes from LDS instead (cost of an LDS-resident sample ring)
+#pragma unroll
+                for (int q = 0; q < P; ++q) x[st][q] = const_cast<const volatile cf*>(lds[st])[lane + kWave * q];
+            }
             if (ff[st] < nwf && !ABL(8)) {
                 const int tl = (a.C == 1) ? ff[st] : ff[st] / a.C, c = ff[st] - tl * a.C;
                 if constexpr (DIRECT)
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
                 else
                     dma_frame<LOG2N>(clip0 + (size_t)c * a.L, a.L, (t0 + tl) * a.hop - N / 2, fbuf_lds[st], lane);
             }
+        }
     };
     int f[S], fn[S];  // frames in registers / frames in flight to the landing buffers
     if (g0 < a.n_chunks) {  // first frames of the first chunk: in flight while the constants are fetched

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3c; mkdir -p $O
-timeout -k 10 900 python scripts/gpu_fuzz.py 700 2026 > $O/fuzz.log 2>&1; echo "fuzz rc $?"; tail -2 $O/fuzz.log
-timeout -k 10 400 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
-python3 -c "
-import json;d=json.load(open('$O/bench.json'));print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['traffic'], d['roofline'].get('traffic_source')); print(d['extra']['device_dataset']['ms_per_batch'], d['extra']['wave_dataset'])"
+O=gpurun_out/r3d; mkdir -p $O
+for mode in "" "--resident"; do
+for ab in 512 520 584; do
+  echo "== $mode IRIS_ABLATE=$ab"
+  IRIS_LIB=$GRAFT_REPO_ROOT/challenge_amd/csrc/libiris_frontend_diag.so IRIS_ABLATE=$ab timeout 300 python3 bench.py $mode --steps 50 --warmup 10 --no-cpu-baseline --no-extras 2>&1 | grep -E "256 workgroups"
+done; done 2>&1 | tee $O/abl_ring.log
