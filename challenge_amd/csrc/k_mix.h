@@ -172,28 +172,54 @@ __global__ __launch_bounds__(256) void k_mix_wave_frame_active(const float* wav,
     if (threadIdx.x == 0 && t < n_frames) active[t] = any ? 1.f : 0.f;
 }
 
-// wav_out[b, c, s] = background + accepted voices + noises, table order, separately rounded multiply and add
+// wav_out[b, c, s] = background + accepted voices + noises, table order, separately rounded multiply and add.
+// Four consecutive samples per thread: 16-byte loads and stores where a source's four samples are contiguous,
+// aligned and inside the clip (hop-granular offsets make that the rule), element by element otherwise.
 __global__ __launch_bounds__(256) void k_mix_wave_sum(const iris_mix_src* srcs, const int32_t* first, const float* flags,
                                                       float* out, int channels, int hop, int out_len) {
 #pragma clang fp contract(off)
-    const int b = blockIdx.z, c = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z, c = blockIdx.y, s = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (s >= out_len) return;
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int si = first[b]; si < first[b + 1]; ++si) {
         const iris_mix_src r = srcs[si];  // uniform
         const int len = r.reserved;
         const float* row = r.src + (size_t)c * len;
+        const bool row16 = (reinterpret_cast<uintptr_t>(row) & 15) == 0;  // (uniform) this channel's row starts on 16 bytes
         if (r.kind == 0) {
-            acc = row[(int)(((long long)r.off * hop + s) % len)];
+            const int p0 = (int)(((long long)r.off * hop + s) % len);
+            if (row16 && (p0 & 3) == 0 && p0 + 3 < len) {
+                const float4 v = *reinterpret_cast<const float4*>(row + p0);
+                acc[0] = v.x; acc[1] = v.y; acc[2] = v.z; acc[3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = row[(p0 + j) % len];
+            }
             continue;
         }
         const float keep = r.kind == 1 ? flags[si] : 1.f;
         const long long ss = (long long)s + (long long)(r.off - r.pad) * hop;
-        if (ss < 0 || ss >= len || keep == 0.f) continue;  // adds exactly zero
-        const float scaled = r.gain * row[ss];
-        acc = acc + scaled;
+        if (ss + 3 < 0 || ss >= len || keep == 0.f) continue;  // adds exactly zero
+        if (row16 && ss >= 0 && ss + 3 < len && (ss & 3) == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(row + ss);
+            const float sc[4] = {r.gain * v.x, r.gain * v.y, r.gain * v.z, r.gain * v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + sc[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ss + j >= 0 && ss + j < len) {
+                    const float scaled = r.gain * row[ss + j];
+                    acc[j] = acc[j] + scaled;
+                }
+        }
     }
-    out[((size_t)b * channels + c) * out_len + s] = acc;
+    float* o = out + ((size_t)b * channels + c) * out_len + s;
+    if (s + 3 < out_len && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+        *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+        for (int j = 0; j < 4 && s + j < out_len; ++j) o[j] = acc[j];
+    }
 }
 
 extern "C" int iris_mix_wave_frame_active(const float* wav, int channels, int len, int n_fft, int hop, float* active_out,
@@ -230,7 +256,7 @@ extern "C" int iris_mix_waves(const iris_mix_src* srcs_dev, int n_srcs, const in
     const int out_len = (n_frame - 1) * hop;
     k_mix_labels<<<batch, 256, lds, s>>>(srcs_dev, first_dev, label_vecs_dev, flags, labels_out, n_frame, max_voices,
                                          n_classes);
-    k_mix_wave_sum<<<dim3((unsigned)((out_len + 255) / 256), channels, batch), 256, 0, s>>>(srcs_dev, first_dev, flags,
+    k_mix_wave_sum<<<dim3((unsigned)((out_len + 1023) / 1024), channels, batch), 256, 0, s>>>(srcs_dev, first_dev, flags,
                                                                                           wav_out, channels, hop, out_len);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;

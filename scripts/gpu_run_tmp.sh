@@ -1,25 +1,21 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r3i; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_frontend_gpu.py -x -q -m gpu 2>&1 | tail -2
-for i in 1 2 3; do for pr in 0 1; do
- IRIS_PAIR=$pr python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
-import sys,json
-r=json.loads(sys.stdin.readline()); print('pair $pr', 'kernel_ms', r['roofline']['kernel_ms'], 'ms_per_step', r['ms_per_step'])"
-done; done 2>&1 | tee $O/ab.log
-for pr in 0 1; do
- IRIS_PAIR=$pr python3 bench.py --resident --steps 300 --warmup 30 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
-import sys,json
-r=json.loads(sys.stdin.readline()); print('resident pair $pr', 'kernel_ms', r['roofline']['kernel_ms'], 'ms_per_step', r['ms_per_step'])"
-done 2>&1 | tee -a $O/ab.log
-PMC_OUT=pmc_pair bash scripts/gpu_pmc.sh "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" > gpurun_out/pmc_pair.log 2>&1
-python3 - <<'PY'
-import csv,glob,collections
-agg=collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob('gpurun_out/pmc_pair/p*/**/*counter_collection.csv',recursive=True):
-    for r in csv.DictReader(open(f)):
-        agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
-for k,v in agg.items():
-    if 'k_wav_to_mel' in k:
-        print(k[:50], {c: round(sum(x)/len(x)/20032,1) for c,x in v.items()})
+O=$GRAFT_REPO_ROOT/gpurun_out/r3k; rm -rf $O; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_transforms_gpu.py -x -q -m gpu -k "wave" 2>&1 | tail -2
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o wave -- python3 - > $O/wave_prof.log 2>&1 <<'PY'
+import sys, os
+sys.path.insert(0, os.getcwd())
+import torch
+from challenge_amd import sj_train as S
+dev = torch.device("cuda", 0)
+cfg = S.ARGS().get(['--v', '9', '--n_mels', '80', '--n_frame', '512', '--n_chan', '2', '--batch_size', '64'])
+ds = iter(S.make_wave_dataset(cfg, True, sources=S.synthetic_wave_sources(2, 3, 256, n_bg=16, n_voice=64, n_noise=32, seed=0), device=dev, seed=0))
+for _ in range(30): next(ds)
+torch.cuda.synchronize()
 PY
+python3 - $O/prof/wave_kernel_stats.csv <<'PY'
+import csv,sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:4]:
+    print('%-70s calls=%4s avg_us=%8.1f' % (r['Name'][:70], r['Calls'], float(r['AverageNs'])/1e3))
+PY
+find $O -name "*kernel_trace.csv" -delete
