@@ -1,21 +1,6 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r3k; rm -rf $O; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_transforms_gpu.py -x -q -m gpu -k "wave" 2>&1 | tail -2
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o wave -- python3 - > $O/wave_prof.log 2>&1 <<'PY'
-import sys, os
-sys.path.insert(0, os.getcwd())
-import torch
-from challenge_amd import sj_train as S
-dev = torch.device("cuda", 0)
-cfg = S.ARGS().get(['--v', '9', '--n_mels', '80', '--n_frame', '512', '--n_chan', '2', '--batch_size', '64'])
-ds = iter(S.make_wave_dataset(cfg, True, sources=S.synthetic_wave_sources(2, 3, 256, n_bg=16, n_voice=64, n_noise=32, seed=0), device=dev, seed=0))
-for _ in range(30): next(ds)
-torch.cuda.synchronize()
-PY
-python3 - $O/prof/wave_kernel_stats.csv <<'PY'
-import csv,sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:4]:
-    print('%-70s calls=%4s avg_us=%8.1f' % (r['Name'][:70], r['Calls'], float(r['AverageNs'])/1e3))
-PY
-find $O -name "*kernel_trace.csv" -delete
+for i in 1 2; do for ev in "--event-every 4" "--event-every 10" "--event-every 20" "--no-kernel-events"; do
+ python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-extras $ev 2>/dev/null | python3 -c "
+import sys,json
+r=json.loads(sys.stdin.readline()); print('$ev', 'ms_per_step', r['ms_per_step'], 'kernel_ms', r['roofline']['kernel_ms'], 'n', r['roofline']['launches_timed'])"
+done; done
