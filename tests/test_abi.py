@@ -66,6 +66,16 @@ def test_argument_validation_without_gpu():
     assert lib.iris_normalize_workspace(32, 160000) == 32 * 40
     assert lib.iris_mask_apply(None, 1, 1, 1, 4, None, 0, 1, None) == -1
     assert lib.iris_mask_apply(C.c_void_p(8), 1, 1, 1, 2, None, 0, 1, None) == -2
+    # batched synthesis, spectrum and waveform domain: NULL / inconsistent sizes are rejected before any launch
+    p8 = C.c_void_p(8)
+    assert lib.iris_mix_specs(None, 1, None, None, None, None, 1, 257, 64, 4, 4, 3, None, 0, None) == -1
+    assert lib.iris_mix_specs(p8, 1, p8, p8, p8, p8, 1, 257, 64, 3, 4, 3, p8, 1, None) == -2        # chan2 not in {1,2,4,8}
+    assert lib.iris_mix_waves(None, 1, None, None, None, None, 1, 2, 256, 64, 4, 3, None, 0, None) == -1
+    assert lib.iris_mix_waves(p8, 1, p8, p8, p8, p8, 2, 2, 256, 64, 4, 3, p8, 1, None) == -1        # fewer sources than samples
+    assert lib.iris_mix_waves(p8, 4, p8, p8, p8, p8, 1, 2, 256, 64, 4, 3, p8, 1, None) == -3        # workspace too small
+    assert lib.iris_mix_waves(p8, 1, p8, p8, p8, p8, 1, 2, 256, 1, 4, 3, p8, 1, None) == -1         # n_frame must exceed 1
+    assert lib.iris_mix_wave_frame_active(None, 1, 100, 1024, 256, None, None) == -1
+    assert lib.iris_mix_wave_frame_active(p8, 1, 100, 1024, 0, p8, None) == -1
 
 
 def test_product_code_refuses_cpu_tensors():
