@@ -183,22 +183,22 @@ def side_measurements(dev, rank, world, steps, fence):
 def two_stream(dev, wavs, outs, plan_a, fence, n):
     """The c2 step issued alternately on two streams, each with its own plan (a plan's workspace belongs to one
     stream, include/iris_frontend.h).  Same rotating batches as the headline; returns whole-job throughput."""
-    from challenge_amd.frontend import FrontendPlan
+    from challenge_amd.frontend import PipelinedFrontend
     length = wavs[0].shape[-1]
-    plan_b = FrontendPlan(N_FFT, HOP, N_MEL, SR, 1, BATCH, length, dev)
-    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-    plans = [plan_a, plan_b]
+    pipe = PipelinedFrontend(2, n_fft=N_FFT, hop=HOP, n_mel=N_MEL, sample_rate=SR, channels=1, max_batch=BATCH,
+                             max_len=length, device=dev)
 
     def run(k):
         for i in range(k):
             j = i % len(wavs)
-            with torch.cuda.stream(streams[i & 1]):
-                plans[i & 1].wav_to_logmel(wavs[j], minmax=True, log=True, out=outs[j])
+            pipe.submit(wavs[j], wait_current=False, minmax=True, log=True, out=outs[j])  # long-lived, complete buffers
     fence()
     run(20)
+    pipe.synchronize()
     fence()
     t0 = time.perf_counter()
     run(n)
+    pipe.synchronize()
     fence()
     dt = (time.perf_counter() - t0) / n
     return {"us_per_step": round(1e6 * dt, 2), "audio_s_per_s": round(BATCH * SECONDS / dt, 1), "streams": 2, "steps": n}

@@ -227,6 +227,53 @@ class FrontendPlan:
 # ---------------------------------------------------------------------------
 # plan-free ops (run on the tensor's device / current stream)
 # ---------------------------------------------------------------------------
+class PipelinedFrontend:
+    """Independent batches through the fused path on `n_streams` HIP streams, one `FrontendPlan` each (a plan's
+    workspace belongs to one stream, include/iris_frontend.h): one stream's min-max/log kernel and launch gaps run in
+    the shadow of another's fused kernel.  c2 on one MI355X: 22.9 us per batch on two streams against 25.6 us on one.
+
+        pipe = PipelinedFrontend(2, n_fft=1024, hop=256, n_mel=64, channels=1, max_batch=32, max_len=160000, device=dev)
+        for wav, out in batches:                 # device tensors; `out` is written asynchronously
+            pipe.submit(wav, out=out)
+        pipe.synchronize()                       # ... or order consumers after pipe.streams[i] with events
+
+    The caller's current stream at `submit` time is waited for (inputs produced on it are ready), and every submit's
+    stream is joined back by `synchronize()` / `join()` so that later work on the current stream sees the outputs."""
+
+    def __init__(self, n_streams: int = 2, **plan_kwargs):
+        if n_streams < 1:
+            raise ValueError("n_streams must be >= 1")
+        self.plans = [FrontendPlan(**plan_kwargs) for _ in range(n_streams)]
+        self.device = self.plans[0].device
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(n_streams)]
+        self._next = 0
+
+    def submit(self, wav: torch.Tensor, wait_current: bool = True, **kwargs) -> torch.Tensor:
+        """wait_current=False skips the event wait on the current stream and the allocator bookkeeping (about 7 us
+        of host time per call, enough to make a 23 us step host-bound): for inputs and `out` buffers that are
+        long-lived and already complete, as in a steady-state loop over preallocated batches."""
+        i, self._next = self._next, (self._next + 1) % len(self.plans)
+        stream = self.streams[i]
+        if wait_current:
+            stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(stream):
+            out = self.plans[i].wav_to_logmel(wav, **kwargs)
+        if wait_current:
+            wav.record_stream(stream)
+            out.record_stream(stream)
+        return out
+
+    def join(self) -> None:
+        """Order the current stream after everything submitted so far (no host wait)."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+
+    def synchronize(self) -> None:
+        for s in self.streams:
+            s.synchronize()
+
+
 def normalize(wav: torch.Tensor) -> torch.Tensor:
     """wav / (10 rms) with the rms over the whole tensor for [C,L] input
     (data_utils.py:32-34) or per leading item for [B,C,L]."""

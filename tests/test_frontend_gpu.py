@@ -330,6 +330,24 @@ def test_side_stream_and_graph_capture(dev):
     assert torch.equal(static_out, plan.wav_to_logmel(wav))
 
 
+def test_pipelined_frontend_equals_single_plan(dev):
+    """PipelinedFrontend: independent batches alternate over two streams with a plan each; every output equals the
+    single-plan result, inputs produced on the current stream are waited for, join() orders the consumer."""
+    rng = np.random.default_rng(43)
+    plan = FE().FrontendPlan(1024, 256, 64, 16000, 1, 4, 20000, dev)
+    pipe = FE().PipelinedFrontend(2, n_fft=1024, hop=256, n_mel=64, sample_rate=16000, channels=1, max_batch=4,
+                                  max_len=20000, device=dev)
+    wavs = [torch.from_numpy((rng.standard_normal((4, 1, 20000)) * 0.1).astype(np.float32)).to(dev) for _ in range(7)]
+    scaled = [w * 0.5 for w in wavs]                      # produced on the current stream right before the submit
+    outs = [pipe.submit(w) for w in scaled]
+    pipe.join()
+    total = torch.stack(outs).sum()                       # a consumer on the current stream
+    pipe.synchronize()
+    for w, o in zip(scaled, outs):
+        assert torch.equal(o, plan.wav_to_logmel(w))
+    assert torch.isfinite(total)
+
+
 def test_two_plans_interleaved(dev):
     """Distinct plans are independent: interleaved launches on one stream do not disturb
     each other's workspace."""
