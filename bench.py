@@ -9,18 +9,24 @@ min-max -> log, data resident in HBM) over BASELINE.json configs[1]: a batch of
 rotate through ROTATE distinct batches (inputs AND outputs, > 256 MiB touched per cycle),
 so that every step's waveform comes from HBM and not from the 256 MiB Infinity Cache.
 
+Order of a run: an untimed pre-conditioning burst (clock / cache state of a busy GPU), the W
+warm-up steps, the K timed steps (no event pairs, nothing but the steps on the stream), then -
+untimed and separate - the kernel-timing pass: KERNEL_PASS more rotating steps with a HIP
+event pair around each kernel on the launch stream, from which `roofline` is computed.
+
 With N > 1 there is one process per GPU: launched by the driver through
 torch.distributed.run, or - when WORLD_SIZE is unset - by this script itself, which starts
 `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a fresh child process
 before it touches the GPU and relays the child's JSON line and exit code.  Every rank runs
 the same batch shape on its own clips (independent clips: no data-path collective, weak
-scaling) and the job throughput is the sum.  Rank 0 prints ONE JSON line.
+scaling; `--strong` splits a fixed global batch instead) and the job throughput is the sum.
+Rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
 import hashlib
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -35,8 +41,13 @@ if ROOT not in sys.path:
 SR, N_FFT, HOP, N_MEL = 16000, 1024, 256, 64
 BATCH, SECONDS = 32, 10
 ROTATE = 20  # distinct c2 batches per cycle: 20 x (20.5 MB in + 5.1 MB out) = 512 MB > 256 MiB Infinity Cache
+PRECONDITION = 200  # untimed steps before the warm-up: the GPU reaches the clock / cache state of a busy device
+KERNEL_PASS = 100   # event-timed launches of each kernel in the separate, untimed kernel-timing pass
+STRONG_GLOBAL_BATCH = 256       # --strong: c2 clips over all ranks (= 8 x 32)
+STRONG_GLOBAL_TRAIN_BATCH = 512  # --strong: c4 training batch over all ranks
 ALGO_BYTES_PER_AUDIO_S = 4 * SR + 4 * N_MEL * SR // HOP  # fp32 wave in + fp32 mel out = 80,000
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+PMC_JSON = os.path.join("profiles", "r3", "pmc_traffic.json")
 
 
 def cpu_baseline(wav_cpu: np.ndarray):
@@ -96,22 +107,22 @@ def cpu_baseline(wav_cpu: np.ndarray):
     }
 
 
-def side_measurements(dev, rank, world, steps, fence):
+def side_measurements(dev, rank, world, steps, fence, strong=False):
     """BASELINE configs[2] and [3], reported beside the headline (never as `value`):
     c3 = fused frontend with SpecAugment + CRNN v9 forward, batch 64 x 8.176 s (T = 512);
     c4 = the full training step (frontend, forward, backward, RCCL gradient all-reduce via
-    DDP when world > 1, AGC, clipvalue, Adam), batch 64 per GPU, synthetic labels."""
+    DDP when world > 1, AGC, clipvalue, Adam), batch 64 per GPU (--strong: 512 / world), synthetic labels."""
     import torch.distributed as dist
     from challenge_amd import sj_train as S
     S.configure_miopen()  # NORMAL find without the naive reference solvers (see sj_train.configure_miopen)
-    batch, length = 64, 130816
+    batch, length = (STRONG_GLOBAL_TRAIN_BATCH // world if strong else 64), 130816
     audio_s = batch * length / SR
     cfg = S.ARGS().get(['--v', '9', '--n_mels', str(N_MEL), '--n_frame', '512', '--n_chan', '1',
                         '--batch_size', str(batch)])
     torch.manual_seed(0)
     model = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
-    model.compile(S.make_optimizer(cfg, model.parameters()), S.binary_crossentropy, clipvalue=cfg.clipvalue,
-                  ddp=S.wrap_ddp(model, dev, world))
+    ddp = S.wrap_ddp(model, dev, world)
+    model.compile(S.make_optimizer(cfg, model.parameters()), S.binary_crossentropy, clipvalue=cfg.clipvalue, ddp=ddp)
     fe = S.WaveFrontend(N_FFT, HOP, N_MEL, SR, 1, batch, length, dev, training=True, device_draw=True,
                         seed=99 + rank)
     gen = torch.Generator(device=dev).manual_seed(4321 + rank)
@@ -138,22 +149,82 @@ def side_measurements(dev, rank, world, steps, fence):
         with torch.no_grad():
             model(fe(wav))
 
-    folded = S.fold_batchnorm(model)  # inference copy: eval-mode BatchNorm folded into the conv / dense in front of it
-
-    def fwd_folded():
-        with torch.no_grad():
-            folded(fe(wav))
+    infer = S.InferenceEngine(model, fe, wav)  # BN folded, conv + bias + ReLU fused, frontend + forward as one hipGraph
 
     def train():
         model.train_step((fe(wav), y))
 
     t_fwd = timed(fwd, steps)
-    t_fwd_folded = timed(fwd_folded, steps)
+    t_fwd_folded = timed(infer.eager, steps)
+    t_fwd_graph = timed(infer.replay, steps) if infer.graph_ok else None
     t_train = timed(train, steps)
+
+    # where the training step goes: device time per phase from events on the stream (one extra pass, untimed)
+    phases = {}
+    for _ in range(max(3, steps // 2)):
+        marks = []
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        x = fe(wav)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+
+        def mark(name):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+        model.train_step((x, y), _mark=mark)
+        torch.cuda.synchronize(dev)
+        prev, seq = e0, [("frontend", e1)] + marks
+        for name, e in seq:
+            phases.setdefault(name, []).append(prev.elapsed_time(e))
+            prev = e
+    breakdown = {k + "_ms": round(float(np.median(v)), 3) for k, v in phases.items()}
+
+    # exposed gradient all-reduce: the same step with the collectives switched off (DDP.no_sync), A/B
+    comm = None
+    if ddp is not None:
+        def train_nosync():
+            with ddp.no_sync():
+                model.train_step((fe(wav), y))
+        t_nosync = timed(train_nosync, steps)
+        comm = {"step_ms_with_allreduce": round(1e3 * t_train, 3), "step_ms_no_sync": round(1e3 * t_nosync, 3),
+                "exposed_allreduce_ms_per_step": round(1e3 * (t_train - t_nosync), 3),
+                "grad_bytes": 4 * sum(p.numel() for p in model.parameters()), "bucket_cap_mb": 25}
+
+    # opt-in bf16 autocast variant of the forward and the training step, with its deviation from fp32 stated
+    bf16 = None
+    try:
+        model.eval()
+        with torch.no_grad():
+            feats = fe(wav)
+            ref = model(feats)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                lo = model(feats).float()
+        dev_abs = float((lo - ref).abs().max())
+
+        def fwd_bf16():
+            model.eval()
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                model(fe(wav))
+
+        def train_bf16():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                model.train_step((fe(wav), y))
+        t_fb = timed(fwd_bf16, steps)
+        t_tb = timed(train_bf16, steps)
+        bf16 = {"fwd_ms_per_step": round(1e3 * t_fb, 3), "fwd_audio_s_per_s": round(world * audio_s / t_fb, 1),
+                "train_ms_per_step": round(1e3 * t_tb, 3), "train_audio_s_per_s": round(world * audio_s / t_tb, 1),
+                "max_abs_dev_of_sigmoid_outputs_vs_fp32": round(dev_abs, 6),
+                "note": "opt-in (torch.autocast bf16 around the CRNN only; the frontend stays fp32); the reference trains in "
+                        "fp32, so fp32 stays the default and the reported metric"}
+    except Exception as exc:  # an opt-in extra must never take the bench line down
+        bf16 = {"error": repr(exc)[:200]}
 
     # input side of the reference's own training loop (spectra in, sj_train.py:74-130) at its default
     # shape: whole batches synthesised on the device (iris_mix_specs + mel kernel with bands)
-    dcfg = S.ARGS().get(['--v', '9', '--n_mels', '80', '--n_frame', '512', '--n_chan', '2', '--batch_size', str(batch)])
+    dbatch = 64
+    dcfg = S.ARGS().get(['--v', '9', '--n_mels', '80', '--n_frame', '512', '--n_chan', '2', '--batch_size', str(dbatch)])
     ds = iter(S.make_device_dataset(dcfg, True, sources=S.synthetic_sources(2, 3, n_bg=16, n_voice=64, n_noise=32, seed=rank),
                                     device=dev, seed=rank))
     t_data = timed(lambda: next(ds), steps)
@@ -163,29 +234,39 @@ def side_measurements(dev, rank, world, steps, fence):
                                                                               seed=rank), device=dev, seed=rank))
     t_wdata = timed(lambda: next(wds), steps)
     del wds
+    c3 = {"audio_s_per_s": round(world * audio_s / t_fwd, 1), "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch,
+          "what": "training-mode model object in eval(): BatchNorm kernels, separate bias / ReLU kernels (the literal module)",
+          "inference_engine": {
+              "what": "same function for inference: BatchNorm folded into the convolutions, conv + bias + ReLU as one MIOpen "
+                      "fusion call (torch.miopen_convolution_relu), fp32; outputs equal to 1e-4 (GPU test)",
+              "eager": {"audio_s_per_s": round(world * audio_s / t_fwd_folded, 1), "ms_per_step": round(1e3 * t_fwd_folded, 3)},
+              "hipgraph_replay": None if t_fwd_graph is None else {
+                  "audio_s_per_s": round(world * audio_s / t_fwd_graph, 1), "ms_per_step": round(1e3 * t_fwd_graph, 3)},
+              "fused_conv_bias_relu": infer.fused_convs}}
+    best_fwd = min(t for t in (t_fwd, t_fwd_folded, t_fwd_graph) if t is not None)
     return {
-        "device_dataset": {"ms_per_batch": round(1e3 * t_data, 3), "batch_per_gpu": batch,
-                           "audio_s_per_s": round(world * batch * 512 * HOP / SR / t_data, 1),
+        "device_dataset": {"ms_per_batch": round(1e3 * t_data, 3), "batch_per_gpu": dbatch,
+                           "audio_s_per_s": round(world * dbatch * 512 * HOP / SR / t_data, 1),
                            "shape": "spectra [257, T_i, 4] resident in HBM -> log-mel [64, 80, 512, 2] + labels"},
-        "wave_dataset": {"ms_per_batch": round(1e3 * t_wdata, 3), "batch_per_gpu": batch,
-                         "audio_s_per_s": round(world * batch * 511 * HOP / SR / t_wdata, 1),
+        "wave_dataset": {"ms_per_batch": round(1e3 * t_wdata, 3), "batch_per_gpu": dbatch,
+                         "audio_s_per_s": round(world * dbatch * 511 * HOP / SR / t_wdata, 1),
                          "shape": "waveforms [2, L_i] resident in HBM -> mixed [64, 2, 130816] -> log-mel [64, 80, 512, 2] + labels"},
-        "c3_frontend_specaug_crnn_fwd": {"audio_s_per_s": round(world * audio_s / t_fwd, 1),
-                                         "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch,
-                                         "bn_folded_for_inference": {"audio_s_per_s": round(world * audio_s / t_fwd_folded, 1),
-                                                                     "ms_per_step": round(1e3 * t_fwd_folded, 3)}},
+        "c3_frontend_specaug_crnn_fwd": c3,
+        "c3_best_fp32_audio_s_per_s": round(world * audio_s / best_fwd, 1),
         "c4_train_step": {"audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3),
                           "batch_per_gpu": batch, "n_gpus": world, "params": sum(p.numel() for p in model.parameters()),
-                          "grad_allreduce": "DDP/RCCL" if world > 1 else "none"},
+                          "grad_allreduce": "DDP/RCCL" if world > 1 else "none", "device_ms_per_phase": breakdown,
+                          "allreduce": comm},
+        "bf16_autocast_opt_in": bf16,
     }
 
 
-def two_stream(dev, wavs, outs, plan_a, fence, n):
+def two_stream(dev, wavs, outs, fence, n):
     """The c2 step issued alternately on two streams, each with its own plan (a plan's workspace belongs to one
     stream, include/iris_frontend.h).  Same rotating batches as the headline; returns whole-job throughput."""
     from challenge_amd.frontend import PipelinedFrontend
     length = wavs[0].shape[-1]
-    pipe = PipelinedFrontend(2, n_fft=N_FFT, hop=HOP, n_mel=N_MEL, sample_rate=SR, channels=1, max_batch=BATCH,
+    pipe = PipelinedFrontend(2, n_fft=N_FFT, hop=HOP, n_mel=N_MEL, sample_rate=SR, channels=1, max_batch=wavs[0].shape[0],
                              max_len=length, device=dev)
 
     def run(k):
@@ -201,11 +282,27 @@ def two_stream(dev, wavs, outs, plan_a, fence, n):
     pipe.synchronize()
     fence()
     dt = (time.perf_counter() - t0) / n
-    return {"us_per_step": round(1e6 * dt, 2), "audio_s_per_s": round(BATCH * SECONDS / dt, 1), "streams": 2, "steps": n}
+    return {"us_per_step": round(1e6 * dt, 2), "audio_s_per_s": round(wavs[0].shape[0] * SECONDS / dt, 1), "streams": 2, "steps": n}
+
+
+def graph_replay(dev, plan, wavs, outs, fence, n):
+    """The c2 step captured once per rotating batch into a hipGraph (FrontendPlan.capture) and replayed: what the
+    host-side launch path costs when it is taken out (same device work, same rotation)."""
+    graphs = [plan.capture(wavs[i], out=outs[i], minmax=True, log=True) for i in range(len(wavs))]
+    for g in graphs:
+        g.replay()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(n):
+        graphs[i % len(graphs)].replay()
+    fence()
+    dt = (time.perf_counter() - t0) / n
+    return {"us_per_step": round(1e6 * dt, 2), "audio_s_per_s": round(wavs[0].shape[0] * SECONDS / dt, 1), "graphs": len(graphs),
+            "steps": n}
 
 
 def kernel_source_sha() -> str:
-    """sha256 over the sources of the step's two kernels and of their launch geometry (the fused kernel, the FFT
+    """sha256 over the sources of the step's kernels and of their launch geometry (the fused kernel, the FFT
     core, the min-max/log kernel, the host code that sizes chunks and grids): ties a committed PMC traffic figure to
     the code it was measured on.  The unrelated kernels of the library (mixing, STFT, spectrum -> mel, the MFMA
     variant) are left out, so that work on them does not invalidate a figure they cannot change."""
@@ -218,37 +315,60 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def committed_traffic(kernel_key: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r2/pmc_traffic.json,
-    written by scripts/pmc_summarise.py).  Refused (None + reason) when the kernel sources changed since."""
-    path = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")
+def committed_traffic():
+    """HBM bytes per launch of the step's kernels from the committed PMC passes (profiles/r3/pmc_traffic.json,
+    written by scripts/pmc_summarise.py).  Refused (None + reason) when the kernel sources changed since.
+    Returns (dominant-kernel bytes, whole-step bytes, note)."""
+    path = os.path.join(ROOT, PMC_JSON)
     try:
         with open(path) as f:
             doc = json.load(f)
-        rec = doc[kernel_key]
-    except (OSError, KeyError, ValueError):
-        return None, "no committed PMC pass for " + kernel_key
+    except (OSError, ValueError):
+        return None, None, "no committed PMC pass (" + PMC_JSON + ")"
     sha = kernel_source_sha()
     if doc.get("kernel_src_sha") != sha:
-        return None, f"PMC pass was taken at kernel sources {doc.get('kernel_src_sha')}, this build is {sha}: refused"
-    return rec["hbm_bytes_per_launch"], (f"profiles/r2/pmc_traffic.json (git {doc.get('git_sha')}, kernel sources {sha}; "
-                                         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950)")
+        return None, None, f"PMC pass was taken at kernel sources {doc.get('kernel_src_sha')}, this build is {sha}: refused"
+    k1 = [v for k, v in doc.items() if k.startswith("k_wav_to_mel") and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
+    k2 = [v for k, v in doc.items() if k.startswith("k_minmax") and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
+    if not k1:
+        return None, None, "no fused-kernel record in " + PMC_JSON
+    step = k1[0]["hbm_bytes_per_launch"] + sum(v["hbm_bytes_per_launch"] for v in k2)
+    return k1[0]["hbm_bytes_per_launch"], step, (
+        f"{PMC_JSON} (git {doc.get('git_sha')}, kernel sources {sha}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+        "passes, FETCH_SIZE x2 on gfx950)")
+
+
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT touching the HIP runtime (a parent that has initialised the GPU holds a
+    KFD handle for the whole run): the *_VISIBLE_DEVICES lists if set, else the KFD topology in sysfs."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(prop) as f:
+                for line in f:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def self_launch(args, argv):
     """--gpus N > 1 without a launcher: start one fresh process per GPU through torch.distributed.run and relay
-    its output.  Runs BEFORE this process touches the GPU (no torch.cuda call, no HIP call): a process that has
-    initialised the GPU must never exec or be replaced, so the ranks are children and we exit with their code."""
+    its output.  This parent never calls into HIP or torch.cuda (devices are counted from the environment / sysfs): a
+    process that has initialised the GPU must never exec or be replaced, so the ranks are children and we exit with
+    their code.  --standalone lets the launcher pick (and hold) a free rendezvous port on 127.0.0.1 itself."""
     share = os.environ.get("IRIS_BENCH_SHARE_GPU") == "1"
-    n_dev = torch.cuda.device_count()  # counts devices without initialising them
+    n_dev = visible_gpu_count()
     if not share and n_dev < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
         sys.exit(2)
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL needs it on this driver)
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -275,23 +395,40 @@ def batch_sweep(dev, fence, steps):
         outs = [torch.empty((b, N_MEL, plan.num_frames(length), 1), device=dev) for _ in range(copies)]
         for i in range(max(3, copies)):
             plan.wav_to_logmel(wavs[i % copies], out=outs[i % copies])
-        plan.timing_enable(1)
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
             plan.wav_to_logmel(wavs[i % copies], out=outs[i % copies])
         fence()
         dt = (time.perf_counter() - t0) / steps
-        n_ev, k_ms = plan.timing_read()
+        plan.timing_enable(1)
+        for i in range(steps + 4):
+            plan.wav_to_logmel(wavs[i % copies], out=outs[i % copies])
+        fence()
+        k = plan.timing_samples(0)
         plan.timing_enable(False)
+        k_ms = float(k.mean()) if len(k) else float("nan")
         algo = ALGO_BYTES_PER_AUDIO_S * b * SECONDS
         rows.append({"batch": b, "distinct_batches": copies, "bytes_touched_per_cycle": copies * per_batch,
-                     "k1_us": round(1e3 * k_ms, 2), "k1_frac_of_8TBs": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "step_us_with_event_pairs": round(1e6 * dt, 2),
+                     "k1_us": round(1e3 * k_ms, 2), "k1_us_median": round(1e3 * float(np.median(k)), 2) if len(k) else None,
+                     "k1_frac_of_8TBs": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "step_us": round(1e6 * dt, 2), "step_frac_of_8TBs": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4),
                      "audio_s_per_s": round(b * SECONDS / dt, 1)})
         del wavs, outs, plan
         torch.cuda.empty_cache()
     return rows
+
+
+def device_identity(dev):
+    """What tells two ranks' devices apart in the JSON line: PCI bus id and uuid where torch exposes them."""
+    p = torch.cuda.get_device_properties(dev)
+    ident = {"name": p.name}
+    for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"):
+        if hasattr(p, k):
+            ident[k] = int(getattr(p, k))
+    if hasattr(p, "uuid"):
+        ident["uuid"] = str(p.uuid)
+    return ident
 
 
 def main():
@@ -301,16 +438,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
-                    help="do not bracket the dominant kernel with HIP events (roofline.achieved = null)")
-    ap.add_argument("--event-every", type=int, default=10,
-                    help="event-time every n-th launch of the dominant kernel (a pair costs ~4 us of stream time: every 4th "
-                         "launch measured 0.6-1.0 us per step, every 10th under 0.1)")
+                    help="skip the kernel-timing pass (roofline.achieved = null)")
+    ap.add_argument("--no-precondition", action="store_true", help="skip the untimed pre-conditioning burst")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (batch sweep, cache-resident replay, c3 forward, c4 training step)")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--only-sweep", action="store_true", help="of the side measurements, run only the K1 batch sweep (A/B runs)")
     ap.add_argument("--resident", action="store_true",
                     help="replay ONE batch every step (Infinity-Cache resident, as round 1 measured) instead of rotating")
+    ap.add_argument("--strong", action="store_true",
+                    help=f"strong scaling: a fixed global batch ({STRONG_GLOBAL_BATCH} c2 clips; {STRONG_GLOBAL_TRAIN_BATCH} for "
+                         "the c4 training step) split over the ranks instead of a fixed batch per GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -329,6 +467,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -336,16 +475,22 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL
+        backend = dist.get_backend()
+    if args.strong and STRONG_GLOBAL_BATCH % world:
+        print(f"bench.py: --strong needs a world size that divides {STRONG_GLOBAL_BATCH}", file=sys.stderr)
+        sys.exit(2)
+    batch = STRONG_GLOBAL_BATCH // world if args.strong else BATCH
 
     from challenge_amd.frontend import FrontendPlan, normalize
 
     length = SECONDS * SR
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    n_rot = 1 if args.resident else ROTATE
+    per_batch = batch * (length * 4 + N_MEL * (1 + length // HOP) * 4)
+    n_rot = 1 if args.resident else max(2, min(ROTATE, -(-(488 << 20) // per_batch)))
     # reference normalisation x / (10 rms), data_utils.py:32-34
-    wavs = [normalize(torch.randn(BATCH, 1, length, generator=gen, device=dev, dtype=torch.float32)) for _ in range(n_rot)]
-    plan = FrontendPlan(N_FFT, HOP, N_MEL, SR, 1, BATCH, length, dev)
-    outs = [torch.empty((BATCH, N_MEL, plan.num_frames(length), 1), device=dev) for _ in range(n_rot)]
+    wavs = [normalize(torch.randn(batch, 1, length, generator=gen, device=dev, dtype=torch.float32)) for _ in range(n_rot)]
+    plan = FrontendPlan(N_FFT, HOP, N_MEL, SR, 1, batch, length, dev)
+    outs = [torch.empty((batch, N_MEL, plan.num_frames(length), 1), device=dev) for _ in range(n_rot)]
     cursor = [0]
 
     def step():
@@ -359,47 +504,68 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if not args.no_precondition:
+        for _ in range(PRECONDITION):
+            step()
     for _ in range(args.warmup):
         step()
-    # every 10th launch of the dominant kernel carries a start/stop event pair (an event pair on every
-    # launch costs ~4 us of stream time per step, which would distort `value`)
-    plan.timing_enable(0 if args.no_kernel_events else args.event_every)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
-    elapsed = time.perf_counter() - t0
-    n_ev, kernel_ms = plan.timing_read()
-    plan.timing_enable(False)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    audio_s_per_step = BATCH * SECONDS
+    # kernel-timing pass: separate from the timed region, independent of --steps
+    k1 = k2 = np.zeros(0, np.float32)
+    if not args.no_kernel_events:
+        plan.timing_enable(1)  # every call; the library never samples the first 4 calls after enabling
+        for _ in range(KERNEL_PASS + 4):
+            step()
+        fence()
+        k1, k2 = plan.timing_samples(0), plan.timing_samples(1)
+        plan.timing_enable(False)
+
+    audio_s_per_step = batch * SECONDS
     value = world * audio_s_per_step * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
     result = {
         "metric": "audio-seconds/sec @16 kHz, STFT+mel frontend only (STFT+|X|+mel+min-max+log; the CRNN forward is NOT "
                   "inside `value`: see stft_mel_fwd_audio_s_per_s)",
         "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "c2: batch 32 x 10 s mono 16 kHz per GPU, n_fft 1024 hop 256 n_mel 64; "
+        "config": {"workload": f"c2: batch {batch} x 10 s mono 16 kHz per GPU, n_fft 1024 hop 256 n_mel 64; "
                                "fused STFT+magnitude+mel+min-max+log (frontend only, no collective); "
                                + (f"steps rotate through {n_rot} distinct batches = "
-                                  f"{n_rot * (BATCH * length * 4 + outs[0].numel() * 4) >> 20} MiB per cycle (> 256 MiB "
+                                  f"{n_rot * per_batch >> 20} MiB per cycle (> 256 MiB "
                                   "Infinity Cache): inputs come from HBM" if n_rot > 1 else
-                                  "ONE batch replayed every step (Infinity-Cache resident)"),
-                   "global_batch": world * BATCH, "parallelism": f"dp{world}"},
+                                  "ONE batch replayed every step (Infinity-Cache resident)")
+                               + ("" if args.no_precondition else
+                                  f"; {PRECONDITION} untimed pre-conditioning steps run before the warm-up (busy-GPU clock / cache state)"),
+                   "global_batch": world * batch, "parallelism": f"dp{world}"},
         "stft_mel_fwd_audio_s_per_s": None,
     }
+    if world > 1:  # self-audit of the N > 1 run: who ran where, and did the collective backend see N ranks
+        mine = {"rank": rank, "local_rank": local_rank, "device": device_identity(dev),
+                "value": round(audio_s_per_step * args.steps / elapsed_local, 1),
+                "ms_per_step": round(1e3 * elapsed_local / args.steps, 5)}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        result["ranks"] = ranks
+        result["rccl_world"] = dist.get_world_size()
+        result["backend"] = backend
     extras = None
     if args.only_sweep and world == 1:
         extras = {"k1_batch_sweep": batch_sweep(dev, fence, max(args.extra_steps, 20))}
     elif not args.no_extras:
-        extras = side_measurements(dev, rank, world, args.extra_steps, fence)
+        extras = side_measurements(dev, rank, world, args.extra_steps, fence, args.strong)
         if world == 1:
             extras["k1_batch_sweep"] = batch_sweep(dev, fence, max(args.extra_steps, 20))
             # BASELINE configs[4]: 22.05 kHz stereo, n_fft 2048, 128 mel - banded fp32 (default) vs fp16 MFMA variant
@@ -410,39 +576,57 @@ def main():
             # two plans on two HIP streams, alternating batches: independent batches overlap (one stream's min-max/log
             # kernel and launch gaps run in the shadow of the other stream's fused kernel).  Throughput only - kernel
             # durations read under overlap include queueing, so the headline and the roofline stay single-stream.
-            extras["two_stream_pipeline"] = two_stream(dev, wavs, outs, plan, fence, max(200, args.steps))
+            extras["two_stream_pipeline"] = two_stream(dev, wavs, outs, fence, max(200, args.steps))
+            # the step as a replayed hipGraph (one graph per rotating batch): the host launch path taken out
+            extras["graph_replay"] = graph_replay(dev, plan, wavs, outs, fence, max(200, args.steps))
             # the round-1 configuration (one batch replayed, Infinity-Cache resident) beside the rotating one
-            plan.timing_enable(1)
             fence()
             t0 = time.perf_counter()
-            for _ in range(50):
+            for _ in range(100):
                 plan.wav_to_logmel(wavs[0], minmax=True, log=True, out=outs[0])
             fence()
-            dt = (time.perf_counter() - t0) / 50
-            n1, k1 = plan.timing_read()
+            dt = (time.perf_counter() - t0) / 100
+            plan.timing_enable(1)
+            for _ in range(54):
+                plan.wav_to_logmel(wavs[0], minmax=True, log=True, out=outs[0])
+            fence()
+            kr = plan.timing_samples(0)
             plan.timing_enable(False)
-            extras["c2_cache_resident_replay"] = {"k1_us": round(1e3 * k1, 2), "step_us_with_event_pairs": round(1e6 * dt, 2)}
+            extras["c2_cache_resident_replay"] = {"k1_us": round(1e3 * float(kr.mean()), 2) if len(kr) else None,
+                                                  "step_us": round(1e6 * dt, 2)}
     if rank == 0:
         if extras:
             result["extra"] = extras
             if "c3_frontend_specaug_crnn_fwd" in extras:
-                result["stft_mel_fwd_audio_s_per_s"] = extras["c3_frontend_specaug_crnn_fwd"]["audio_s_per_s"]
+                result["stft_mel_fwd_audio_s_per_s"] = extras["c3_best_fp32_audio_s_per_s"]
         algo_bytes = ALGO_BYTES_PER_AUDIO_S * audio_s_per_step  # per launch
-        achieved = (algo_bytes / (kernel_ms * 1e-3) / 1e9) if n_ev and kernel_ms > 0 else None
-        kernel_key = "k_wav_to_mel<10,0,false,false,1>"
-        traffic, traffic_note = committed_traffic(kernel_key)
+        traffic, step_traffic, traffic_note = committed_traffic()
         step_gbs = algo_bytes / (elapsed / args.steps) / 1e9
-        result["roofline"] = {
-            "bound": "hbm", "kernel": kernel_key,
-            "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
-            "traffic_source": traffic_note,
+        roof = {
+            "bound": "hbm", "kernel": plan.fused_kernel_name(), "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": None, "traffic": traffic, "step_traffic": step_traffic, "traffic_source": traffic_note,
             "algorithmic_bytes_per_launch": algo_bytes,
-            "kernel_ms": round(kernel_ms, 5) if n_ev else None, "launches_timed": n_ev,
-            # whole step (dominant kernel + min-max/log kernel + the boundary between them) against the same bytes
+            # whole step (every kernel of the step + the boundaries between them) against the same bytes
             "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
-            "event_pair_floor_us": 4.1,  # begin->end of an EMPTY kernel read this way (scripts/microbench/launch_floor.hip)
+            "how": f"kernel-timing pass after the timed region: {KERNEL_PASS} rotating steps with a HIP event pair around each "
+                   "kernel on the launch stream (hipExtLaunchKernel); `achieved` = algorithmic bytes / MEAN duration of the "
+                   "dominant kernel.  Such a pair reads marker-end -> kernel-end, i.e. the dispatch gap in front of the kernel "
+                   "is inside it: 1-2 us above rocprofv3's duration of the same kernel (profiles/r3/), so `frac` errs low",
         }
+        if len(k1):
+            kernel_ms, k2_ms = float(k1.mean()), (float(k2.mean()) if len(k2) else 0.0)
+            roof.update({"kernel_ms": round(kernel_ms, 5), "kernel_ms_median": round(float(np.median(k1)), 5),
+                         "kernel_ms_min": round(float(k1.min()), 5), "launches_timed": int(len(k1)),
+                         "second_kernel": "k_minmax_log_apply" if len(k2) else None,
+                         "second_kernel_ms": round(k2_ms, 5) if len(k2) else None,
+                         "second_kernel_ms_median": round(float(np.median(k2)), 5) if len(k2) else None})
+            if kernel_ms + k2_ms <= ms_per_step * 1.05 + 0.004:  # the event reading carries up to ~2 us of dispatch gap per kernel
+                achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+                roof["achieved"], roof["frac"] = round(achieved, 1), round(achieved / HBM_PEAK_GBS, 4)
+            else:
+                roof["frac_withheld"] = (f"kernel_ms {kernel_ms:.5f} + second_kernel_ms {k2_ms:.5f} exceed ms_per_step "
+                                         f"{ms_per_step:.5f} x 1.05: inconsistent, no fraction reported")
+        result["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wavs[0].cpu().numpy())
         print(json.dumps(result), flush=True)

@@ -44,8 +44,12 @@ SIGNATURES = {
     "iris_mix_specs": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "iris_mix_wave_frame_active": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "iris_mix_waves": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "iris_bias_relu": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "iris_bias_relu_maxpool": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "iris_plan_kernel_name": (_i, [_vp, _i, C.c_char_p, _i]),
     "iris_timing_enable": (_i, [_vp, _i]),
     "iris_timing_read": (_i, [_vp, C.POINTER(_i), _fp]),
+    "iris_timing_samples": (_i, [_vp, _i, _fp, _i, C.POINTER(_i)]),
 }
 
 _lib = None

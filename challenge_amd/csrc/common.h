@@ -95,12 +95,24 @@ struct iris_plan {
     // timing
     int timing;        // 0 off, n: every n-th launch carries an event pair
     long launch_no;    // launches since timing was enabled
-    std::vector<hipEvent_t> ev;  // pairs
+    std::vector<hipEvent_t> ev;  // pairs around the fused kernel
     int ev_used;
+    std::vector<hipEvent_t> ev2;  // pairs around the min-max / log kernel of the same calls
+    int ev2_used;
+    // launch geometry of the fused kernel per (kernel, batch, frames, chunk bitmap): the occupancy query runs once per
+    // shape, never on the hot launch path
+    struct FusedGeom {
+        const void* kernel;
+        int batch, T;
+        int chunk_frames, chunks_per_clip, grid;
+        size_t lds;
+    };
+    std::vector<FusedGeom> geom_cache;
 };
 
 constexpr int kChunk = 4096;        // elements per partial-reduction block
 constexpr int kMaxTimedLaunches = 4096;
+constexpr int kTimingSkip = 4;  // launches after iris_timing_enable that are never sampled (idle-GPU dispatch, clock ramp)
 
 // ---------------------------------------------------------------------------
 // small device helpers

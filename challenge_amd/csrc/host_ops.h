@@ -198,25 +198,46 @@ static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int
     *chunk_frames = (T + cpc - 1) / cpc;
 }
 
-// Geometry + grid for the residency the hardware really grants (registers and LDS): start from
-// the register-limited occupancy and go down until the occupancy query agrees.
-static int fused_config(const iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, bool bands, int* chunk_frames,
+// Geometry + grid of the fused kernel: one workgroup per CU (every wave the registers allow), checked once per
+// (kernel, batch, frames) against the occupancy the hardware really grants and cached in the plan - the hot launch
+// path does no runtime query.
+static int fused_config(iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, bool bands, int* chunk_frames,
                         int* chunks_per_clip, int* grid, size_t* lds) {
-    for (int per_cu = fused_occ(p->log2n); per_cu >= 1; --per_cu) {
-        fused_geometry(p, batch, T, per_cu, chunk_frames, chunks_per_clip);
-        *lds = fused_lds_bytes(p, streams, bands, *chunk_frames);
-        if (*lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
-        int resident = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
-                                                                    64 * fused_waves(p->log2n, streams, bands, p->need_hi != 0), *lds);
-        if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s",
-                                         hipGetErrorString(e));
-        if (resident >= per_cu) {
-            *grid = std::min(batch * *chunks_per_clip, p->num_cu * per_cu);
+    for (const iris_plan::FusedGeom& g : p->geom_cache)
+        if (g.kernel == (const void*)kernel && g.batch == batch && g.T == T) {
+            *chunk_frames = g.chunk_frames;
+            *chunks_per_clip = g.chunks_per_clip;
+            *grid = g.grid;
+            *lds = g.lds;
             return IRIS_OK;
         }
+    fused_geometry(p, batch, T, 1, chunk_frames, chunks_per_clip);
+    *lds = fused_lds_bytes(p, streams, bands, *chunk_frames);
+    if (*lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
+    int resident = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
+                                                                64 * fused_waves(p->log2n, streams, bands, p->need_hi != 0), *lds);
+    if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+    if (resident < 1) return fail(IRIS_E_UNSUPPORTED, "fused kernel does not fit one workgroup per CU (LDS %zu B)", *lds);
+    *grid = std::min(batch * *chunks_per_clip, p->num_cu);
+    if (p->geom_cache.size() >= 64) p->geom_cache.clear();
+    p->geom_cache.push_back({(const void*)kernel, batch, T, *chunk_frames, *chunks_per_clip, *grid, *lds});
+    return IRIS_OK;
+}
+
+// bench hook: launch with the kernel's own start/stop timestamps attached to an event pair by the AMD launch
+// extension (no hipEventRecord packets of our own on the stream)
+static hipError_t launch_timed(std::vector<hipEvent_t>& ev, int& used, const void* kernel, dim3 grid, dim3 block,
+                               void** kargs, size_t lds, hipStream_t s) {
+    while ((int)ev.size() < 2 * (used + 1)) {
+        hipEvent_t e;
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) return rc;
+        ev.push_back(e);
     }
-    return fail(IRIS_E_UNSUPPORTED, "fused kernel does not fit one workgroup per CU (LDS %zu B)", *lds);
+    hipError_t rc = hipExtLaunchKernel(kernel, grid, block, kargs, lds, s, ev[2 * used], ev[2 * used + 1], 0);
+    if (rc == hipSuccess) ++used;
+    return rc;
 }
 
 extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, int batch, int len, int flags,
@@ -286,32 +307,36 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     }
     if (n_partial > p->ws_floats) return fail(IRIS_E_CAPACITY, "iris_wav_to_logmel: workspace too small");
 
-    // bench hook: the kernel's own start/stop timestamps are attached to an event pair by the
-    // AMD launch extension (no extra packets on the stream, unlike hipEventRecord brackets)
-    const bool timed = p->timing > 0 && (p->launch_no++ % p->timing) == 0 && p->ev_used < kMaxTimedLaunches;
+    // bench hook (iris_timing_enable): every n-th call carries event pairs around both kernels; the first
+    // kTimingSkip calls after enabling are never sampled (first dispatch on an idle GPU, clock ramp)
+    const bool timed = p->timing > 0 && p->launch_no >= kTimingSkip && ((p->launch_no - kTimingSkip) % p->timing) == 0 &&
+                       p->ev_used < kMaxTimedLaunches;
+    p->launch_no++;
     hipError_t e;
     if (timed) {
-        while ((int)p->ev.size() < 2 * (p->ev_used + 1)) {
-            hipEvent_t ev;
-            HIP_TRY(hipEventCreate(&ev));
-            p->ev.push_back(ev);
-        }
         FusedArgs args = a;
         void* kargs[] = {&args};
-        e = hipExtLaunchKernel((const void*)kernel, dim3(grid), dim3(64 * waves), kargs, lds, s,
-                               p->ev[2 * p->ev_used], p->ev[2 * p->ev_used + 1], 0);
-        if (e == hipSuccess) p->ev_used++;
+        e = launch_timed(p->ev, p->ev_used, (const void*)kernel, dim3(grid), dim3(64 * waves), kargs, lds, s);
     } else {
         kernel<<<grid, 64 * waves, lds, s>>>(a);
         e = hipGetLastError();
     }
     HIP_TRY(e);
     if (do_minmax || do_log) {
-        const size_t row_len = (size_t)p->n_mel * a.T * p->channels;
+        size_t row_len = (size_t)p->n_mel * a.T * p->channels;
         const unsigned n_chunks = (unsigned)((row_len + kApply - 1) / kApply);
-        k_minmax_log_apply<<<dim3(n_chunks, batch), 256, 0, s>>>(out, p->d_ws, a.chunks_per_clip * parts_per_chunk, row_len, do_minmax,
-                                                               do_log, 1e-8f, 1e-8f);
-        HIP_TRY(hipGetLastError());
+        float* x = out;
+        const float* partial = p->d_ws;
+        int n_part = a.chunks_per_clip * parts_per_chunk, mm = do_minmax, lg = do_log;
+        float eps_div = 1e-8f, eps_log = 1e-8f;
+        if (timed) {
+            void* kargs[] = {&x, &partial, &n_part, &row_len, &mm, &lg, &eps_div, &eps_log};
+            e = launch_timed(p->ev2, p->ev2_used, (const void*)k_minmax_log_apply, dim3(n_chunks, batch), dim3(256), kargs, 0, s);
+        } else {
+            k_minmax_log_apply<<<dim3(n_chunks, batch), 256, 0, s>>>(x, partial, n_part, row_len, mm, lg, eps_div, eps_log);
+            e = hipGetLastError();
+        }
+        HIP_TRY(e);
     }
     return IRIS_OK;
 }
@@ -346,11 +371,60 @@ extern "C" int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float 
     return IRIS_OK;
 }
 
+extern "C" int iris_bias_relu(float* x, const float* bias, size_t n_outer, int channels, void* stream) {
+    if (!x || !bias) return fail(IRIS_E_INVALID, "iris_bias_relu: NULL argument");
+    if (channels <= 0 || (channels & 3)) return fail(IRIS_E_UNSUPPORTED, "iris_bias_relu: channels=%d must be a positive multiple of 4", channels);
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias)) & 15)
+        return fail(IRIS_E_INVALID, "iris_bias_relu: x and bias must be 16-byte aligned");
+    if (n_outer == 0) return IRIS_OK;
+    const size_t n4 = n_outer * (size_t)(channels / 4);
+    k_bias_relu<<<grid_for(n4), 256, 0, (hipStream_t)stream>>>(x, bias, n4, channels / 4);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_bias_relu_maxpool(const float* x, const float* bias, float* y, int batch, int height, int width, int channels,
+                                      void* stream) {
+    if (!x || !bias || !y) return fail(IRIS_E_INVALID, "iris_bias_relu_maxpool: NULL argument");
+    if (channels <= 0 || (channels & 3)) return fail(IRIS_E_UNSUPPORTED, "iris_bias_relu_maxpool: channels=%d must be a positive multiple of 4", channels);
+    if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_bias_relu_maxpool: empty tensor");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(y)) & 15)
+        return fail(IRIS_E_INVALID, "iris_bias_relu_maxpool: x, bias and y must be 16-byte aligned");
+    const size_t n4 = (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
+    k_bias_relu_pool<<<grid_for(n4), 256, 0, (hipStream_t)stream>>>(x, bias, y, batch, height, width, channels / 4);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_plan_kernel_name(const iris_plan* p, int with_bands, char* out, int capacity) {
+    if (!p || !out || capacity <= 0) return fail(IRIS_E_INVALID, "iris_plan_kernel_name: bad argument");
+    if (p->mel_only) return fail(IRIS_E_UNSUPPORTED, "iris_plan_kernel_name: mel-only plan");
+    if (p->mel_precision == 1 && !with_bands)
+        snprintf(out, (size_t)capacity, "k_wav_to_mel_mfma<%d>", p->log2n);
+    else
+        snprintf(out, (size_t)capacity, "k_wav_to_mel<%d,%d,%s,%s,1>", p->log2n, p->mel_mode,
+                 (p->need_hi && p->mel_mode != 0 && p->mel_mode != 3) ? "true" : "false", with_bands ? "true" : "false");
+    return IRIS_OK;
+}
+
 extern "C" int iris_timing_enable(iris_plan* p, int enable) {
     if (!p) return fail(IRIS_E_INVALID, "iris_timing_enable: NULL plan");
     p->timing = enable > 0 ? enable : 0;
     p->launch_no = 0;
     p->ev_used = 0;
+    p->ev2_used = 0;
+    return IRIS_OK;
+}
+
+static int read_events(const std::vector<hipEvent_t>& ev, int used, float* out_ms, int capacity, double* total) {
+    *total = 0.0;
+    for (int i = 0; i < used; ++i) {
+        HIP_TRY(hipEventSynchronize(ev[2 * i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        *total += ms;
+        if (out_ms && i < capacity) out_ms[i] = ms;
+    }
     return IRIS_OK;
 }
 
@@ -358,14 +432,23 @@ extern "C" int iris_timing_read(iris_plan* p, int* n_launches, float* mean_ms) {
     if (!p || !n_launches || !mean_ms) return fail(IRIS_E_INVALID, "iris_timing_read: NULL argument");
     DeviceGuard guard(p->device);
     double total = 0.0;
-    for (int i = 0; i < p->ev_used; ++i) {
-        HIP_TRY(hipEventSynchronize(p->ev[2 * i + 1]));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]));
-        total += ms;
-    }
+    int rc = read_events(p->ev, p->ev_used, nullptr, 0, &total);
+    if (rc) return rc;
     *n_launches = p->ev_used;
     *mean_ms = p->ev_used ? (float)(total / p->ev_used) : 0.f;
     p->ev_used = 0;
+    p->ev2_used = 0;
+    return IRIS_OK;
+}
+
+extern "C" int iris_timing_samples(iris_plan* p, int kernel, float* out_ms, int capacity, int* n_samples) {
+    if (!p || !n_samples || (capacity > 0 && !out_ms)) return fail(IRIS_E_INVALID, "iris_timing_samples: NULL argument");
+    if (kernel != 0 && kernel != 1) return fail(IRIS_E_INVALID, "iris_timing_samples: kernel must be 0 or 1");
+    DeviceGuard guard(p->device);
+    double total = 0.0;
+    const int used = kernel == 0 ? p->ev_used : p->ev2_used;
+    int rc = read_events(kernel == 0 ? p->ev : p->ev2, used, out_ms, capacity, &total);
+    if (rc) return rc;
+    *n_samples = used;
     return IRIS_OK;
 }

@@ -143,8 +143,14 @@ static int upload(T** dst, const std::vector<T>& src) {
     return IRIS_OK;
 }
 
+// two frames in flight per wave (IRIS_STREAMS=2) was measured slower twice: it exists in diagnostic builds only
 static int plan_streams(const iris_plan* p) {
+#if IRIS_DIAG
     return (p->streams == 2 && (p->log2n == 9 || p->log2n == 10)) ? 2 : 1;
+#else
+    (void)p;
+    return 1;
+#endif
 }
 
 // LDS of the fused kernel: landing + exchange buffers of every wave (the constant block is
@@ -183,9 +189,12 @@ static fused_kernel_t fused_kernel_mm(int mel_mode, bool hi, bool bands) {
 // two frame streams per wave exist for n_fft 512 / 1024
 template <int LOG2N>
 static fused_kernel_t fused_kernel_m(int mel_mode, bool hi, bool bands, int streams) {
+#if IRIS_DIAG
     if constexpr (LOG2N == 9 || LOG2N == 10) {
         if (streams == 2) return fused_kernel_mm<LOG2N, 2>(mel_mode, hi, bands);
     }
+#endif
+    (void)streams;
     return fused_kernel_mm<LOG2N, 1>(mel_mode, hi, bands);
 }
 static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands, int streams) {
@@ -223,7 +232,7 @@ static const void* stft_kernel(int log2n) {
 static hipError_t allow_big_lds(const iris_plan* p) {
     constexpr int kMaxLds = 160 * 1024;
     hipError_t e;
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < (IRIS_DIAG ? 4 : 2); ++v) {
         const int streams = (v & 2) ? 2 : 1;
         if (streams == 2 && p->log2n != 9 && p->log2n != 10) continue;
         e = hipFuncSetAttribute((const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, (v & 1) != 0, streams),
@@ -291,11 +300,14 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->d_dbg = nullptr;
     p->ablate = 0;
     p->streams = 1;
+#if IRIS_DIAG
     if (const char* e = getenv("IRIS_STREAMS")) p->streams = atoi(e) == 2 ? 2 : 1;
+#endif
     p->magmel_generic = getenv("IRIS_MAGMEL_GENERIC") != nullptr;  // test hook: read once, never per launch
     p->timing = 0;
     p->launch_no = 0;
     p->ev_used = 0;
+    p->ev2_used = 0;
 
     p->mel.resize((size_t)n_bins * n_mel);
     if (mel_host) {
@@ -587,6 +599,7 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
     (void)hipFree(p->d_dbg);
 #endif
     for (hipEvent_t ev : p->ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : p->ev2) (void)hipEventDestroy(ev);
     (void)hipFree(p->d_consts);
     (void)hipFree(p->d_band_lo);
     (void)hipFree(p->d_band_len);

@@ -212,3 +212,57 @@ __global__ __launch_bounds__(256) void k_agc_clip(const iris_agc_row* rows, size
         }
     }
 }
+
+// ---------------------------------------------------------------------------
+// inference epilogue of a folded Conv2D + BatchNorm + ReLU (sj_train.py:191-201): y = max(x + bias[c], 0) in place on a
+// channels-last tensor [n_outer, C]; POOL: the 2x2 / stride-2 'same' max-pool of the block fused behind it
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bias_relu(float* x, const float* bias, size_t n_vec4, int C4) {
+    const float4* b4 = reinterpret_cast<const float4*>(bias);
+    float4* x4 = reinterpret_cast<float4*>(x);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = x4[i];
+        const float4 b = b4[i % C4];
+        v.x = fmaxf(v.x + b.x, 0.f);
+        v.y = fmaxf(v.y + b.y, 0.f);
+        v.z = fmaxf(v.z + b.z, 0.f);
+        v.w = fmaxf(v.w + b.w, 0.f);
+        x4[i] = v;
+    }
+}
+
+// x [B, H, W, C] -> y [B, ceil(H/2), ceil(W/2), C]: y = maxpool2x2(relu(x + bias)) = relu(max over the window of x + bias)
+__global__ __launch_bounds__(256) void k_bias_relu_pool(const float* x, const float* bias, float* y, int B, int H, int W, int C4) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    const float4* b4 = reinterpret_cast<const float4*>(bias);
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int wo = (int)(r % Wo);
+        r /= Wo;
+        const int ho = (int)(r % Ho), b = (int)(r / Ho);
+        const int h0 = 2 * ho, w0 = 2 * wo;
+        const bool h1 = h0 + 1 < H, w1 = w0 + 1 < W;
+        const size_t base = (((size_t)b * H + h0) * W + w0) * C4 + c;
+        float4 m = x4[base];
+        auto take = [&](size_t off) {
+            const float4 v = x4[base + off];
+            m.x = fmaxf(m.x, v.x);
+            m.y = fmaxf(m.y, v.y);
+            m.z = fmaxf(m.z, v.z);
+            m.w = fmaxf(m.w, v.w);
+        };
+        if (w1) take(C4);
+        if (h1) take((size_t)W * C4);
+        if (h1 && w1) take((size_t)W * C4 + C4);
+        const float4 bb = b4[c];
+        m.x = fmaxf(m.x + bb.x, 0.f);
+        m.y = fmaxf(m.y + bb.y, 0.f);
+        m.z = fmaxf(m.z + bb.z, 0.f);
+        m.w = fmaxf(m.w + bb.w, 0.f);
+        y4[i] = m;
+    }
+}

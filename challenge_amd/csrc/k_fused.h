@@ -30,7 +30,6 @@
 // ---------------------------------------------------------------------------
 // One workgroup per CU holding every wave of the CU: all waves are of one age class for the issue
 // arbiter (which favours older waves) and share one frame queue.
-constexpr int fused_occ(int log2n) { return 1; }
 // waves per workgroup: 4 per SIMD at n_fft <= 1024 (<= 128 VGPRs: a twiddle takes one register pair, see
 // cmul_tw) - except the n_fft 1024 variants with bands, which need 134 and stay at 3 per SIMD rather than
 // spill (a kernel with scratch pays ~5 us more per dispatch); 2 when a wave keeps two frames in flight or at

@@ -168,20 +168,29 @@ def label_downsample(resolution: int = 32, ref_batch_slice: bool = False):
     return _label_downsample
 
 
+def random_merge_aug_apply(x, number: int, factor):
+    """Deterministic half of random_merge_aug (data_utils.py:106-115): `factor` [1, 1, number - 2] is the
+    U(0.1, 0.9) draw.  Works on any device (torch slicing / arithmetic on the tensor's own device)."""
+    chan = x.shape[-1] // 2
+    if chan != 2:
+        raise ValueError("This augment can be used in 2 channel audio")
+    real, imag = x[..., :chan], x[..., chan:]
+    k = number - chan
+    factor = torch.as_tensor(factor, dtype=x.dtype, device=x.device)
+    aug_real = factor * real[..., :1].repeat_interleave(k, -1) \
+        + torch.sqrt(1 - factor) * real[..., 1:].repeat_interleave(k, -1)
+    real = torch.cat([real, aug_real], -1)
+    imag = torch.cat([imag, (imag[..., :1] + imag[..., 1:]).repeat_interleave(k, -1)], -1)
+    return torch.cat([real, imag], -1)
+
+
 def random_merge_aug(number: int):
-    """Extra mixed channels from a 2-channel spectrogram (data_utils.py:100-117)."""
+    """Extra mixed channels from a 2-channel spectrogram (data_utils.py:100-117): draw + apply."""
     def _random_merge_aug(x, y=None):
-        chan = x.shape[-1] // 2
-        if chan != 2:
+        if x.shape[-1] // 2 != 2:
             raise ValueError("This augment can be used in 2 channel audio")
-        real, imag = x[..., :chan], x[..., chan:]
-        k = number - chan
-        factor = torch.as_tensor(_tr.get_rng().uniform(0.1, 0.9, size=(1, 1, k)), dtype=x.dtype, device=x.device)
-        aug_real = factor * real[..., :1].repeat_interleave(k, -1) \
-            + torch.sqrt(1 - factor) * real[..., 1:].repeat_interleave(k, -1)
-        real = torch.cat([real, aug_real], -1)
-        imag = torch.cat([imag, (imag[..., :1] + imag[..., 1:]).repeat_interleave(k, -1)], -1)
-        out = torch.cat([real, imag], -1)
+        factor = _tr.get_rng().uniform(0.1, 0.9, size=(1, 1, number - 2))
+        out = random_merge_aug_apply(x, number, factor)
         if y is not None:
             return out, y
         return out

@@ -213,7 +213,20 @@ class FrontendPlan:
         N.check(rc, "iris_wav_to_logmel")
         return out
 
+    # ---- hipGraph ------------------------------------------------------------
+    def capture(self, wav: torch.Tensor, out: Optional[torch.Tensor] = None, **kwargs) -> "CapturedStep":
+        """Capture `wav_to_logmel(wav, out=out, **kwargs)` into a hipGraph (torch.cuda.CUDAGraph) once and return an
+        object whose `.replay()` re-runs it on the current stream with no per-launch host work; `.out` is the output
+        tensor.  The entry points never allocate or synchronise and keep no per-call host state, so a replay is
+        the same device work.  `wav`, `out` and any bands tensors are captured BY ADDRESS: refill them in place."""
+        return CapturedStep(self, wav, out, kwargs)
+
     # ---- bench hooks ---------------------------------------------------------
+    def fused_kernel_name(self, with_bands: bool = False) -> str:
+        buf = C.create_string_buffer(128)
+        N.check(N.lib().iris_plan_kernel_name(self._handle, 1 if with_bands else 0, buf, 128), "iris_plan_kernel_name")
+        return buf.value.decode()
+
     def timing_enable(self, enable=True) -> None:
         """True / 1: every launch of the main kernel carries an event pair; n > 1: every n-th; False / 0: off."""
         N.check(N.lib().iris_timing_enable(self._handle, int(enable)), "iris_timing_enable")
@@ -223,10 +236,71 @@ class FrontendPlan:
         N.check(N.lib().iris_timing_read(self._handle, C.byref(n), C.byref(ms)), "iris_timing_read")
         return n.value, ms.value
 
+    def timing_samples(self, kernel: int = 0) -> np.ndarray:
+        """Durations (ms) of the sampled launches of kernel 0 (fused) / 1 (min-max + log) since timing_enable."""
+        cap = 4096
+        buf = np.zeros(cap, np.float32)
+        n = C.c_int(0)
+        N.check(N.lib().iris_timing_samples(self._handle, int(kernel), buf.ctypes.data_as(C.POINTER(C.c_float)), cap,
+                                            C.byref(n)), "iris_timing_samples")
+        return buf[:min(n.value, cap)].copy()
+
+
+class CapturedStep:
+    """One fused frontend call as a replayable hipGraph (see FrontendPlan.capture)."""
+
+    def __init__(self, plan: FrontendPlan, wav: torch.Tensor, out: Optional[torch.Tensor], kwargs: dict):
+        self.plan, self.wav = plan, wav
+        dev = plan.device
+        # bands must be device tensors that outlive the graph (they are read at replay time)
+        for k in ("t_bands", "f_bands"):
+            if kwargs.get(k) is not None:
+                kwargs[k] = torch.as_tensor(kwargs[k]).to(device=dev, dtype=torch.int32).contiguous()
+        self.kwargs = kwargs
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up outside the capture: geometry cache, lazy module load
+            self.out = plan.wav_to_logmel(wav, out=out, **kwargs)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            plan.wav_to_logmel(wav, out=self.out, **kwargs)
+
+    def replay(self) -> torch.Tensor:
+        self.graph.replay()
+        return self.out
+
 
 # ---------------------------------------------------------------------------
 # plan-free ops (run on the tensor's device / current stream)
 # ---------------------------------------------------------------------------
+def bias_relu_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """In place max(x + bias[c], 0) on a channels-last activation: x is [B, C, H, W] with channels_last strides (or any
+    dense tensor whose innermost axis is the channel axis).  One HIP launch (iris_bias_relu)."""
+    x = _require_device_f32(x, "x") if x.is_contiguous(memory_format=torch.channels_last) or x.is_contiguous() else None
+    if x is None:
+        raise ValueError("bias_relu_: x must be dense (channels_last 4-D or contiguous with channels innermost)")
+    c = int(bias.shape[0])
+    with torch.cuda.device(x.device):
+        rc = N.lib().iris_bias_relu(x.data_ptr(), bias.data_ptr(), x.numel() // c, c, _stream_ptr(x.device))
+    N.check(rc, "iris_bias_relu")
+    return x
+
+
+def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """maxpool2x2('same')(relu(x + bias)) for a channels_last [B, C, H, W] activation in ONE pass (iris_bias_relu_maxpool):
+    reads x once, writes a quarter of it.  Returns a channels_last [B, C, ceil(H/2), ceil(W/2)] tensor."""
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or not x.is_cuda or x.dtype != torch.float32:
+        raise ValueError("bias_relu_maxpool: x must be a float32 channels_last [B, C, H, W] device tensor")
+    b, c, h, w = (int(v) for v in x.shape)
+    y = torch.empty((b, c, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device,
+                    memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = N.lib().iris_bias_relu_maxpool(x.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w, c, _stream_ptr(x.device))
+    N.check(rc, "iris_bias_relu_maxpool")
+    return y
+
+
 class PipelinedFrontend:
     """Independent batches through the fused path on `n_streams` HIP streams, one `FrontendPlan` each (a plan's
     workspace belongs to one stream, include/iris_frontend.h): one stream's min-max/log kernel and launch gaps run in

@@ -601,9 +601,11 @@ class CustomModel(nn.Module):
     def _call(self, x):
         return self._ddp(x) if self._ddp is not None else self(x)
 
-    def train_step(self, data):
+    def train_step(self, data, _mark=None):
         """Forward, loss, backward, AGC on the (all-reduced) gradients, element-wise
-        clipvalue, optimiser step (sj_train.py:162-188).  Returns {'loss': tensor}."""
+        clipvalue, optimiser step (sj_train.py:162-188).  Returns {'loss': tensor}.
+        `_mark(name)` (bench hook) is called after each phase: 'forward', 'backward', 'agc_clip', 'optimizer'."""
+        mark = _mark or (lambda name: None)
         x, y = data
         self.train()
         fused = self.use_agc and x.is_cuda  # one HIP launch for AGC + clipvalue over the whole model
@@ -612,7 +614,9 @@ class CustomModel(nn.Module):
         self.optimizer.zero_grad(set_to_none=not fused)
         y_pred = self._call(x)
         loss = self.loss_fn(y, y_pred)
+        mark('forward')
         loss.backward()  # under DDP the bucketed RCCL all-reduce overlaps with this
+        mark('backward')
         if fused:
             if self._fused_agc is None:
                 object.__setattr__(self, '_fused_agc', FusedAGC(list(self.parameters())))
@@ -625,7 +629,9 @@ class CustomModel(nn.Module):
                     p.grad = g
             if self.clipvalue:
                 torch.nn.utils.clip_grad_value_(params, self.clipvalue)
+        mark('agc_clip')
         self.optimizer.step()
+        mark('optimizer')
         return {'loss': loss.detach()}
 
     @torch.no_grad()
@@ -671,6 +677,114 @@ def fold_batchnorm(model: nn.Module) -> nn.Module:
             mod.fc.bias.copy_(mod.fc.bias * s + t)
             mod.bn = None
     return m
+
+
+class _ConvBiasReLU(nn.Module):
+    """Inference form of a folded _ConvBNReLU: the convolution without bias on MIOpen, then ONE HIP pass for
+    bias + ReLU (iris_bias_relu) - or, for the last convolution of a block, bias + ReLU + the block's 2x2 max-pool
+    (iris_bias_relu_maxpool) - instead of separate add / clamp / pooling kernels over the activation."""
+
+    def __init__(self, conv: nn.Conv2d, pool: bool):
+        super().__init__()
+        self.weight = nn.Parameter(conv.weight.detach().clone(memory_format=torch.channels_last), requires_grad=False)
+        self.bias = nn.Parameter(conv.bias.detach().clone(), requires_grad=False)
+        self.padding, self.pool = conv.padding, pool
+
+    def forward(self, x):
+        y = torch.nn.functional.conv2d(x, self.weight, None, padding=self.padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        return _fe.bias_relu_maxpool(y, self.bias) if self.pool else _fe.bias_relu_(y, self.bias)
+
+
+class InferenceEngine:
+    """Inference-only execution of a CustomModel (the c3 path: HIP frontend + SpecAugment + CRNN forward):
+      * eval-mode BatchNorm folded into the layer in front of it (`fold_batchnorm`);
+      * every Conv2D + bias + ReLU (+ MaxPool) of the conv stack as MIOpen convolution + one HIP epilogue pass;
+      * frontend + forward captured into ONE hipGraph (`replay`), when a frontend and an example batch are given.
+    Same function as `model.eval()(x)` up to fp32 rounding (GPU test: <= 1e-4 on the sigmoid outputs).  The model
+    stays on PyTorch-ROCm (MIOpen / hipBLASLt); only the elementwise epilogues are this repository's kernels."""
+
+    def __init__(self, model: "CustomModel", frontend: Optional["WaveFrontend"] = None,
+                 example_wav: Optional[torch.Tensor] = None, fuse_epilogues: bool = True):
+        self.model = fold_batchnorm(model)
+        self.fused_convs = 0
+        dev = next(self.model.parameters()).device
+        if fuse_epilogues and dev.type == 'cuda':
+            for blk in self.model.features:
+                if not isinstance(blk, ConvMPBlock):
+                    continue
+                convs = list(blk.convs)
+                has_pool = isinstance(blk.pool, nn.MaxPool2d)
+                ok = all(len(m) == 3 and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.Identity) and
+                         m[0].out_channels % 4 == 0 for m in convs)
+                if not ok:
+                    continue
+                blk.convs = nn.Sequential(*[_ConvBiasReLU(m[0], has_pool and i == len(convs) - 1)
+                                            for i, m in enumerate(convs)])
+                if has_pool:
+                    blk.pool = nn.Identity()
+                self.fused_convs += len(convs)
+        self.frontend, self.graph, self.graph_ok, self.graph_error = frontend, None, False, None
+        if frontend is not None and example_wav is not None and dev.type == 'cuda':
+            self.wav = example_wav
+            try:
+                self._capture()
+                self.graph_ok = True
+            except Exception as exc:  # capture is an optimisation: the eager path stays available
+                self.graph_error = repr(exc)[:300]
+                self.graph = None
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        return self.model(x)
+
+    @torch.no_grad()
+    def eager(self, wav: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.model(self.frontend(self.wav if wav is None else wav))
+
+    def _draw(self):
+        fe = self.frontend
+        b, n_time = self.wav.shape[0], fe.plan.num_frames(self.wav.shape[2])
+        tb, fb = fe.draw_bands_device(b, n_time)
+        if fe.filter_bins:
+            flt = torch.tensor([[[1, fe.filter_bins]]], dtype=torch.int32, device=fe.plan.device).expand(b, 1, 2)
+            fb = torch.cat([fb, flt], dim=1)
+        return tb.contiguous(), fb.contiguous()
+
+    @torch.no_grad()
+    def _capture(self):
+        fe, dev = self.frontend, self.frontend.plan.device
+        self._tb = self._fb = None
+        if fe.training:
+            self._tb, self._fb = self._draw()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up: MIOpen find, geometry caches, allocator
+            for _ in range(3):
+                feats = fe.plan.wav_to_logmel(self.wav, minmax=fe.do_minmax, log=True, t_bands=self._tb, f_bands=self._fb)
+                self.model(feats)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            feats = fe.plan.wav_to_logmel(self.wav, minmax=fe.do_minmax, log=True, t_bands=self._tb, f_bands=self._fb)
+            self.out = self.model(feats)
+
+    @torch.no_grad()
+    def replay(self, wav: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Frontend (fresh SpecAugment bands, drawn on the device) + forward as one graph replay.  `wav` is copied into
+        the captured input buffer; None re-uses its current contents."""
+        if self.graph is None:
+            return self.eager(wav)
+        if wav is not None and wav.data_ptr() != self.wav.data_ptr():
+            self.wav.copy_(wav)
+        if self._tb is not None:
+            tb, fb = self._draw()
+            self._tb.copy_(tb)
+            self._fb.copy_(fb)
+        self.graph.replay()
+        return self.out
 
 
 def define_keras_model(config=None):

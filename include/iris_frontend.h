@@ -107,6 +107,9 @@ int iris_plan_destroy(iris_plan* plan);
 #define IRIS_MEL_F16_MFMA 1
 int iris_plan_set_mel_precision(iris_plan* plan, int precision);
 
+/* Name of the fused kernel iris_wav_to_logmel launches for this plan (with / without SpecAugment bands), as rocprofv3
+ * prints it without the argument list, e.g. "k_wav_to_mel<10,0,false,false,1>"; HOST buffer. */
+int iris_plan_kernel_name(const iris_plan* plan, int with_bands, char* out_host, int capacity);
 /* Copy the plan's mel matrix [n_bins*n_mel] to HOST memory. */
 int iris_plan_get_mel(const iris_plan* plan, float* out_host);
 /* Frames for a clip of `len` samples: 1 + len / hop. */
@@ -211,6 +214,19 @@ int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float clip_factor
                   float clipvalue, void* stream);
 
 /*
+ * Inference epilogue of ConvMPBlock's Conv2D + BatchNormalization + ReLU (+ MaxPool2D 2x2 'same'), sj_train.py:191-201,
+ * once the eval-mode BatchNorm is folded into the convolution (sj_train.fold_batchnorm): the convolution itself stays
+ * MIOpen (PyTorch-ROCm, per north_star); these replace the separate bias-add, ReLU and pooling passes over its output.
+ *   iris_bias_relu:          x[o, c] = max(x[o, c] + bias[c], 0) in place on a channels-last tensor [n_outer, channels]
+ *   iris_bias_relu_maxpool:  y[b, i, j, c] = max over the 2x2 window (stride 2, clipped at the edges = Keras 'same' /
+ *                            ceil mode) of max(x[b, 2i+di, 2j+dj, c] + bias[c], 0);  x [B, H, W, C] -> y [B, ceil(H/2), ceil(W/2), C]
+ * channels must be a multiple of 4; x, y, bias DEVICE, 16-byte aligned.  Run on the current HIP device.
+ */
+int iris_bias_relu(float* x, const float* bias, size_t n_outer, int channels, void* stream);
+int iris_bias_relu_maxpool(const float* x, const float* bias, float* y, int batch, int height, int width, int channels,
+                           void* stream);
+
+/*
  * Sample synthesis in the complex-STFT domain, deterministic half of
  * merge_complex_specs (pipeline.py:6-110) for a whole batch: every output sample
  * is   background crop (tiled along time, pipeline.py:29-35)
@@ -278,16 +294,20 @@ int iris_mix_waves(const iris_mix_src* srcs_dev, int n_srcs, const int32_t* firs
                    float* workspace, size_t workspace_floats, void* stream);
 
 /*
- * Per-kernel timing for bench.py: with enable = n > 0 every n-th launch of the
- * dominant kernel of iris_wav_to_logmel carries a start/stop hipEvent pair on
- * the launch stream (n = 1: every launch; an event pair costs a few
- * microseconds of stream time, so sampling keeps the step rate honest);
- * 0 switches it off.  iris_timing_read synchronises those events and returns
- * the number of launches recorded since the last reset and their mean
- * duration in ms.
+ * Per-kernel timing for bench.py: with enable = n > 0 every n-th call of
+ * iris_wav_to_logmel carries a start/stop hipEvent pair around each of its
+ * kernels on the launch stream (n = 1: every call; an event pair costs a few
+ * microseconds of stream time, so time throughput with timing off and the
+ * kernels in a separate pass); 0 switches it off.  The first 4 calls after
+ * enabling are never sampled (first dispatch on an idle GPU, clock ramp).
+ * iris_timing_samples synchronises the events and copies the durations (ms) of
+ * kernel 0 (the fused kernel) or 1 (the min-max / log kernel, when the call
+ * ran it) recorded since the last enable / read to HOST memory; it does not
+ * reset.  iris_timing_read returns count and mean of kernel 0 and resets both.
  */
 int iris_timing_enable(iris_plan* plan, int enable);
 int iris_timing_read(iris_plan* plan, int* n_launches, float* mean_ms);
+int iris_timing_samples(iris_plan* plan, int kernel, float* out_ms_host, int capacity, int* n_samples);
 
 #ifdef __cplusplus
 }

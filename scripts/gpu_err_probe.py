@@ -27,3 +27,22 @@ for n_fft, hop, m, c, b, length, sr in [(1024, 256, 64, 1, 40, 25600, 16000), (5
     hip = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), minmax=False, log=False).cpu().numpy()
     print(f"n_fft {n_fft} M {m} C {c}: HIP vs fp64 {rel_err(hip, ref64):.2e} | numpy fp32 vs fp64 {rel_err(ref32, ref64):.2e} | "
           f"torch.stft fp32 vs fp64 {rel_err(t32, ref64):.2e} | HIP vs numpy fp32 {rel_err(hip, ref32):.2e} | mel range [{ref64.min():.3g}, {ref64.max():.3g}]")
+
+
+# the two inputs of tests/test_frontend_gpu.py::test_workgroups_looping_over_several_chunks (same generator sequence)
+rng = np.random.default_rng(77)
+for n_fft, hop, m, c, b, length in [(1024, 256, 64, 1, 40, 25600), (512, 256, 80, 2, 24, 20000)]:
+    wav = (rng.standard_normal((b, c, length)) * 0.1).astype(np.float32)
+    n_t, n_f = 1 + length // hop, n_fft // 2 + 1
+    tb = np.stack([np.stack(R.mask_draw(rng, n_t, 12, 3), 1) for _ in range(b)])
+    fb = np.stack([np.stack(R.mask_draw(rng, n_f, 24, 2), 1) for _ in range(b)])
+    plan = FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
+    w = torch.from_numpy(R.linear_to_mel_weight_matrix(m, n_f, 16000))
+    t32 = wav_to_logmel_cpu(torch.from_numpy(wav), w, n_fft, hop, False, False).numpy()
+    for name, kw in (("no bands", {}), ("t", {"t_bands": tb}), ("t+f", {"t_bands": tb, "f_bands": fb}), ("f", {"f_bands": fb})):
+        ref64 = R.wav_to_mel(wav, n_fft, hop, m, 16000, dtype=np.float64, **kw)
+        ref32 = R.wav_to_mel(wav, n_fft, hop, m, 16000, **kw)
+        hip = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), minmax=False, log=False, **kw).cpu().numpy()
+        extra = f" | torch.stft fp32 vs fp64 {rel_err(t32, ref64):.2e}" if not kw else ""
+        print(f"test input n_fft {n_fft} M {m} C {c} [{name}]: HIP vs fp64 {rel_err(hip, ref64):.2e} | numpy fp32 vs fp64 "
+              f"{rel_err(ref32, ref64):.2e}{extra}")

@@ -1,5 +1,7 @@
-"""c3 forward (frontend + SpecAugment + CRNN v9, batch 64) under rocprofv3 --kernel-trace --stats:
-which kernels the 6 ms are made of.   usage: rocprofv3 --kernel-trace --stats ... -- python3 scripts/gpu_fwdprof.py [n]"""
+"""c3 forward (frontend + SpecAugment + CRNN v9, batch 64) under rocprofv3 --kernel-trace --stats: which kernels the
+step is made of.   usage: rocprofv3 --kernel-trace --stats ... -- python3 scripts/gpu_fwdprof.py [n] [module|engine|graph]
+Run it once WITHOUT the profiler first: MIOpen's find step (NORMAL mode benchmarks every applicable solver once per
+shape and stores the winner in the user find-db) otherwise lands in the kernel statistics."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,12 +15,25 @@ model = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last).eval()
 fe = S.WaveFrontend(1024, 256, 64, 16000, 1, batch, length, dev, training=True, device_draw=True, seed=99)
 wav = torch.randn(batch, 1, length, device=dev) * 0.1
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-with torch.no_grad():
-    for _ in range(3):
-        model(fe(wav))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        model(fe(wav))
-    torch.cuda.synchronize()
-print(f"fwd {1e3 * (time.perf_counter() - t0) / n:.3f} ms per batch of {batch}")
+mode = sys.argv[2] if len(sys.argv) > 2 else "module"
+if mode == "module":
+    def step():
+        with torch.no_grad():
+            model(fe(wav))
+else:
+    eng = S.InferenceEngine(model, fe, wav if mode == "graph" else None)
+    if mode == "graph":
+        assert eng.graph_ok, eng.graph_error
+        step = eng.replay
+    else:
+        eng.frontend, eng.wav = fe, wav
+        step = eng.eager
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+print(f"fwd[{mode}] {1e3 * dt:.3f} ms per batch of {batch} = {batch * length / 16000 / dt:.0f} audio-s/s")

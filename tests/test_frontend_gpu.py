@@ -382,15 +382,17 @@ def test_workgroups_looping_over_several_chunks(dev, monkeypatch):
         from oracle.torch_cpu_ref import wav_to_logmel_cpu
         w32 = torch.from_numpy(R.linear_to_mel_weight_matrix(m, n_f, 16000))
         engine = wav_to_logmel_cpu(torch.from_numpy(wav), w32, n_fft, hop, False, False).numpy()
-        engine_err = rel_err(engine, R.wav_to_mel(wav, n_fft, hop, m, 16000, dtype=np.float64))
+        # the reference's own fp32 engine on this input (informational; bounded so that it cannot drift silently)
+        assert rel_err(engine, R.wav_to_mel(wav, n_fft, hop, m, 16000, dtype=np.float64)) <= 5e-5
         for kw in ({}, {"t_bands": tb}, {"t_bands": tb, "f_bands": fb}, {"f_bands": fb}):
             raw = small.wav_to_logmel(x, minmax=False, log=False, **kw)
             assert torch.equal(raw, ref_plan.wav_to_logmel(x, minmax=False, log=False, **kw))
-            # Against the fp64 oracle, at north_star's 1e-5 - or, where the reference's own fp32 engine (torch.stft +
-            # fp32 matmul, oracle/torch_cpu_ref.py) misses 1e-5 on this very input (narrow low bands ~1000x below
-            # the spectrum's peak: an fp32 FFT's error scales with the peak), at the error that engine makes.
+            # Against the fp64 oracle at ONE stated constant per shape: north_star's 1e-5 at n_fft 1024; 2e-5 at the
+            # n_fft 512 / 80 mel / stereo shape, whose narrow low bands sit ~1000x below the spectral peak, where an fp32
+            # transform's absolute noise floor (eps x rms of the spectrum) shows in the 1e-3-floored relative error:
+            # measured HIP values in profiles/r3/hip_vs_fp64.log.
             ref64 = R.wav_to_mel(wav, n_fft, hop, m, 16000, dtype=np.float64, **kw)
-            assert rel_err(raw.cpu().numpy(), ref64) <= max(1e-5, engine_err)
+            assert rel_err(raw.cpu().numpy(), ref64) <= (1e-5 if n_fft == 1024 else 2e-5)
             full = small.wav_to_logmel(x, **kw)
             assert torch.equal(full, ref_plan.wav_to_logmel(x, **kw))
 
@@ -439,3 +441,52 @@ def test_fp16_mfma_mel_unsupported_shapes(dev):
     with pytest.raises(ValueError):
         small.set_mel_precision("fp16_mfma")                  # n_fft 256 is not instantiated
     assert small.mel_precision == "fp32"
+
+
+def test_timing_sampler_skips_first_launches_and_reads_both_kernels(dev):
+    """iris_timing_enable: the first 4 calls after enabling are never sampled (first dispatch on an idle GPU);
+    iris_timing_samples returns one duration per sampled call for the fused kernel (0) and the min-max/log kernel (1)."""
+    plan = FE().FrontendPlan(1024, 256, 64, 16000, 1, 8, 32000, dev)
+    x = torch.randn(8, 1, 32000, device=dev) * 0.1
+    ref = plan.wav_to_logmel(x).clone()
+    plan.timing_enable(1)
+    for _ in range(4):
+        plan.wav_to_logmel(x)
+    torch.cuda.synchronize()
+    assert len(plan.timing_samples(0)) == 0
+    for _ in range(6):
+        out = plan.wav_to_logmel(x)
+    torch.cuda.synchronize()
+    k1, k2 = plan.timing_samples(0), plan.timing_samples(1)
+    assert len(k1) == 6 and len(k2) in (0, 6)           # 0: the step is one kernel (min-max/log fused into it)
+    assert np.all(k1 > 0) and np.all(k1 < 5.0)
+    plan.timing_enable(3)
+    for _ in range(4 + 7):
+        plan.wav_to_logmel(x)
+    torch.cuda.synchronize()
+    assert len(plan.timing_samples(0)) == 3             # calls 4, 7, 10 after enabling
+    n, mean_ms = plan.timing_read()
+    assert n == 3 and mean_ms > 0
+    plan.timing_enable(False)
+    assert torch.equal(out, ref)
+    assert plan.fused_kernel_name().startswith("k_wav_to_mel<10,0,false,false")
+    assert plan.fused_kernel_name(True).startswith("k_wav_to_mel<10,0,false,true")
+
+
+def test_captured_step_replays_bit_exact(dev):
+    """FrontendPlan.capture: the fused call as a hipGraph; replays equal the eager call bit for bit, follow in-place
+    changes of the captured input / bands, and keep doing so after other launches on the same plan."""
+    rng = np.random.default_rng(5)
+    plan = FE().FrontendPlan(1024, 256, 64, 16000, 1, 6, 40000, dev)
+    x = torch.from_numpy((rng.standard_normal((6, 1, 40000)) * 0.1).astype(np.float32)).to(dev)
+    tb = torch.tensor(np.tile(np.array([[[3, 5], [40, 2]]], np.int32), (6, 1, 1)), device=dev)
+    step = plan.capture(x, minmax=True, log=True, t_bands=tb)
+    want = plan.wav_to_logmel(x, t_bands=tb).clone()
+    assert torch.equal(step.replay(), want)
+    x.mul_(0.5)
+    tb[:, 0, 0] = 7
+    plan.wav_to_logmel(torch.randn(2, 1, 9000, device=dev))     # an unrelated launch in between
+    want2 = plan.wav_to_logmel(x, t_bands=tb).clone()
+    assert not torch.equal(want, want2)
+    for _ in range(3):
+        assert torch.equal(step.replay(), want2)
