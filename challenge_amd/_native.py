@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("IRIS_LIB") or os.path.join(_HERE, "csrc", "libiris_fr
 
 IRIS_F_MINMAX, IRIS_F_LOG, IRIS_F_NORMALIZE = 1, 2, 4
 IRIS_MEL_F32, IRIS_MEL_F16_MFMA = 0, 1
+IRIS_EPILOGUE_FUSED, IRIS_EPILOGUE_TWO_KERNELS = 0, 1
 
 # every symbol include/iris_frontend.h declares, with (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -26,6 +27,8 @@ SIGNATURES = {
     "iris_plan_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _fp]),
     "iris_plan_destroy": (_i, [_vp]),
     "iris_plan_set_mel_precision": (_i, [_vp, _i]),
+    "iris_plan_set_epilogue": (_i, [_vp, _i]),
+    "iris_plan_status": (_i, [_vp, C.POINTER(_i)]),
     "iris_plan_get_mel": (_i, [_vp, _fp]),
     "iris_plan_num_frames": (_i, [_vp, _i]),
     "iris_normalize_workspace": (_sz, [_i, _sz]),

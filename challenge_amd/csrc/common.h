@@ -85,6 +85,11 @@ struct iris_plan {
     void* d_wfrag;
     int* d_tile_ks;
     float* d_ws;  // workspace
+    unsigned long long* d_slots;  // fused epilogue: [n_slots][2] {epoch, value} granules, then the status word
+    unsigned* d_status;
+    size_t n_slots;
+    unsigned epoch;  // launches of the fused-epilogue kernel so far (granule tag; never 0)
+    int epilogue;    // IRIS_EPILOGUE_*
     unsigned long long* d_dbg;  // diagnostic stamps (IRIS_DIAG builds only; nullptr otherwise)
     int ablate;                 // IRIS_DIAG builds: IRIS_ABLATE bits, read once at plan creation
     bool magmel_generic;        // IRIS_MAGMEL_GENERIC set at plan creation: iris_magmel takes the generic kernel

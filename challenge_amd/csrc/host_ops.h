@@ -201,26 +201,30 @@ static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int
 // Geometry + grid of the fused kernel: one workgroup per CU (every wave the registers allow), checked once per
 // (kernel, batch, frames) against the occupancy the hardware really grants and cached in the plan - the hot launch
 // path does no runtime query.
-static int fused_config(iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, bool bands, int* chunk_frames,
-                        int* chunks_per_clip, int* grid, size_t* lds) {
+static int fused_config(iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, bool bands, bool fuse,
+                        int* chunk_frames, int* chunks_per_clip, int* grid, size_t* lds) {
     for (const iris_plan::FusedGeom& g : p->geom_cache)
         if (g.kernel == (const void*)kernel && g.batch == batch && g.T == T) {
             *chunk_frames = g.chunk_frames;
             *chunks_per_clip = g.chunks_per_clip;
             *grid = g.grid;
             *lds = g.lds;
-            return IRIS_OK;
+            return g.lds == 0 ? IRIS_E_UNSUPPORTED : IRIS_OK;  // lds 0: this shape does not fit (remembered)
         }
     fused_geometry(p, batch, T, 1, chunk_frames, chunks_per_clip);
-    *lds = fused_lds_bytes(p, streams, bands, *chunk_frames);
-    if (*lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
-    int resident = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
-                                                                64 * fused_waves(p->log2n, streams, bands, p->need_hi != 0), *lds);
-    if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
-    if (resident < 1) return fail(IRIS_E_UNSUPPORTED, "fused kernel does not fit one workgroup per CU (LDS %zu B)", *lds);
+    *lds = fused_lds_bytes(p, streams, bands, *chunk_frames, fuse);
+    if (fuse) *lds = fused_tile_off(*lds) + fused_tile_bytes(p, streams, bands, *chunk_frames);
     *grid = std::min(batch * *chunks_per_clip, p->num_cu);
     if (p->geom_cache.size() >= 64) p->geom_cache.clear();
+    if (*lds > 160 * 1024) {
+        p->geom_cache.push_back({(const void*)kernel, batch, T, *chunk_frames, *chunks_per_clip, *grid, 0});
+        return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
+    }
+    int resident = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
+                                                                64 * fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse), *lds);
+    if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+    if (resident < 1) return fail(IRIS_E_UNSUPPORTED, "fused kernel does not fit one workgroup per CU (LDS %zu B)", *lds);
     p->geom_cache.push_back({(const void*)kernel, batch, T, *chunk_frames, *chunks_per_clip, *grid, *lds});
     return IRIS_OK;
 }
@@ -273,24 +277,58 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     const bool bands = (n_tb > 0) || (n_fb > 0);
     const bool mfma = p->mel_precision == 1 && !bands;  // calls with bands always take the fp32 kernel
     const int streams = mfma ? 1 : plan_streams(p);
-    const fused_kernel_t kernel = mfma ? mfma_kernel(p->log2n) : fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams);
+    // min-max / log inside the kernel (one launch) unless: nothing to apply, the MFMA variant, two frame streams
+    // (diag), the plan says two kernels, the stream is being captured (the epoch is a host counter: it would be
+    // frozen in the graph), or the chunk's mel tile does not fit the LDS
+    bool fuse = (do_minmax || do_log) && !mfma && streams == 1 && p->epilogue == IRIS_EPILOGUE_FUSED;
+    if (fuse) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) fuse = false;
+    }
+    fused_kernel_t kernel = nullptr;
     int grid = 0;
     size_t lds = 0;
     a.wfrag = p->d_wfrag;
     a.tile_ks = p->d_tile_ks;
     a.kb = p->mfma_kb;
     if (mfma) {
+        kernel = mfma_kernel(p->log2n);
         fused_geometry(p, batch, a.T, 1, &a.chunk_frames, &a.chunks_per_clip);
         lds = mfma_lds_bytes(p);
         grid = std::min(batch * a.chunks_per_clip, p->num_cu);
-    } else if ((rc = fused_config(p, kernel, batch, a.T, streams, bands, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
-        return rc;
+    } else {
+        if (fuse) {
+            kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams, true);
+            rc = fused_config(p, kernel, batch, a.T, streams, bands, true, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds);
+            // no fused epilogue when the tile does not fit, or when a clip has more chunks than the grid has workgroups
+            // (a workgroup would then wait for a chunk it has yet to process itself)
+            if (rc == IRIS_E_UNSUPPORTED || (size_t)batch * a.chunks_per_clip > p->n_slots || a.chunks_per_clip > grid) fuse = false;
+            else if (rc) return rc;
+        }
+        if (!fuse) {
+            kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams, false);
+            if ((rc = fused_config(p, kernel, batch, a.T, streams, bands, false, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
+                return rc;
+        }
+    }
+    a.slots = p->d_slots;
+    a.status = p->d_status;
+    a.epoch = 0;
+    a.tile_off = a.pitch = 0;
+    a.do_minmax = do_minmax;
+    a.do_log = do_log;
+    if (fuse) {
+        if (++p->epoch == 0) p->epoch = 1;
+        a.epoch = p->epoch;
+        a.pitch = fused_tile_pitch(p, a.chunk_frames);
+        a.tile_off = (int)fused_tile_off(fused_lds_bytes(p, streams, bands, a.chunk_frames, true));
+    }
     if ((size_t)p->n_mel * a.T * p->channels * 4 > 0xffffffffull || (size_t)a.T * p->channels * 4 >= (1u << 24))
         return fail(IRIS_E_UNSUPPORTED, "iris_wav_to_logmel: clip too long (%d frames x %d channels)", a.T, p->channels);
     a.n_chunks = batch * a.chunks_per_clip;
     a.chunk_base = a.T / a.chunks_per_clip;
     a.chunk_rem = a.T % a.chunks_per_clip;
-    const int waves = mfma ? kMfmaWaves : fused_waves(p->log2n, streams, bands, p->need_hi != 0);
+    const int waves = mfma ? kMfmaWaves : fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse);
     const int parts_per_chunk = waves;
     const size_t n_partial = 2 * (size_t)a.n_chunks * parts_per_chunk;
     a.partial = p->d_ws;
@@ -322,7 +360,7 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         e = hipGetLastError();
     }
     HIP_TRY(e);
-    if (do_minmax || do_log) {
+    if ((do_minmax || do_log) && !fuse) {
         size_t row_len = (size_t)p->n_mel * a.T * p->channels;
         const unsigned n_chunks = (unsigned)((row_len + kApply - 1) / kApply);
         float* x = out;

@@ -155,54 +155,62 @@ static int plan_streams(const iris_plan* p) {
 
 // LDS of the fused kernel: landing + exchange buffers of every wave (the constant block is
 // staged through the exchange area once), the frame queue, the MELMODE 1 tables
-static size_t fused_lds_bytes(const iris_plan* p, int streams, bool bands, int chunk_frames = 0) {
+static size_t fused_lds_bytes(const iris_plan* p, int streams, bool bands, int chunk_frames = 0, bool fuse = false) {
     const size_t xbuf = (wave_buf_bytes(p->log2n) + 15) & ~(size_t)15;
-    const size_t waves = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0) * streams;
+    const size_t waves = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse) * streams;
     const size_t stage = (size_t)const_nv4(p->log2n) * 64 * 16;
     const size_t land = fused_direct(p->log2n) ? ((stage + 15) & ~(size_t)15) : waves * (size_t)p->n_fft * 4;
     size_t bytes = land + std::max(waves * xbuf, stage) + 16;
     if (p->mel_mode == 1) bytes += ((size_t)p->rows * p->n_mel + p->n_mel) * 4;
     // time-band bitmap of a chunk, written 2 words per wave per pass over the chunk's frames
-    const size_t pass = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0) * 64;
+    const size_t pass = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse) * 64;
     bytes += (((size_t)chunk_frames + pass - 1) / pass * pass / 32 + 2) * 4;
     return bytes;
+}
+// fused epilogue: mel tile [M][pitch] (+ the workgroup's reduction scratch) behind everything else, 16-byte aligned
+static int fused_tile_pitch(const iris_plan* p, int chunk_frames) { return (chunk_frames * p->channels) | 1; }
+static size_t fused_tile_off(size_t lds_without_tile) { return (lds_without_tile + 15) & ~(size_t)15; }
+static size_t fused_tile_bytes(const iris_plan* p, int streams, bool bands, int chunk_frames) {
+    const size_t waves = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, true);
+    return ((size_t)p->n_mel * fused_tile_pitch(p, chunk_frames) + 2 * waves + 4) * 4;
 }
 
 typedef void (*fused_kernel_t)(const FusedArgs);
 
-template <int LOG2N, int MELMODE, int S>
+template <int LOG2N, int MELMODE, int S, bool FUSE>
 static fused_kernel_t fused_kernel_hb(bool hi, bool bands) {
     if (hi)
-        return bands ? k_wav_to_mel<LOG2N, MELMODE, true, true, S> : k_wav_to_mel<LOG2N, MELMODE, true, false, S>;
-    return bands ? k_wav_to_mel<LOG2N, MELMODE, false, true, S> : k_wav_to_mel<LOG2N, MELMODE, false, false, S>;
+        return bands ? k_wav_to_mel<LOG2N, MELMODE, true, true, S, FUSE> : k_wav_to_mel<LOG2N, MELMODE, true, false, S, FUSE>;
+    return bands ? k_wav_to_mel<LOG2N, MELMODE, false, true, S, FUSE> : k_wav_to_mel<LOG2N, MELMODE, false, false, S, FUSE>;
 }
-template <int LOG2N, int S>
+template <int LOG2N, int S, bool FUSE>
 static fused_kernel_t fused_kernel_mm(int mel_mode, bool hi, bool bands) {
     if constexpr (LOG2N <= 10) {
         if (mel_mode == 0)  // register weights exist only for the half-spectrum variant up to n_fft 1024
-            return bands ? k_wav_to_mel<LOG2N, 0, false, true, S> : k_wav_to_mel<LOG2N, 0, false, false, S>;
-        if (mel_mode == 3) return bands ? k_wav_to_mel<LOG2N, 3, false, true, S> : k_wav_to_mel<LOG2N, 3, false, false, S>;
+            return bands ? k_wav_to_mel<LOG2N, 0, false, true, S, FUSE> : k_wav_to_mel<LOG2N, 0, false, false, S, FUSE>;
+        if (mel_mode == 3)
+            return bands ? k_wav_to_mel<LOG2N, 3, false, true, S, FUSE> : k_wav_to_mel<LOG2N, 3, false, false, S, FUSE>;
     }
-    if (mel_mode == 1) return fused_kernel_hb<LOG2N, 1, S>(hi, bands);
-    return fused_kernel_hb<LOG2N, 2, S>(hi, bands);
+    if (mel_mode == 1) return fused_kernel_hb<LOG2N, 1, S, FUSE>(hi, bands);
+    return fused_kernel_hb<LOG2N, 2, S, FUSE>(hi, bands);
 }
-// two frame streams per wave exist for n_fft 512 / 1024
+// two frame streams per wave exist for n_fft 512 / 1024, in diagnostic builds only
 template <int LOG2N>
-static fused_kernel_t fused_kernel_m(int mel_mode, bool hi, bool bands, int streams) {
+static fused_kernel_t fused_kernel_m(int mel_mode, bool hi, bool bands, int streams, bool fuse) {
 #if IRIS_DIAG
     if constexpr (LOG2N == 9 || LOG2N == 10) {
-        if (streams == 2) return fused_kernel_mm<LOG2N, 2>(mel_mode, hi, bands);
+        if (streams == 2) return fused_kernel_mm<LOG2N, 2, false>(mel_mode, hi, bands);
     }
 #endif
     (void)streams;
-    return fused_kernel_mm<LOG2N, 1>(mel_mode, hi, bands);
+    return fuse ? fused_kernel_mm<LOG2N, 1, true>(mel_mode, hi, bands) : fused_kernel_mm<LOG2N, 1, false>(mel_mode, hi, bands);
 }
-static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands, int streams) {
+static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands, int streams, bool fuse = false) {
     switch (log2n) {
-        case 11: return fused_kernel_m<11>(mel_mode, hi, bands, streams);
-        case 10: return fused_kernel_m<10>(mel_mode, hi, bands, streams);
-        case 9: return fused_kernel_m<9>(mel_mode, hi, bands, streams);
-        default: return fused_kernel_m<8>(mel_mode, hi, bands, streams);
+        case 11: return fused_kernel_m<11>(mel_mode, hi, bands, streams, fuse);
+        case 10: return fused_kernel_m<10>(mel_mode, hi, bands, streams, fuse);
+        case 9: return fused_kernel_m<9>(mel_mode, hi, bands, streams, fuse);
+        default: return fused_kernel_m<8>(mel_mode, hi, bands, streams, fuse);
     }
 }
 static fused_kernel_t mfma_kernel(int log2n) {
@@ -235,9 +243,11 @@ static hipError_t allow_big_lds(const iris_plan* p) {
     for (int v = 0; v < (IRIS_DIAG ? 4 : 2); ++v) {
         const int streams = (v & 2) ? 2 : 1;
         if (streams == 2 && p->log2n != 9 && p->log2n != 10) continue;
-        e = hipFuncSetAttribute((const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, (v & 1) != 0, streams),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-        if (e != hipSuccess) return e;
+        for (int fuse = 0; fuse < (streams == 1 ? 2 : 1); ++fuse) {
+            e = hipFuncSetAttribute((const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, (v & 1) != 0, streams, fuse != 0),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+            if (e != hipSuccess) return e;
+        }
     }
     if (p->mfma_ok) {
         e = hipFuncSetAttribute((const void*)mfma_kernel(p->log2n), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
@@ -304,6 +314,11 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     if (const char* e = getenv("IRIS_STREAMS")) p->streams = atoi(e) == 2 ? 2 : 1;
 #endif
     p->magmel_generic = getenv("IRIS_MAGMEL_GENERIC") != nullptr;  // test hook: read once, never per launch
+    p->d_slots = nullptr;
+    p->d_status = nullptr;
+    p->epoch = 0;
+    p->epilogue = IRIS_EPILOGUE_FUSED;
+    if (const char* e = getenv("IRIS_EPILOGUE")) p->epilogue = atoi(e) == IRIS_EPILOGUE_TWO_KERNELS ? IRIS_EPILOGUE_TWO_KERNELS : IRIS_EPILOGUE_FUSED;
     p->timing = 0;
     p->launch_no = 0;
     p->ev_used = 0;
@@ -532,6 +547,16 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
         iris_plan_destroy(p);
         return fail((int)e, "hipMalloc(workspace %zu floats) failed: %s", p->ws_floats, hipGetErrorString(e));
     }
+    // fused epilogue: per-chunk {epoch, min} / {epoch, max} granules (worst case one frame per chunk) + a status word;
+    // zeroed once - a granule is valid only when it carries the epoch of the launch that reads it
+    p->n_slots = (size_t)max_batch * t_max;
+    e = hipMalloc((void**)&p->d_slots, p->n_slots * 16 + 64);
+    if (e == hipSuccess) e = hipMemset(p->d_slots, 0, p->n_slots * 16 + 64);
+    if (e != hipSuccess) {
+        iris_plan_destroy(p);
+        return fail((int)e, "hipMalloc(epilogue slots) failed: %s", hipGetErrorString(e));
+    }
+    p->d_status = reinterpret_cast<unsigned*>(p->d_slots + 2 * p->n_slots);
     *out = p;
     return IRIS_OK;
 }
@@ -611,6 +636,7 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
     (void)hipFree(p->d_wfrag);
     (void)hipFree(p->d_tile_ks);
     (void)hipFree(p->d_ws);
+    (void)hipFree(p->d_slots);
     delete p;
     return IRIS_OK;
 }
@@ -626,6 +652,24 @@ extern "C" int iris_plan_set_mel_precision(iris_plan* p, int precision) {
         return fail(IRIS_E_UNSUPPORTED, "fp16 MFMA mel needs n_fft 512/1024/2048, n_mel <= 128, bands inside the lower half "
                                         "of the spectrum and <= 256 bins per 16 bands");
     p->mel_precision = 1;
+    return IRIS_OK;
+}
+
+extern "C" int iris_plan_set_epilogue(iris_plan* p, int mode) {
+    if (!p) return fail(IRIS_E_INVALID, "iris_plan_set_epilogue: NULL plan");
+    if (mode != IRIS_EPILOGUE_FUSED && mode != IRIS_EPILOGUE_TWO_KERNELS)
+        return fail(IRIS_E_INVALID, "iris_plan_set_epilogue: unknown mode %d", mode);
+    p->epilogue = mode;
+    return IRIS_OK;
+}
+
+extern "C" int iris_plan_status(iris_plan* p, int* status) {
+    if (!p || !status) return fail(IRIS_E_INVALID, "iris_plan_status: NULL argument");
+    DeviceGuard guard(p->device);
+    unsigned v = 0;
+    HIP_TRY(hipMemcpy(&v, p->d_status, sizeof(v), hipMemcpyDeviceToHost));  // synchronises with the device
+    if (v) HIP_TRY(hipMemset(p->d_status, 0, sizeof(v)));
+    *status = (int)v;
     return IRIS_OK;
 }
 

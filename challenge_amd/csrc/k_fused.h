@@ -26,7 +26,9 @@
 //   HI        = some band needs bins above n_fft/4 (both halves of the untangle)
 //   BANDS     = SpecAugment / filter bands present (time bands: per-chunk bitmap, masked frames skip
 //               the transform; frequency bands: folded into the chunk's band weights)
-//   S         = frames in flight per wave (1; 2 exists for n_fft 512 / 1024 and measured slower)
+//   S         = frames in flight per wave (1; 2 exists in diagnostic builds for n_fft 512 / 1024 and measured slower)
+//   FUSE      = min-max / log inside the kernel (LDS mel tile + clip-level granule exchange, see the epilogue) instead of
+//               per-wave partials for a second kernel
 // ---------------------------------------------------------------------------
 // One workgroup per CU holding every wave of the CU: all waves are of one age class for the issue
 // arbiter (which favours older waves) and share one frame queue.
@@ -52,9 +54,11 @@
 #endif
 constexpr bool fused_direct(int log2n) { return IRIS_DIRECT_LOAD && log2n <= IRIS_DIRECT_MAX; }
 // hi: the variant computes both halves of the untangle (n_fft 2048: 12 waves would spill, so 8)
-constexpr int fused_waves(int log2n, int streams = 1, bool bands = false, bool hi = false) {
+// fuse: the variant applies min-max / log itself (its epilogue needs a few registers more: at n_fft 2048 twelve waves
+// would spill, so 8 there)
+constexpr int fused_waves(int log2n, int streams = 1, bool bands = false, bool hi = false, bool fuse = false) {
     return streams > 1 ? IRIS_S2_WAVES
-                       : (log2n >= 11 ? ((IRIS_W2048 == 0 && fused_direct(11) && !bands && !hi) ? 12 : (IRIS_W2048 ? IRIS_W2048 : 8))
+                       : (log2n >= 11 ? ((IRIS_W2048 == 0 && fused_direct(11) && !bands && !hi && !fuse) ? 12 : (IRIS_W2048 ? IRIS_W2048 : 8))
                                       : (log2n == 10 ? (bands ? 12 : IRIS_W1024) : 16));
 }
 
@@ -80,6 +84,14 @@ struct FusedArgs {
     const void* wfrag;
     const int* tile_ks;
     int kb;
+    // fused epilogue (FUSE): min-max / log applied inside the kernel.  The chunk's mel values are collected in an LDS
+    // tile [M][pitch] at byte offset tile_off; the workgroups of a clip exchange their (min, max) through 8-byte
+    // {epoch, value} granules slots[chunk][2] (agent-scope sc1 stores / loads; epoch = the plan's launch counter,
+    // never 0); a wait that does not complete within ~2 s sets *status and fills the chunk with NaN
+    unsigned long long* slots;
+    unsigned* status;
+    unsigned epoch;
+    int tile_off, pitch, do_minmax, do_log;
     int ablate;  // diagnostic only (IRIS_ABLATE): skip phases, results are wrong when non-zero
     unsigned long long* dbg;  // diagnostic only: [4] shader-clock / 100 MHz stamps of workgroup 0
 };
@@ -164,9 +176,12 @@ __device__ __forceinline__ void dma_frame(const float* clip, int len, int start,
         dma_frame_x1<LOG2N>(clip, len, start, fbuf_lds, lane);
 }
 
-template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S>
-__global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(LOG2N, S, BANDS, HI) / 4) void k_wav_to_mel(const FusedArgs a) {
-    constexpr int kFusedWaves = fused_waves(LOG2N, S, BANDS, HI);
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+constexpr unsigned long long kEpilogueTimeoutTicks = 200000000ull;  // s_memrealtime runs at 100 MHz: 2 s
+
+template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S, bool FUSE>
+__global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_waves(LOG2N, S, BANDS, HI, FUSE) / 4) void k_wav_to_mel(const FusedArgs a) {
+    constexpr int kFusedWaves = fused_waves(LOG2N, S, BANDS, HI, FUSE);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the wave index is uniform: keep it (and everything derived from it) in SGPRs
@@ -288,7 +303,9 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
             }
         }
         __syncthreads();
-        load_consts<LOG2N>(reinterpret_cast<const float*>(stage), lane, tw, post, win, wreg, lo0);
+        // FUSE: the constants are (re)read from the staging area at the top of every chunk instead, so that they are
+        // dead - and their 72 registers free - during the epilogue
+        if constexpr (!FUSE) load_consts<LOG2N>(reinterpret_cast<const float*>(stage), lane, tw, post, win, wreg, lo0);
         if constexpr (MELMODE == 1) {
             const int* fbc = nullptr;
             if constexpr (BANDS) {
@@ -304,6 +321,10 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
     }
     for (int chunk = g0; chunk < a.n_chunks; chunk += gridDim.x) {
         PH_BEGIN();
+        if constexpr (FUSE) {
+            static_assert(!FUSE || DIRECT, "the staging area must survive the frame loop");
+            load_consts<LOG2N>(reinterpret_cast<const float*>(smem), lane, tw, post, win, wreg, lo0);
+        }
         const int b = chunk_clip(chunk);
         const int t0 = chunk_t0(chunk, b), nt = chunk_nt(chunk, b);
         const int* tb = nullptr;
@@ -337,7 +358,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
             // LDS table where the chunk starts) instead of touching the magnitudes of every frame.
             if constexpr (MELMODE == 0) {
                 if (fb) {
-                    if (chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);  // pristine weights (not hoisted)
+                    if (!FUSE && chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);  // pristine weights (not hoisted)
                     for (int i = 0; i < a.n_fb; ++i) {  // band bounds are wave-uniform (scalar loads)
                         const int off = fb[2 * i] - lo0, end = off + fb[2 * i + 1];
 #pragma unroll
@@ -348,7 +369,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
             }
             if constexpr (MELMODE == 3) {  // two windows of 8 bins: wreg[0..7] at lo0 & 0xffff, wreg[8..15] at lo0 >> 16
                 if (fb) {
-                    if (chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);
+                    if (!FUSE && chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);
                     for (int i = 0; i < a.n_fb; ++i) {
                         const int offa = fb[2 * i] - (lo0 & 0xffff), enda = offa + fb[2 * i + 1];
                         const int offb = fb[2 * i] - (lo0 >> 16), endb = offb + fb[2 * i + 1];
@@ -387,9 +408,17 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
         // address = (uniform) out + ((b M T + t0) C + f) * 4  +  (per lane) m * T * C * 4
         const unsigned rowpitch_b = (unsigned)a.T * (unsigned)a.C * 4u;
         float* const chunk_out = a.out + ((size_t)b * a.M * a.T + t0) * a.C;
-        auto store_band = [&](int fidx, unsigned off, float v) {
-            if (!ABL(16))
-                asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(chunk_out + fidx) : "memory");
+        // FUSE: the value goes to the chunk's LDS tile [M][pitch] instead (pitch is odd: the 64 lanes of a frame hit
+        // 64 different banks); min-max / log and the coalesced write-out follow once the clip's range is known
+        float* const tile = reinterpret_cast<float*>(smem + a.tile_off);
+        auto store_band = [&](int fidx, int m, float v) {
+            if constexpr (FUSE) {
+                tile[__umul24((unsigned)m, (unsigned)a.pitch) + fidx] = v;
+            } else {
+                const unsigned off = __umul24((unsigned)m, rowpitch_b);  // host checks rowpitch < 2^24
+                if (!ABL(16))
+                    asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(chunk_out + fidx) : "memory");
+            }
         };
         float mn = INFINITY, mx = -INFINITY;
 
@@ -476,7 +505,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
 #pragma unroll
                     for (int st = 0; st < S; ++st)
                         if (live[st])
-                            for (int m = lane; m < a.M; m += kWave) store_band(fcur[st], (unsigned)m * rowpitch_b, 0.f);
+                            for (int m = lane; m < a.M; m += kWave) store_band(fcur[st], m, 0.f);
                     mn = fminf(mn, 0.f);
                     mx = fmaxf(mx, 0.f);
                     advance();
@@ -526,11 +555,11 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
                     sb += tb2;
                     if (live[st]) {
                         const float va = (sa.x + sa.y) * keep, vb = (sb.x + sb.y) * keep;
-                        store_band(fcur[st], __umul24((unsigned)lane, rowpitch_b), va);
+                        store_band(fcur[st], lane, va);
                         mn = fminf(mn, va);
                         mx = fmaxf(mx, va);
                         if (lane + kWave < a.M) {
-                            store_band(fcur[st], __umul24((unsigned)(lane + kWave), rowpitch_b), vb);
+                            store_band(fcur[st], lane + kWave, vb);
                             mn = fminf(mn, vb);
                             mx = fmaxf(mx, vb);
                         }
@@ -550,7 +579,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
                     const float acc = acc2.x + acc2.y;
                     if (live[st] && lane < a.M) {
                         const float v = acc * keep;
-                        store_band(fcur[st], __umul24((unsigned)lane, rowpitch_b), v);  // host checks rowpitch < 2^24
+                        store_band(fcur[st], lane, v);
                         mn = fminf(mn, v);
                         mx = fmaxf(mx, v);
                     }
@@ -577,7 +606,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
                                     acc = fmaf(a.wband[i * a.M + m], magbuf[st][lo + i], acc);
                             }
                             const float v = acc * keep;
-                            store_band(fcur[st], (unsigned)m * rowpitch_b, v);
+                            store_band(fcur[st], m, v);
                             mn = fminf(mn, v);
                             mx = fmaxf(mx, v);
                         }
@@ -591,12 +620,88 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI), fused_waves(
             if ABL(4096) ph[7] += 1;
         }
         PH_BEGIN();
-        // every wave leaves its own (min, max) partial for k_minmax_log_apply
         mn = wave_min(mn);
         mx = wave_max(mx);
-        if (lane == 0) {
-            a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 0] = mn;
-            a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 1] = mx;
+        if constexpr (!FUSE) {
+            // every wave leaves its own (min, max) partial for k_minmax_log_apply
+            if (lane == 0) {
+                a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 0] = mn;
+                a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 1] = mx;
+            }
+        } else {
+            // Fused epilogue: the chunk's mel values sit in the LDS tile.  Workgroup range -> (clips split over several
+            // workgroups) one 8-byte {epoch, value} granule each for min and max, published with agent-scope stores and
+            // swept by wave 0 until every chunk of the clip carries this launch's epoch -> (x - min) / max(max - min,
+            // 1e-8), ln(x + 1e-8) -> coalesced rows of out[b, m, t0 .. t0 + nt, :].  Every workgroup publishes before
+            // it waits and all workgroups of the grid are resident (grid <= CUs), so the waits always complete; the
+            // sweep is bounded all the same (status word + NaN output instead of a hang).
+            float* red = tile + (size_t)a.M * a.pitch;  // [2 * waves + 4]
+            int le = lane;  // epilogue lane index, hidden from loop-invariant code motion: per-lane addresses of the
+            asm volatile("" : "+v"(le));  // epilogue must not be hoisted across the frame loop (they would spill there)
+            if (lane == 0) {
+                red[wv] = mn;
+                red[kFusedWaves + wv] = mx;
+            }
+            __syncthreads();  // tile complete, wave ranges visible
+            if (wv == 0) {
+                float lo = le < kFusedWaves ? red[le] : INFINITY, hi = le < kFusedWaves ? red[kFusedWaves + le] : -INFINITY;
+                lo = wave_min(lo);
+                hi = wave_max(hi);
+                unsigned failed = 0;
+                if (a.do_minmax && a.chunks_per_clip > 1) {
+                    gu64* slots = (gu64*)opaque(a.slots) + 2 * (size_t)b * a.chunks_per_clip;
+                    const unsigned long long tag = (unsigned long long)a.epoch << 32;
+                    if (lane == 0) {
+                        const int ci = chunk - b * a.chunks_per_clip;
+                        __hip_atomic_store(slots + 2 * ci, tag | __float_as_uint(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(slots + 2 * ci + 1, tag | __float_as_uint(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        bool ok = true;
+                        float l2 = INFINITY, h2 = -INFINITY;
+                        for (int i = le; i < a.chunks_per_clip; i += kWave) {
+                            const unsigned long long g0v = __hip_atomic_load(slots + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long g1v = __hip_atomic_load(slots + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && ((g0v >> 32) == a.epoch) && ((g1v >> 32) == a.epoch);
+                            l2 = fminf(l2, __uint_as_float((unsigned)g0v));
+                            h2 = fmaxf(h2, __uint_as_float((unsigned)g1v));
+                        }
+                        if (__all(ok)) {
+                            lo = wave_min(l2);
+                            hi = wave_max(h2);
+                            break;
+                        }
+                        if (__builtin_amdgcn_s_memrealtime() - t_begin > kEpilogueTimeoutTicks) {
+                            failed = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                if (lane == 0) {
+                    red[2 * kFusedWaves + 0] = lo;
+                    red[2 * kFusedWaves + 1] = hi;
+                    red[2 * kFusedWaves + 2] = __uint_as_float(failed);
+                    if (failed) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            const float cmn = red[2 * kFusedWaves], cmx = red[2 * kFusedWaves + 1];
+            const bool failed = __float_as_uint(red[2 * kFusedWaves + 2]) != 0;
+            const float den = fmaxf(cmx - cmn, 1e-8f);
+            const int mm = a.do_minmax, lg = a.do_log;
+            for (int m = wv; m < a.M; m += kFusedWaves) {  // wave-uniform row; lanes run along the row
+                const float* trow = tile + __umul24((unsigned)m, (unsigned)a.pitch);
+                float* orow = chunk_out + (size_t)m * a.T * a.C;
+                for (int f0 = le; f0 < nwf; f0 += kWave) {
+                    float y = trow[f0];
+                    if (mm) y = (y - cmn) / den;
+                    if (lg) y = logf(y + 1e-8f);
+                    if (failed) y = NAN;
+                    asm volatile("global_store_dword %0, %1, %2" ::"v"((unsigned)f0 * 4u), "v"(y), "s"(orow) : "memory");
+                }
+            }
         }
         if (chunk + (int)gridDim.x < a.n_chunks) {  // another chunk follows: restart the queue
             __syncthreads();

@@ -7,6 +7,7 @@ must be float32, contiguous and on a ROCm device -- there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from typing import Optional, Tuple
 
@@ -99,6 +100,7 @@ class FrontendPlan:
         self._handle = handle
         self._lock = threading.Lock()
         self.mel_precision = "fp32"
+        self.epilogue = "two_kernels" if os.environ.get("IRIS_EPILOGUE") == "1" else "fused"
 
     @classmethod
     def mel_only(cls, n_mel: int, n_bins: int, channels: int, max_batch: int, device,
@@ -131,6 +133,20 @@ class FrontendPlan:
         code = {"fp32": N.IRIS_MEL_F32, "fp16_mfma": N.IRIS_MEL_F16_MFMA}[precision]
         N.check(N.lib().iris_plan_set_mel_precision(self._handle, code), "iris_plan_set_mel_precision")
         self.mel_precision = precision
+
+    def set_epilogue(self, mode: str = "fused") -> None:
+        """'fused' (default): min-max / log inside the fused kernel, one launch per call.  'two_kernels': raw mel +
+        per-wave partials, then the min-max / log kernel - for several plans running CONCURRENTLY on one device
+        (see iris_plan_set_epilogue in include/iris_frontend.h); calls under hipGraph capture take it by themselves."""
+        code = {"fused": N.IRIS_EPILOGUE_FUSED, "two_kernels": N.IRIS_EPILOGUE_TWO_KERNELS}[mode]
+        N.check(N.lib().iris_plan_set_epilogue(self._handle, code), "iris_plan_set_epilogue")
+        self.epilogue = mode
+
+    def status(self) -> int:
+        """0 = every bounded in-kernel wait of the fused epilogue completed so far (synchronises; resets the word)."""
+        st = C.c_int(0)
+        N.check(N.lib().iris_plan_status(self._handle, C.byref(st)), "iris_plan_status")
+        return st.value
 
     def close(self) -> None:
         if self._handle is not None:
@@ -277,9 +293,13 @@ class CapturedStep:
 def bias_relu_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """In place max(x + bias[c], 0) on a channels-last activation: x is [B, C, H, W] with channels_last strides (or any
     dense tensor whose innermost axis is the channel axis).  One HIP launch (iris_bias_relu)."""
-    x = _require_device_f32(x, "x") if x.is_contiguous(memory_format=torch.channels_last) or x.is_contiguous() else None
-    if x is None:
-        raise ValueError("bias_relu_: x must be dense (channels_last 4-D or contiguous with channels innermost)")
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
+        raise TypeError("bias_relu_: x must be a float32 tensor on a ROCm device (no CPU fallback)")
+    nhwc = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+    if not nhwc and not (x.is_contiguous() and x.shape[-1] == bias.shape[0]):
+        raise ValueError("bias_relu_: x must be channels_last [B, C, H, W], or contiguous with the channel axis innermost")
+    if (nhwc and x.shape[1] != bias.shape[0]) or bias.dtype != torch.float32 or not bias.is_contiguous():
+        raise ValueError("bias_relu_: bias must be a contiguous float32 vector with one entry per channel")
     c = int(bias.shape[0])
     with torch.cuda.device(x.device):
         rc = N.lib().iris_bias_relu(x.data_ptr(), bias.data_ptr(), x.numel() // c, c, _stream_ptr(x.device))
@@ -303,8 +323,8 @@ def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
 
 class PipelinedFrontend:
     """Independent batches through the fused path on `n_streams` HIP streams, one `FrontendPlan` each (a plan's
-    workspace belongs to one stream, include/iris_frontend.h): one stream's min-max/log kernel and launch gaps run in
-    the shadow of another's fused kernel.  c2 on one MI355X: 22.9 us per batch on two streams against 25.6 us on one.
+    workspace belongs to one stream, include/iris_frontend.h), in the two-kernel form of the step: one stream's
+    min-max/log kernel and launch gaps run in the shadow of another's fused kernel.
 
         pipe = PipelinedFrontend(2, n_fft=1024, hop=256, n_mel=64, channels=1, max_batch=32, max_len=160000, device=dev)
         for wav, out in batches:                 # device tensors; `out` is written asynchronously
@@ -318,6 +338,9 @@ class PipelinedFrontend:
         if n_streams < 1:
             raise ValueError("n_streams must be >= 1")
         self.plans = [FrontendPlan(**plan_kwargs) for _ in range(n_streams)]
+        if n_streams > 1:  # concurrent launches on one device: no in-kernel waits between workgroups
+            for p in self.plans:
+                p.set_epilogue("two_kernels")
         self.device = self.plans[0].device
         self.streams = [torch.cuda.Stream(self.device) for _ in range(n_streams)]
         self._next = 0

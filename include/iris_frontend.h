@@ -107,6 +107,27 @@ int iris_plan_destroy(iris_plan* plan);
 #define IRIS_MEL_F16_MFMA 1
 int iris_plan_set_mel_precision(iris_plan* plan, int precision);
 
+/*
+ * How iris_wav_to_logmel applies min-max / log (data_utils.py:37-55):
+ *   IRIS_EPILOGUE_FUSED        (default) inside the fused kernel: ONE launch per call.  A clip's workgroups exchange
+ *                              their (min, max) through the plan's device memory while the kernel runs, which needs
+ *                              every workgroup of the launch resident (guaranteed: grid <= CUs) and a per-launch epoch
+ *                              from the host - so calls made while `stream` is being captured into a hipGraph, the
+ *                              fp16-MFMA variant and shapes whose chunk does not fit the LDS tile take the two-kernel
+ *                              path by themselves.  Do not run several fused launches CONCURRENTLY on one device
+ *                              (plans on different streams): each could hold CUs while waiting for workgroups the
+ *                              other keeps from starting; the wait is bounded (~2 s: the affected clips come out as
+ *                              NaN and iris_plan_status reports 1), never a hang.  Use TWO_KERNELS for such pipelines.
+ *   IRIS_EPILOGUE_TWO_KERNELS  fused kernel (raw mel + per-wave partials), then the min-max / log kernel.
+ * IRIS_EPILOGUE=1 in the environment at plan creation selects TWO_KERNELS (test / A-B hook; so do IRIS_CHUNK_FRAMES=n,
+ * frames per chunk of the fused kernel, and IRIS_MAGMEL_GENERIC - test hooks read once per plan, never per launch).
+ * iris_plan_status: 0 = every bounded wait so far completed; synchronises with the device; resets the word.
+ */
+#define IRIS_EPILOGUE_FUSED 0
+#define IRIS_EPILOGUE_TWO_KERNELS 1
+int iris_plan_set_epilogue(iris_plan* plan, int mode);
+int iris_plan_status(iris_plan* plan, int* status_out);
+
 /* Name of the fused kernel iris_wav_to_logmel launches for this plan (with / without SpecAugment bands), as rocprofv3
  * prints it without the argument list, e.g. "k_wav_to_mel<10,0,false,false,1>"; HOST buffer. */
 int iris_plan_kernel_name(const iris_plan* plan, int with_bands, char* out_host, int capacity);
@@ -175,10 +196,11 @@ int iris_minmax_log(float* x, int n_rows, size_t row_len, int do_minmax, int do_
  * The fused hot path: [normalize ->] STFT -> magnitude -> band masks -> mel
  * [-> min-max] [-> log] without materialising the spectrum
  * (load_wav data_utils.py:22-23 + sj_train.py:108-123).  flags = IRIS_F_*.
- * Two launches on `stream` (the fused kernel, then min-max / log over its per-wave partials); the partials live in
- * the plan's own workspace, so calls on ONE plan must be ordered on one stream (or otherwise serialised) - create one
- * plan per stream to run batches concurrently.  Safe under hipGraph capture and replay (no per-call host state, no
- * atomics to reset).
+ * One launch on `stream` (min-max / log inside the fused kernel, IRIS_EPILOGUE_FUSED) or two (the fused kernel, then
+ * min-max / log over its per-wave partials) - see iris_plan_set_epilogue.  Partials and exchange slots live in the
+ * plan's own workspace, so calls on ONE plan must be ordered on one stream (or otherwise serialised) - create one
+ * plan per stream to run batches concurrently.  Safe under hipGraph capture and replay: a call made during capture
+ * takes the two-kernel path, which keeps no per-call host state and has no atomics to reset.
  */
 int iris_wav_to_logmel(iris_plan* plan, const float* wav, float* out, int batch, int len,
                        int flags, const int32_t* t_bands, int n_t_bands,

@@ -490,3 +490,42 @@ def test_captured_step_replays_bit_exact(dev):
     assert not torch.equal(want, want2)
     for _ in range(3):
         assert torch.equal(step.replay(), want2)
+
+
+@pytest.mark.parametrize("n_fft,hop,m,c,b,length,chunk", [(1024, 256, 64, 1, 32, 40000, 0),   # 8 workgroups per clip
+                                                          (1024, 256, 64, 1, 5, 30000, 8),    # 75 chunks of 8 frames
+                                                          (1024, 256, 64, 1, 40, 25600, 8),   # 520 chunks: workgroups loop
+                                                          (512, 256, 80, 2, 24, 20000, 0),    # two bands per lane, stereo
+                                                          (2048, 512, 128, 2, 3, 33075, 0),   # table mel, 8 waves
+                                                          (256, 128, 40, 1, 300, 4000, 0),    # one chunk per clip: no exchange
+                                                          (1024, 256, 150, 1, 2, 600000, 0),  # table mel, 124 chunks per clip
+                                                          (256, 128, 40, 1, 260, 166400, 0)]) # chunk too long for the LDS tile: falls back
+def test_fused_epilogue_equals_two_kernels(dev, monkeypatch, n_fft, hop, m, c, b, length, chunk):
+    """min-max / log inside the fused kernel (LDS mel tile, clip-level (min, max) exchange between workgroups, one
+    launch) against the two-kernel form of the same step: identical bits for every flag combination, with SpecAugment
+    bands, with the normalize flag, when workgroups loop over several chunks; the bounded waits all completed."""
+    rng = np.random.default_rng(n_fft + b)
+    wav = (rng.standard_normal((b, c, length)) * rng.uniform(0.02, 0.5, (b, 1, 1))).astype(np.float32)
+    x = torch.from_numpy(wav).to(dev)
+    n_t, n_f = 1 + length // hop, n_fft // 2 + 1
+    tb = np.stack([np.stack(R.mask_draw(rng, n_t, 12, 3), 1) for _ in range(b)])
+    fb = np.stack([np.stack(R.mask_draw(rng, n_f, 24, 2), 1) for _ in range(b)])
+    if chunk:
+        monkeypatch.setenv("IRIS_CHUNK_FRAMES", str(chunk))
+    fused = FE().FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
+    two = FE().FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
+    if chunk:
+        monkeypatch.delenv("IRIS_CHUNK_FRAMES")
+    two.set_epilogue("two_kernels")
+    for kw in ({}, {"t_bands": tb, "f_bands": fb}):
+        for flags in ({}, {"minmax": False}, {"log": False}, {"normalize": True}):
+            a = fused.wav_to_logmel(x, **kw, **flags)
+            bb = two.wav_to_logmel(x, **kw, **flags)
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, bb), (kw.keys(), flags)
+    for _ in range(5):  # back to back: a new epoch every launch, slots of the previous launch never match
+        a = fused.wav_to_logmel(x)
+    assert torch.equal(a, two.wav_to_logmel(x))
+    assert fused.status() == 0
+    ref = R.wav_to_logmel(wav[:2], n_fft, hop, m, 16000)
+    assert np.abs(np.exp(a[:2].cpu().numpy()) - np.exp(ref)).max() <= 5e-6
