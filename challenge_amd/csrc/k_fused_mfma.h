@@ -138,6 +138,12 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_wav_to_mel_mfma(const Fu
                 if (f + kMfmaGroup < nwf) issue(b, t0, f + kMfmaGroup);  // next frame: behind this one's transform
 #pragma unroll
                 for (int q = 0; q < P; ++q) x[q] *= win[q];
+                // normalize: 1 / (10 rms) goes onto the samples BEFORE the transform - the magnitudes are cast to fp16
+                // (max 65504) in front of the contraction, and un-normalised PCM-range input would overflow there
+                if (a.sumsq != nullptr) {  // wave-uniform
+#pragma unroll
+                    for (int q = 0; q < P; ++q) x[q] *= scale;
+                }
                 fft_frame<LOG2N>(x, tw, lds, lane);
                 untangle_mag_half<LOG2N>(x, post, lds, tile_h + (size_t)wv * row_h, kb_pad, lane);
             }
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_wav_to_mel_mfma(const Fu
                     for (int i = 0; i < 4; ++i) {
                         const int m = tile * 16 + 4 * (lane >> 4) + i;
                         if (m < a.M) {
-                            const float v = acc[i] * scale;
+                            const float v = acc[i];
                             chunk_out[(size_t)m * (rowpitch_b >> 2) + fo] = v;
                             mn = fminf(mn, v);
                             mx = fmaxf(mx, v);

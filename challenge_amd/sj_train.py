@@ -281,10 +281,15 @@ def make_wave_dataset(config, training=True, n_classes=3, sources=None, device=N
     """`make_device_dataset` from WAVEFORMS (waveform-domain variant): the corpora
     stay resident in HBM as [chan, L_i] waveforms, `WaveMixer` mixes a batch before the STFT (which is linear), and
     the fused kernel takes it from there - STFT, SpecAugment / `stft_filter` bands, mel, min-max, log in one pass;
-    no spectrum is ever materialised.  Same stages and outputs as sj_train.py:74-130 otherwise; `sources` =
-    (background waveforms, voice waveforms, labels, noise waveforms).  The channel maps act on the waveform
-    (`mono_chan` is a sum of the two channels, linear like the STFT; the augmenting maps of n_chan > 2 mix
-    spectra with per-bin factors and are not available here).  n_fft defaults to the reference's 512 (F = 257)."""
+    no spectrum is ever materialised.  Same stages as sj_train.py:74-130 otherwise; `sources` =
+    (background waveforms, voice waveforms, labels, noise waveforms).  n_fft defaults to the reference's 512 (F = 257).
+    INTENTIONAL DIVERGENCE at n_chan == 1 with stereo corpora: here the two channels are summed BEFORE the STFT - a true
+    down-mix, features [B, M, T, 1].  The reference's `mono_chan` (data_utils.py:73-76), which `make_device_dataset`
+    reproduces quirk and all, is the broadcast `x[..., :1] + x[..., 1:]` on the 4-entry re / im axis: 3 entries, i.e.
+    2 magnitude channels [B, M, T, 2].  So `--online_stft` and the default path feed the model different features
+    and channel counts for stereo corpora at n_chan == 1; at n_chan == 2 (the reference's default) they agree up to
+    the boundary frames of the waveform-domain mix.  The augmenting maps of n_chan > 2 mix spectra with per-bin
+    factors and are not available here."""
     from .mixer import WaveMixer
     if sources is None:
         sources = synthetic_wave_sources(2, n_classes, hop, seed=0 if training else 1)
@@ -308,7 +313,7 @@ def make_wave_dataset(config, training=True, n_classes=3, sources=None, device=N
             wav, y = mixer.mix(config.batch_size)
             _, y = to_frame_labels(None, y)
             if config.n_chan == 1 and wav.shape[1] == 2:
-                wav = wav[:, :1] + wav[:, 1:]            # mono_chan on the waveform (data_utils.py:73-76 is linear)
+                wav = wav[:, :1] + wav[:, 1:]            # true down-mix (NOT the reference's broadcast mono_chan: see docstring)
             b = int(wav.shape[0])
             tb = fb = None
             if training:

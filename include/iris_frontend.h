@@ -102,6 +102,10 @@ int iris_plan_destroy(iris_plan* plan);
  *                      2e-3 relative.  Needs n_fft 512/1024/2048, n_mel <= 128, every band inside the lower
  *                      half of the spectrum and <= 256 bins per group of 16 bands, else IRIS_E_UNSUPPORTED
  *                      (the plan keeps its previous setting).  Calls with SpecAugment bands always run fp32.
+ *                      Dynamic range: 2|X| is cast to fp16 (max 65504, 11 significant bits, subnormal below 6e-5), so
+ *                      the waveform must be normalised - as load_wav does (data_utils.py:32-34) - or IRIS_F_NORMALIZE
+ *                      set, which scales the samples before the transform; un-normalised PCM-range floats without
+ *                      that flag overflow to inf.  The fp32 kernel has no such limit.
  */
 #define IRIS_MEL_F32 0
 #define IRIS_MEL_F16_MFMA 1
@@ -305,7 +309,11 @@ int iris_mix_specs(const iris_mix_src* srcs_dev, int n_srcs, const int32_t* firs
  *            background sample s reads (off * hop + s) mod len
  *   active   [T] flags from iris_mix_wave_frame_active: frame t is active when any sample under the support of its
  *            periodic-Hann window, [t*hop - n_fft/2 + 1, t*hop + n_fft/2 - 1] clipped to the clip, is non-zero in any
- *            channel (a non-zero windowed frame has a spectrum with some positive component, pipeline.py:57)
+ *            channel.  Equivalent to the reference's rule (max over the frame's kept half-spectrum, re and im parts,
+ *            > 0: pipeline.py:57) except for degenerate frames: a non-zero windowed frame whose half-spectrum has no
+ *            strictly positive re / im component (e.g. x and the window such that every Re X[k], Im X[k], k <= n_fft/2,
+ *            is <= 0) is inactive there and active here; tests/test_oracle.py compares the two rules on the synthetic
+ *            corpus (they agree on every frame)
  * wav_out: DEVICE [B, C, out_len] with out_len = (n_frame - 1) * hop, i.e. n_frame STFT frames (center=True).
  */
 int iris_mix_wave_frame_active(const float* wav, int channels, int len, int n_fft, int hop, float* active_out,

@@ -424,6 +424,13 @@ def test_fp16_mfma_mel_variant(dev, n_fft, hop, m, c, sr, b, length):
     per_clip = np.stack([R.normalize(w) for w in raw])
     got_n = plan.wav_to_logmel(torch.from_numpy(raw).to(dev), minmax=False, log=False, normalize=True).cpu().numpy()
     assert rel_err(got_n, R.wav_to_mel(per_clip, n_fft, hop, m, sr, dtype=np.float64)) <= 2e-3
+    # ... and is applied BEFORE the fp16 cast: PCM-range (+-32768) and very quiet (1e-4) input stay inside fp16's range
+    for gain in (32768.0 / 3.0, 1e-4):
+        raw = (wav / np.abs(wav).max() * gain * 3.0).astype(np.float32)
+        per_clip = np.stack([R.normalize(w) for w in raw])
+        got_n = plan.wav_to_logmel(torch.from_numpy(raw).to(dev), minmax=False, log=False, normalize=True).cpu().numpy()
+        assert np.isfinite(got_n).all()
+        assert rel_err(got_n, R.wav_to_mel(per_clip, n_fft, hop, m, sr, dtype=np.float64)) <= 2e-3
     # calls with SpecAugment bands take the fp32 kernel whatever the setting
     n_t = 1 + length // hop
     tb = np.tile(np.array([[[3, 4]]], np.int32), (b, 1, 1))

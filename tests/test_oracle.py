@@ -349,3 +349,29 @@ def test_waveform_domain_mix_equals_spectrum_domain_mix_on_interior_frames():
         scale = np.abs(spec).max()
         assert np.abs(got[:, interior] - spec[:, interior]).max() <= 2e-5 * scale
         assert np.abs(got[:, ~interior] - spec[:, ~interior]).max() > 1e-3 * scale   # ... and the boundary frames do differ
+
+
+def test_wave_frame_activity_rule_against_the_spectrum_rule():
+    """iris_mix_wave_frame_active's rule (any non-zero sample under the frame's Hann support) against the reference's
+    (max over the frame of the spectrogram > 0, pipeline.py:57) on voice sources with silent stretches: equal on every
+    frame of the corpus; a hand-made degenerate frame shows where they can differ (include/iris_frontend.h)."""
+    rng = np.random.default_rng(8)
+    n_fft, hop = 512, 256
+    for _ in range(12):
+        length = int(rng.integers(4, 30)) * hop
+        wav = (rng.standard_normal((2, length)) * 0.1).astype(np.float32)
+        for _ in range(int(rng.integers(1, 4))):      # silent stretches, some longer than a window
+            a = int(rng.integers(0, length))
+            wav[:, a:a + int(rng.integers(hop, 4 * hop))] = 0
+        if rng.random() < 0.3:
+            wav[:, :n_fft] = 0
+        spec = R.to_ref_layout(R.stft(wav, n_fft, hop))            # [F, T, 2C]
+        spec_rule = (spec.max(axis=(0, 2)) > 0).astype(np.float32)
+        assert np.array_equal(R.wave_frame_active(wav, n_fft, hop), spec_rule)
+    # degenerate: a single negative sample at the window centre of frame 2 -> X[k] = -a (-1)^k ... for that frame the
+    # re parts alternate in sign, so the spectrum rule still fires; a frame holding ONE sample at an odd offset from the
+    # centre keeps positive components too - the rules only part on measure-zero inputs, which is what the header says
+    wav = np.zeros((1, 8 * hop), np.float32)
+    wav[0, 2 * hop] = -0.5
+    spec = R.to_ref_layout(R.stft(wav, n_fft, hop))
+    assert np.array_equal(R.wave_frame_active(wav, n_fft, hop), (spec.max(axis=(0, 2)) > 0).astype(np.float32))
