@@ -225,30 +225,39 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
     # shape: whole batches synthesised on the device (iris_mix_specs + mel kernel with bands)
     dbatch = 64
     dcfg = S.ARGS().get(['--v', '9', '--n_mels', '80', '--n_frame', '512', '--n_chan', '2', '--batch_size', str(dbatch)])
-    ds = iter(S.make_device_dataset(dcfg, True, sources=S.synthetic_sources(2, 3, n_bg=16, n_voice=64, n_noise=32, seed=rank),
-                                    device=dev, seed=rank))
+    ssrc = S.synthetic_sources(2, 3, n_bg=16, n_voice=64, n_noise=32, seed=rank)
+    ds = iter(S.make_device_dataset(dcfg, True, sources=ssrc, device=dev, seed=rank, device_draw=True))
     t_data = timed(lambda: next(ds), steps)
     del ds
+    ds = iter(S.make_device_dataset(dcfg, True, sources=ssrc, device=dev, seed=rank))
+    t_data_host = timed(lambda: next(ds), steps)
+    del ds, ssrc
     # the same from WAVEFORM corpora: mixed before the STFT (iris_mix_waves), then the fused kernel with bands
-    wds = iter(S.make_wave_dataset(dcfg, True, sources=S.synthetic_wave_sources(2, 3, HOP, n_bg=16, n_voice=64, n_noise=32,
-                                                                              seed=rank), device=dev, seed=rank))
+    wsrc = S.synthetic_wave_sources(2, 3, HOP, n_bg=16, n_voice=64, n_noise=32, seed=rank)
+    wds = iter(S.make_wave_dataset(dcfg, True, sources=wsrc, device=dev, seed=rank, device_draw=True))
     t_wdata = timed(lambda: next(wds), steps)
     del wds
+    wds = iter(S.make_wave_dataset(dcfg, True, sources=wsrc, device=dev, seed=rank))
+    t_wdata_host = timed(lambda: next(wds), steps)
+    del wds, wsrc
     c3 = {"audio_s_per_s": round(world * audio_s / t_fwd, 1), "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch,
           "what": "training-mode model object in eval(): BatchNorm kernels, separate bias / ReLU kernels (the literal module)",
           "inference_engine": {
-              "what": "same function for inference: BatchNorm folded into the convolutions, conv + bias + ReLU as one MIOpen "
-                      "fusion call (torch.miopen_convolution_relu), fp32; outputs equal to 1e-4 (GPU test)",
+              "what": "same function for inference (sj_train.InferenceEngine): BatchNorm folded into the convolutions, MIOpen "
+                      "convolution + ONE HIP epilogue pass (bias + ReLU, + the block's 2x2 max-pool), fp32; outputs equal to "
+                      "1e-4 (GPU test)",
               "eager": {"audio_s_per_s": round(world * audio_s / t_fwd_folded, 1), "ms_per_step": round(1e3 * t_fwd_folded, 3)},
               "hipgraph_replay": None if t_fwd_graph is None else {
                   "audio_s_per_s": round(world * audio_s / t_fwd_graph, 1), "ms_per_step": round(1e3 * t_fwd_graph, 3)},
               "fused_conv_bias_relu": infer.fused_convs}}
     best_fwd = min(t for t in (t_fwd, t_fwd_folded, t_fwd_graph) if t is not None)
     return {
-        "device_dataset": {"ms_per_batch": round(1e3 * t_data, 3), "batch_per_gpu": dbatch,
+        "device_dataset": {"ms_per_batch": round(1e3 * t_data, 3), "ms_per_batch_host_draws": round(1e3 * t_data_host, 3),
+                           "draws": "on the device (iris_mix_draw + iris_augment_draw)", "batch_per_gpu": dbatch,
                            "audio_s_per_s": round(world * dbatch * 512 * HOP / SR / t_data, 1),
                            "shape": "spectra [257, T_i, 4] resident in HBM -> log-mel [64, 80, 512, 2] + labels"},
-        "wave_dataset": {"ms_per_batch": round(1e3 * t_wdata, 3), "batch_per_gpu": dbatch,
+        "wave_dataset": {"ms_per_batch": round(1e3 * t_wdata, 3), "ms_per_batch_host_draws": round(1e3 * t_wdata_host, 3),
+                         "draws": "on the device (iris_mix_draw + iris_augment_draw)", "batch_per_gpu": dbatch,
                          "audio_s_per_s": round(world * dbatch * 511 * HOP / SR / t_wdata, 1),
                          "shape": "waveforms [2, L_i] resident in HBM -> mixed [64, 2, 130816] -> log-mel [64, 80, 512, 2] + labels"},
         "c3_frontend_specaug_crnn_fwd": c3,

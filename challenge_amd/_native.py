@@ -47,6 +47,8 @@ SIGNATURES = {
     "iris_mix_specs": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "iris_mix_wave_frame_active": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "iris_mix_waves": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "iris_mix_draw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, C.c_uint64, _vp, _vp, _vp, _vp]),
+    "iris_augment_draw": (_i, [_i, _i, _i, _i, _i, _i, _i, C.c_uint64, _vp, _vp, _vp, _vp]),
     "iris_bias_relu": (_i, [_vp, _vp, _sz, _i, _vp]),
     "iris_bias_relu_maxpool": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "iris_plan_kernel_name": (_i, [_vp, _i, C.c_char_p, _i]),

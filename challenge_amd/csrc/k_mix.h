@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_mix_labels(const iris_mix_src* srcs, co
     __syncthreads();
     for (int si = first[b]; si < first[b + 1]; ++si) {
         const iris_mix_src s = srcs[si];
-        if (s.kind != 1) continue;  // uniform
+        if (s.kind != 1) continue;  // uniform (background, noise, or an unused slot of a fixed-stride table: kind -1)
         const float* lv = label_vecs + (size_t)s.label_row * n_classes;
         auto act = [&](int t) {  // frame t of the output lies in the padding, or in a silent / active frame
             const int fr = mix_frame(s, t);
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void k_mix_sum(const iris_mix_src* srcs, const
     vecT acc = vecT(0.f);
     for (int si = first[b]; si < first[b + 1]; ++si) {
         const iris_mix_src s = srcs[si];  // uniform
+        if (s.kind < 0) continue;  // unused slot of a fixed-stride table (iris_mix_draw)
         if (s.kind == 0) {
             const int fr = (s.off + t) % s.T;
             acc = *reinterpret_cast<const vecT*>(s.src + ((size_t)f * s.T + fr) * C2);
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void k_mix_wave_sum(const iris_mix_src* srcs, 
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int si = first[b]; si < first[b + 1]; ++si) {
         const iris_mix_src r = srcs[si];  // uniform
+        if (r.kind < 0) continue;  // unused slot of a fixed-stride table (iris_mix_draw)
         const int len = r.reserved;
         const float* row = r.src + (size_t)c * len;
         const bool row16 = (reinterpret_cast<uintptr_t>(row) & 15) == 0;  // (uniform) this channel's row starts on 16 bytes

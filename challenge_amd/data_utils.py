@@ -119,6 +119,41 @@ def augment_draw_batch(batch: int, n_time: int, n_freq: int, rng: Optional[np.ra
     return _tr.mask_draw_batch(batch, n_time, 24, 6, rng), _tr.mask_draw_batch(batch, n_freq, 16, 1, rng)
 
 
+class DeviceAugmentDraw:
+    """The draws of `augment` (6 time masks up to 23 frames, 1 frequency mask up to 15 bins per sample, data_utils.py:58-61)
+    made ON THE DEVICE by one small HIP kernel (`iris_augment_draw`: Philox keyed by `seed`, call counter in device
+    memory): no host draw, no upload, replayable from a hipGraph.  Optional fixed `stft_filter` band (bins 1..k) appended
+    to the frequency bands.  Returns long-lived int32 device tensors (t_bands [B, 6, 2], f_bands [B, 1 (+1), 2])."""
+
+    def __init__(self, device, seed: int = 0, filter_bins: int = 0):
+        from . import _native as N
+        self._N, self.device = N, torch.device(device)
+        N.lib()
+        self.seed, self.filter_bins = int(seed) & 0xFFFFFFFFFFFFFFFF, int(filter_bins)
+        self.state = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._bufs = {}
+
+    def __call__(self, batch: int, n_time: int, n_freq: int):
+        import ctypes as C
+        key = (batch, n_time, n_freq)
+        if key not in self._bufs:
+            nf = 2 if self.filter_bins else 1
+            tb = torch.zeros((batch, 6, 2), dtype=torch.int32, device=self.device)
+            fb = torch.zeros((batch, nf, 2), dtype=torch.int32, device=self.device)
+            if self.filter_bins:
+                fb[:, 1, 0], fb[:, 1, 1] = 1, self.filter_bins
+            self._bufs[key] = (tb, fb, torch.empty((batch, 1, 2), dtype=torch.int32, device=self.device))
+        tb, fb, f1 = self._bufs[key]
+        with torch.cuda.device(self.device):
+            rc = self._N.lib().iris_augment_draw(batch, n_time, 6, 24, n_freq, 1, 16, self.seed, self.state.data_ptr(),
+                                                 tb.data_ptr(), (f1 if self.filter_bins else fb).data_ptr(),
+                                                 C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        self._N.check(rc, "iris_augment_draw")
+        if self.filter_bins:
+            fb[:, :1].copy_(f1)
+        return tb, fb
+
+
 def to_frame_labels(x, y):
     """[..., n_voices, n_frames, n_classes] -> [..., n_frames, n_classes] (data_utils.py:64-70)."""
     return x, torch.sum(y, dim=-3)

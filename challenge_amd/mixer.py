@@ -27,7 +27,12 @@ MIX_SRC = np.dtype([("src", "<u8"), ("active", "<u8"), ("T", "<i4"), ("pad", "<i
                     ("gain", "<f4"), ("kind", "<i4"), ("slot", "<i4"), ("label_row", "<i4"), ("reserved", "<i4")])
 assert MIX_SRC.itemsize == 48
 
-KIND_BACKGROUND, KIND_VOICE, KIND_NOISE = 0, 1, 2
+KIND_BACKGROUND, KIND_VOICE, KIND_NOISE, KIND_UNUSED = 0, 1, 2, -1
+
+
+class _Corpus(C.Structure):
+    """iris_mix_corpus (include/iris_frontend.h): device arrays describing one corpus."""
+    _fields_ = [("src", C.c_void_p), ("active", C.c_void_p), ("T", C.c_void_p), ("len", C.c_void_p), ("n", C.c_int32)]
 
 
 class _Stream:
@@ -248,13 +253,17 @@ class DeviceMixer:
         """One batch of (complex spectrogram [B, F, n_frame, 2C], labels [B, max_voices, n_frame,
         n_classes]) - `merge_complex_specs` (pipeline.py:6-110) for every sample, two launches.
         draws: a BatchDraw or a list of per-sample dicts (default: a fresh `draw_arrays(batch)`)."""
-        draws = self.draw_arrays(batch) if draws is None else draws
-        batch = len(draws)
-        table, first = self.table(draws)
-        n_srcs = int(table.shape[0])
         dev = self.device
-        table_d = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(dev, non_blocking=True)
-        first_d = torch.from_numpy(first).to(dev, non_blocking=True)
+        on_device = draws is None and getattr(self, "_dd", None) is not None
+        if on_device:
+            table_d, first_d, n_srcs = self._draw_on_device(batch)
+        else:
+            draws = self.draw_arrays(batch) if draws is None else draws
+            batch = len(draws)
+            table, first = self.table(draws)
+            n_srcs = int(table.shape[0])
+            table_d = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(dev, non_blocking=True)
+            first_d = torch.from_numpy(first).to(dev, non_blocking=True)
         spec = torch.empty((batch, self.n_bins, self.n_frame, self.chan2), device=dev, dtype=torch.float32)
         label = torch.empty((batch, self.max_voices, self.n_frame, self.n_classes), device=dev, dtype=torch.float32)
         ws_floats = int(N.lib().iris_mix_workspace(n_srcs, self.n_frame))
@@ -266,9 +275,81 @@ class DeviceMixer:
                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         N.check(rc, "iris_mix_specs")
         # the table, ranges and workspace must outlive the kernels: tie them to the stream
-        for t in (table_d, first_d, ws):
+        for t in ((ws,) if on_device else (table_d, first_d, ws)):
             t.record_stream(torch.cuda.current_stream(dev))
         return spec, label
+
+    # -- random half on the device ----------------------------------------------------
+    def enable_device_draw(self, seed: int = 0) -> None:
+        """Draw every later `mix(batch)` ON THE DEVICE (`iris_mix_draw`): no NumPy draws, no table upload - the source
+        table is written by one small kernel from a Philox generator keyed by `seed`, whose call counter and stream
+        positions live in device memory (so a captured batch replays with fresh draws).  Same distributions as
+        `draw_arrays`; `last_table()` returns the records of the latest batch for replay through the oracle."""
+        dev = self.device
+        i64 = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).to(dev)  # noqa: E731
+        i32 = lambda a: torch.from_numpy(np.asarray(a).astype(np.int32)).to(dev)  # noqa: E731
+        self._dd = {"seed": int(seed) & 0xFFFFFFFFFFFFFFFF, "state": torch.zeros(4, dtype=torch.int64, device=dev),
+                    "keep": [], "bufs": {}}
+
+        def corpus(ptr, act, T, L):
+            t = {"src": i64(ptr.astype(np.int64)), "act": None if act is None else i64(act.astype(np.int64)), "T": i32(T),
+                 "len": None if L is None else i32(L)}
+            self._dd["keep"].append(t)
+            return _Corpus(t["src"].data_ptr(), 0 if t["act"] is None else t["act"].data_ptr(), t["T"].data_ptr(),
+                           0 if t["len"] is None else t["len"].data_ptr(), int(len(ptr)))
+        wave = getattr(self, "_bg_L", None) is not None
+        self._dd["bg"] = corpus(self._bg_ptr, None, self._bg_T, self._bg_L if wave else None)
+        self._dd["voice"] = corpus(self._v_ptr, self._v_act, self._v_T, self._v_L if wave else None)
+        self._dd["noise"] = corpus(self._n_ptr, None, self._n_T, self._n_L if wave else None) if self.noises is not None else None
+
+    def _draw_on_device(self, batch: int):
+        """(table_d [batch * stride, 48 B], first_d [batch + 1], n_srcs) written by iris_mix_draw on the current stream."""
+        dd, dev = self._dd, self.device
+        nn = self.max_noises if self.noises is not None else 0
+        stride = 1 + self.max_voices + nn
+        key = (batch, stride)
+        if key not in dd["bufs"]:  # long-lived: a captured graph keeps their addresses
+            dd["bufs"][key] = (torch.empty(batch * stride * MIX_SRC.itemsize, dtype=torch.uint8, device=dev),
+                               torch.empty(batch + 1, dtype=torch.int32, device=dev))
+        table_d, first_d = dd["bufs"][key]
+        with torch.cuda.device(dev):
+            rc = N.lib().iris_mix_draw(C.byref(dd["bg"]), C.byref(dd["voice"]),
+                                       C.byref(dd["noise"]) if dd["noise"] is not None else None, batch, self.n_frame,
+                                       self.max_voices, nn, float(self.min_ratio), float(self.min_noise_ratio), float(self.snr),
+                                       dd["seed"], dd["state"].data_ptr(), table_d.data_ptr(), first_d.data_ptr(),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        N.check(rc, "iris_mix_draw")
+        return table_d, first_d, batch * stride
+
+    def last_table(self, batch: int) -> np.ndarray:
+        """The device-drawn records of the latest `mix(batch)` as a host structured array [batch, stride] (synchronises)."""
+        nn = self.max_noises if self.noises is not None else 0
+        stride = 1 + self.max_voices + nn
+        raw = self._dd["bufs"][(batch, stride)][0].cpu().numpy()
+        return raw.view(MIX_SRC).reshape(batch, stride)
+
+    def table_to_draws(self, table: np.ndarray) -> List[dict]:
+        """Per-sample draw dicts (layout of `pipeline.merge_draw`) recovered from device-drawn records: what the oracle's
+        apply takes.  Sources are identified by their device address."""
+        V = self.max_voices
+        nn = table.shape[1] - 1 - V
+        bg_of = {int(p): i for i, p in enumerate(self._bg_ptr)}
+        v_of = {int(p): i for i, p in enumerate(self._v_ptr)}
+        n_of = {int(p): i for i, p in enumerate(self._n_ptr)} if self._n_ptr is not None else {}
+        out = []
+        for row in table:
+            voices, noises = row[1:1 + V], row[1 + V:]
+            nv, n_n = int((voices["kind"] == KIND_VOICE).sum()), int((noises["kind"] == KIND_NOISE).sum())
+            assert np.all(voices["kind"][:nv] == KIND_VOICE) and np.all(voices["kind"][nv:] == KIND_UNUSED)
+            assert np.all(noises["kind"][:n_n] == KIND_NOISE) and np.all(noises["kind"][n_n:] == KIND_UNUSED)
+            v_idx = [v_of[int(p)] for p in voices["src"]]
+            n_idx = [n_of[int(p)] for p in noises["src"]]
+            out.append({"bg": bg_of[int(row[0]["src"])], "bg_offset": int(row[0]["off"]), "voices": v_idx,
+                        "v_len": int(max(self._v_T[v_idx])), "n_voices": nv,
+                        "v_gain": [float(g) for g in voices["gain"][:nv]], "v_offset": [int(o) for o in voices["off"][:nv]],
+                        "noises": n_idx if nn else None, "n_len": int(max(self._n_T[n_idx])) if nn else 0, "n_noises": n_n,
+                        "n_gain": [float(g) for g in noises["gain"][:n_n]], "n_offset": [int(o) for o in noises["off"][:n_n]]})
+        return out
 
     def __iter__(self):
         raise TypeError("DeviceMixer yields whole batches: call mix(batch)")
@@ -349,13 +430,17 @@ class WaveMixer(DeviceMixer):
 
     def mix(self, batch: int, draws=None):
         """One batch of (waveforms [B, C, (n_frame - 1) * hop], labels [B, max_voices, n_frame, n_classes])."""
-        draws = self.draw_arrays(batch) if draws is None else draws
-        batch = len(draws)
-        table, first = self.table(draws)
-        n_srcs = int(table.shape[0])
         dev = self.device
-        table_d = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(dev, non_blocking=True)
-        first_d = torch.from_numpy(first).to(dev, non_blocking=True)
+        on_device = draws is None and getattr(self, "_dd", None) is not None
+        if on_device:
+            table_d, first_d, n_srcs = self._draw_on_device(batch)
+        else:
+            draws = self.draw_arrays(batch) if draws is None else draws
+            batch = len(draws)
+            table, first = self.table(draws)
+            n_srcs = int(table.shape[0])
+            table_d = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(dev, non_blocking=True)
+            first_d = torch.from_numpy(first).to(dev, non_blocking=True)
         wav = torch.empty((batch, self.channels, (self.n_frame - 1) * self.hop), device=dev, dtype=torch.float32)
         label = torch.empty((batch, self.max_voices, self.n_frame, self.n_classes), device=dev, dtype=torch.float32)
         ws_floats = int(N.lib().iris_mix_workspace(n_srcs, self.n_frame))
@@ -366,6 +451,6 @@ class WaveMixer(DeviceMixer):
                                         self.max_voices, self.n_classes, ws.data_ptr(), ws_floats,
                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         N.check(rc, "iris_mix_waves")
-        for t in (table_d, first_d, ws):
+        for t in ((ws,) if on_device else (table_d, first_d, ws)):
             t.record_stream(torch.cuda.current_stream(dev))
         return wav, label

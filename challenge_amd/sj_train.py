@@ -215,13 +215,16 @@ def make_dataset(config, training=True, n_classes=3, sources=None):
     return _label_tail(pipeline, config)
 
 
-def make_device_dataset(config, training=True, n_classes=3, sources=None, device=None, seed=None):
+def make_device_dataset(config, training=True, n_classes=3, sources=None, device=None, seed=None, device_draw=False):
     """MI355X-native `make_dataset`: same stages, same outputs (sj_train.py:74-130), but a whole
     batch at a time on the device.  The corpora stay resident in HBM; `DeviceMixer` synthesises the
     batch in two launches (merge_complex_specs, pipeline.py:6-110); SpecAugment and `stft_filter`
     reach the mel kernel as band descriptors instead of being multiplied into the 135 MB complex
     batch (they zero time / frequency ranges, which commutes with the per-bin channel mixes and with
-    the magnitude).  Yields (x [B, n_mels, n_frame, C], y) forever, like the repeated reference graph."""
+    the magnitude).  Yields (x [B, n_mels, n_frame, C], y) forever, like the repeated reference graph.
+    device_draw=True: the random half of a batch (sources, offsets, gains, SpecAugment bands) is drawn by two small HIP
+    kernels on the device (`iris_mix_draw`, `iris_augment_draw`) instead of NumPy on the host - no table upload, the
+    host only enqueues launches."""
     from .mixer import DeviceMixer
     backgrounds, voices, labels, noises = _load_sources(config, training, n_classes, sources)
     if config.model_type == 'se' and config.v == 9:
@@ -230,6 +233,11 @@ def make_device_dataset(config, training=True, n_classes=3, sources=None, device
                         max_noises=config.max_noises, n_classes=n_classes, device=device, snr=config.snr,
                         min_ratio=1, seed=seed)
     rng = np.random.default_rng(None if seed is None else seed + 1)
+    filter_bins = int(round(200 / (16000 / 256))) if 'filter' in config.name else 0
+    band_draw = None
+    if device_draw:
+        mixer.enable_device_draw(0 if seed is None else seed)
+        band_draw = _du.DeviceAugmentDraw(mixer.device, (0 if seed is None else seed) + 1, filter_bins) if training else None
     to_mel = complex_to_mel(config.n_mels, mixer.n_bins)
     chan_map = None
     if config.n_chan == 1:
@@ -238,16 +246,17 @@ def make_device_dataset(config, training=True, n_classes=3, sources=None, device
         chan_map = stereo_mono
     elif config.n_chan > 3:
         chan_map = random_merge_aug(config.n_chan)
-    filter_bins = int(round(200 / (16000 / 256))) if 'filter' in config.name else 0
 
     def gen():
         while True:
             x, y = to_frame_labels(*mixer.mix(config.batch_size))
             b = int(x.shape[0])
             tb = fb = None
-            if training:  # `augment` (data_utils.py:58-61): 6 time masks, 1 frequency mask per sample
+            if band_draw is not None:
+                tb, fb = band_draw(b, config.n_frame, mixer.n_bins)  # filter band included
+            elif training:  # `augment` (data_utils.py:58-61): 6 time masks, 1 frequency mask per sample
                 tb, fb = _du.augment_draw_batch(b, config.n_frame, mixer.n_bins, rng)
-            if filter_bins:  # stft_filter (data_utils.py:126-136): bins 1..k
+            if filter_bins and band_draw is None:  # stft_filter (data_utils.py:126-136): bins 1..k
                 flt = np.tile(np.array([[[1, filter_bins]]], np.int32), (b, 1, 1))
                 fb = flt if fb is None else np.concatenate([fb, flt], axis=1)
             if chan_map is not None:
@@ -277,7 +286,7 @@ def synthetic_wave_sources(n_chan: int = 2, n_classes: int = 3, hop: int = 256, 
 
 
 def make_wave_dataset(config, training=True, n_classes=3, sources=None, device=None, seed=None, n_fft=512, hop=256,
-                      sample_rate=16000):
+                      sample_rate=16000, device_draw=False):
     """`make_device_dataset` from WAVEFORMS (waveform-domain variant): the corpora
     stay resident in HBM as [chan, L_i] waveforms, `WaveMixer` mixes a batch before the STFT (which is linear), and
     the fused kernel takes it from there - STFT, SpecAugment / `stft_filter` bands, mel, min-max, log in one pass;
@@ -289,7 +298,8 @@ def make_wave_dataset(config, training=True, n_classes=3, sources=None, device=N
     2 magnitude channels [B, M, T, 2].  So `--online_stft` and the default path feed the model different features
     and channel counts for stereo corpora at n_chan == 1; at n_chan == 2 (the reference's default) they agree up to
     the boundary frames of the waveform-domain mix.  The augmenting maps of n_chan > 2 mix spectra with per-bin
-    factors and are not available here."""
+    factors and are not available here.  device_draw=True: sources / offsets / gains / SpecAugment bands are drawn on
+    the device (`iris_mix_draw`, `iris_augment_draw`), as in `make_device_dataset`."""
     from .mixer import WaveMixer
     if sources is None:
         sources = synthetic_wave_sources(2, n_classes, hop, seed=0 if training else 1)
@@ -307,6 +317,10 @@ def make_wave_dataset(config, training=True, n_classes=3, sources=None, device=N
     plan = _fe.FrontendPlan(n_fft, hop, config.n_mels, sample_rate, config.n_chan, config.batch_size, length, mixer.device)
     filter_bins = int(round(200 / (16000 / 256))) if 'filter' in config.name else 0
     do_minmax = 'nominmax' not in config.name
+    band_draw = None
+    if device_draw:
+        mixer.enable_device_draw(0 if seed is None else seed)
+        band_draw = _du.DeviceAugmentDraw(mixer.device, (0 if seed is None else seed) + 1, filter_bins) if training else None
 
     def gen():
         while True:
@@ -316,9 +330,11 @@ def make_wave_dataset(config, training=True, n_classes=3, sources=None, device=N
                 wav = wav[:, :1] + wav[:, 1:]            # true down-mix (NOT the reference's broadcast mono_chan: see docstring)
             b = int(wav.shape[0])
             tb = fb = None
-            if training:
+            if band_draw is not None:
+                tb, fb = band_draw(b, config.n_frame, plan.n_bins)
+            elif training:
                 tb, fb = _du.augment_draw_batch(b, config.n_frame, plan.n_bins, rng)
-            if filter_bins:
+            if filter_bins and band_draw is None:
                 flt = np.tile(np.array([[[1, filter_bins]]], np.int32), (b, 1, 1))
                 fb = flt if fb is None else np.concatenate([fb, flt], axis=1)
             yield plan.wav_to_logmel(wav.contiguous(), t_bands=tb, f_bands=fb, minmax=do_minmax, log=True), y

@@ -273,7 +273,7 @@ int iris_bias_relu_maxpool(const float* x, const float* bias, float* y, int batc
  *          they depend on the source only, so they are computed once per corpus, not per use)
  *   T      frames in src;  pad: zero frames virtually added on both sides (>= 0);
  *   off    crop offset in the padded (voice, noise) or tiled (background) source;
- *   gain   linear gain (ignored for the background);  kind 0 background, 1 voice, 2 noise;
+ *   gain   linear gain (ignored for the background);  kind 0 background, 1 voice, 2 noise, -1 unused slot (skipped);
  *   slot   row of the labels output (kind 1);  label_row: row of label_vecs (kind 1).
  * label_vecs: DEVICE [n_label_rows, n_classes] fp32 (one-hot rows in the reference).
  * spec_out: DEVICE [B, F, n_frame, C2];  labels_out: DEVICE [B, V, n_frame, n_classes].
@@ -322,6 +322,41 @@ int iris_mix_waves(const iris_mix_src* srcs_dev, int n_srcs, const int32_t* firs
                    const float* label_vecs_dev, float* wav_out, float* labels_out, int batch,
                    int channels, int hop, int n_frame, int max_voices, int n_classes,
                    float* workspace, size_t workspace_floats, void* stream);
+
+/*
+ * The random half of a batch drawn ON THE DEVICE (no host round trip, replayable from a hipGraph): which sources
+ * merge_complex_specs mixes and with which offsets / gains (pipeline.py:29-106; source picking of the dataset graph,
+ * :147-174), written as the source table iris_mix_specs / iris_mix_waves consume, and the SpecAugment bands of
+ * `augment` (data_utils.py:58-61 -> transforms.py:25-26).  Generator: Philox4x32-10 keyed by `seed`, counter = (call
+ * counter, sample, column, purpose); distributions as in the reference:
+ *   background: the next source of a shuffled, repeated stream; crop offset ~ U{0 .. reps*T - n_frame}
+ *   voices:     the next max_voices sources of their stream, padded to the longest of the group;
+ *               n_voices ~ U{1 .. max_voices-1} (1 when max_voices == 1); gain = 10^-U[0, -snr/10);
+ *               offset ~ U{0 .. padded_len - n_frame - 1} (0 when that range is empty)
+ *   noises:     n_noises ~ U{0 .. max_noises-1}; gain = 10^-U[0, 2); offset ~ U{0 .. max(padded_len - n_frame, 0)}
+ *   bands:      size ~ U{0 .. max_mask-1}, offset ~ U{0 .. axis_len - size - 1}
+ * "Shuffled, repeated stream" = one keyed pseudo-random permutation of the corpus per epoch (every source exactly once
+ * per epoch).  A corpus is described by DEVICE arrays of `n` entries: source addresses, (voices) addresses of their
+ * frame-activity flags, frames per source, and - waveform corpora - samples per channel (NULL for spectrogram corpora).
+ * state_dev: DEVICE uint64[4] {call counter, background / voice / noise stream positions} (iris_augment_draw: uint64[1]),
+ * zero-initialised by the caller once and advanced by every call ON THE DEVICE.
+ * table_out: DEVICE [batch * (1 + max_voices + max_noises)] records, FIXED stride per sample (first_out[b] = b * stride,
+ * DEVICE int32 [batch + 1]); unused voice / noise slots carry kind = -1, which the mix kernels skip.  Pass
+ * n_srcs = batch * stride to iris_mix_specs / iris_mix_waves.  t_bands_out / f_bands_out: DEVICE int32 [batch, n, 2].
+ */
+typedef struct {
+    const float* const* src;    /* DEVICE [n] */
+    const float* const* active; /* DEVICE [n] (voices) or NULL */
+    const int32_t* T;           /* DEVICE [n] frames per source */
+    const int32_t* len;         /* DEVICE [n] samples per channel (waveform corpora) or NULL */
+    int32_t n;
+} iris_mix_corpus;
+int iris_mix_draw(const iris_mix_corpus* backgrounds, const iris_mix_corpus* voices, const iris_mix_corpus* noises /* nullable */,
+                  int batch, int n_frame, int max_voices, int max_noises, float min_ratio, float min_noise_ratio, float snr,
+                  uint64_t seed, uint64_t* state_dev, iris_mix_src* table_out, int32_t* first_out, void* stream);
+int iris_augment_draw(int batch, int n_time, int n_time_masks, int max_time_mask, int n_freq, int n_freq_masks,
+                      int max_freq_mask, uint64_t seed, uint64_t* state_dev, int32_t* t_bands_out, int32_t* f_bands_out,
+                      void* stream);
 
 /*
  * Per-kernel timing for bench.py: with enable = n > 0 every n-th call of

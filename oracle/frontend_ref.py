@@ -648,3 +648,118 @@ def pool1d_same(x: np.ndarray, k: int, mode: str) -> np.ndarray:
         lo, hi = max(0, i - left), min(t, i - left + k)
         out[i] = x[lo:hi].max(0) if mode == 'max' else x[lo:hi].mean(0)
     return out
+
+
+# --------------------------------------------------------------------------
+# Device-side draws (challenge_amd/csrc/k_draw.h), restated: Philox4x32-10 + the integer draws of a batch.
+# The generator is the published Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11;
+# Random123 known-answer vectors in tests/test_oracle.py); what is drawn follows pipeline.py:29-106 / transforms.py:25-26.
+# --------------------------------------------------------------------------
+DRAW_SAMPLE, DRAW_VOICE, DRAW_NOISE, DRAW_PERM, DRAW_BAND_T, DRAW_BAND_F = 1, 2, 3, 4, 5, 6
+_M32 = 0xFFFFFFFF
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """One Philox4x32-10 block: counter (c0..c3), key (k0, k1) -> four 32-bit words (Python ints)."""
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & _M32, p1 & _M32, ((p0 >> 32) ^ c3 ^ k1) & _M32, p0 & _M32
+        k0, k1 = (k0 + 0x9E3779B9) & _M32, (k1 + 0xBB67AE85) & _M32
+    return c0, c1, c2, c3
+
+
+def draw_below(word, rng_size):
+    return (word * rng_size) >> 32
+
+
+def draw_unit(word):
+    return np.float32(word >> 8) * np.float32(1.0 / 16777216.0)
+
+
+def stream_perm(i, n, stream, epoch, k0, k1):
+    """Element i of epoch `epoch` of stream `stream`: keyed bijection of [0, n) (k_draw.h stream_perm)."""
+    if n <= 1:
+        return 0
+    bits = 1
+    while (1 << bits) < n:
+        bits += 1
+    mask = (1 << bits) - 1
+    sh = max(bits // 2, 1)
+    h = philox4x32_10(epoch & _M32, (epoch >> 32) & _M32, stream, DRAW_PERM, k0, k1)
+    v = i
+    while True:
+        v = (v + h[0]) & mask
+        v = (v * (h[1] | 1)) & mask
+        v ^= v >> sh
+        v = (v + h[2]) & mask
+        v = (v * (h[3] | 1)) & mask
+        v ^= v >> sh
+        v = (v * 0x9E3779B1) & mask
+        v ^= v >> sh
+        if v < n:
+            return v
+
+
+def mix_draw_device(bg_T, v_T, n_T, batch, n_frame, max_voices, max_noises, min_ratio, min_noise_ratio, snr, seed, state):
+    """The records iris_mix_draw writes for one call, as per-sample dicts in the layout of `merge_draw` (gains as the
+    float32 the kernel's formula gives up to the rounding of 10^x).  state = [call counter, bg / voice / noise stream
+    positions] (list of 4 ints), advanced in place like the device copy."""
+    k0, k1 = seed & _M32, (seed >> 32) & _M32
+    ctr, pos_b, pos_v, pos_n = state
+    c0, c1 = ctr & _M32, (ctr >> 32) & _M32
+    V, Nn = max_voices, (max_noises if n_T is not None and len(n_T) else 0)
+
+    def pick(T, stream, pos):
+        n = len(T)
+        return stream_perm(pos % n, n, stream, pos // n, k0, k1)
+
+    def padded(frames, ratio):
+        pad = n_frame - int(np.float32(ratio) * np.float32(frames))
+        return pad, (frames + 2 * pad if pad > 0 else frames)
+    out = []
+    for b in range(batch):
+        rs = philox4x32_10(c0, c1, b * 64, DRAW_SAMPLE, k0, k1)
+        bg = pick(bg_T, 0, pos_b + b)
+        T = int(bg_T[bg])
+        reps = (n_frame + T - 1) // T
+        d = {"bg": bg, "bg_offset": draw_below(rs[2], reps * T - n_frame + 1)}
+        d["n_voices"] = 1 + draw_below(rs[0], V - 1) if V > 1 else 1
+        d["voices"] = [pick(v_T, 1, pos_v + b * V + j) for j in range(V)]
+        d["v_len"] = int(max(v_T[i] for i in d["voices"]))
+        pad, length = padded(d["v_len"], min_ratio)
+        maxval = length - n_frame
+        d["v_offset_all"], d["v_gain_all"] = [], []
+        for j in range(V):
+            rv = philox4x32_10(c0, c1, b * 64 + 1 + j, DRAW_VOICE, k0, k1)
+            d["v_offset_all"].append(draw_below(rv[1], maxval) if maxval > 0 else 0)
+            d["v_gain_all"].append(np.float32(10.0) ** -(draw_unit(rv[0]) * np.float32(-snr / 10.0)))
+        d["v_pad"] = max(pad, 0)
+        d["n_noises"], d["noises"], d["n_len"], d["n_offset_all"], d["n_gain_all"], d["n_pad"] = 0, None, 0, [], [], 0
+        if Nn:
+            d["n_noises"] = draw_below(rs[1], Nn)
+            d["noises"] = [pick(n_T, 2, pos_n + b * Nn + j) for j in range(Nn)]
+            d["n_len"] = int(max(n_T[i] for i in d["noises"]))
+            pad, length = padded(d["n_len"], min_noise_ratio)
+            d["n_pad"] = max(pad, 0)
+            for j in range(Nn):
+                rn = philox4x32_10(c0, c1, b * 64 + 1 + j, DRAW_NOISE, k0, k1)
+                d["n_offset_all"].append(draw_below(rn[1], max(length - n_frame, 0) + 1))
+                d["n_gain_all"].append(np.float32(10.0) ** -(draw_unit(rn[0]) * np.float32(2.0)))
+        out.append(d)
+    state[0], state[1], state[2], state[3] = ctr + 1, pos_b + batch, pos_v + batch * V, pos_n + batch * Nn
+    return out
+
+
+def augment_draw_device(batch, n_time, n_t, max_t, n_freq, n_f, max_f, seed, state):
+    """(t_bands [B, n_t, 2], f_bands [B, n_f, 2]) of iris_augment_draw; state = [call counter], advanced in place."""
+    k0, k1 = seed & _M32, (seed >> 32) & _M32
+    c0, c1 = state[0] & _M32, (state[0] >> 32) & _M32
+    tb, fb = np.zeros((batch, n_t, 2), np.int32), np.zeros((batch, n_f, 2), np.int32)
+    for b in range(batch):
+        for arr, n, total, mx, purpose in ((tb, n_t, n_time, max_t, DRAW_BAND_T), (fb, n_f, n_freq, max_f, DRAW_BAND_F)):
+            for j in range(n):
+                r = philox4x32_10(c0, c1, b * 64 + j, purpose, k0, k1)
+                size = draw_below(r[0], mx)
+                arr[b, j] = (draw_below(r[1], total - size), size)
+    state[0] += 1
+    return tb, fb

@@ -375,3 +375,29 @@ def test_wave_frame_activity_rule_against_the_spectrum_rule():
     wav[0, 2 * hop] = -0.5
     spec = R.to_ref_layout(R.stft(wav, n_fft, hop))
     assert np.array_equal(R.wave_frame_active(wav, n_fft, hop), (spec.max(axis=(0, 2)) > 0).astype(np.float32))
+
+
+def test_philox_known_answers_and_stream_permutation():
+    """The generator behind the device-side draws (challenge_amd/csrc/k_draw.h) is Philox4x32-10: the oracle's
+    restatement reproduces the Random123 known-answer vectors; `stream_perm` is a bijection of [0, n) for every epoch."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert R.philox4x32_10(*ctr, *key) == want
+    for n in (1, 2, 3, 5, 16, 17, 64, 100, 257):
+        for epoch in (0, 1, 7):
+            perm = [R.stream_perm(i, n, 1, epoch, 123, 456) for i in range(n)]
+            assert sorted(perm) == list(range(n))
+        if n > 16:  # different epochs / streams / keys give different orders
+            a = [R.stream_perm(i, n, 1, 0, 123, 456) for i in range(n)]
+            assert a != [R.stream_perm(i, n, 1, 1, 123, 456) for i in range(n)]
+            assert a != [R.stream_perm(i, n, 2, 0, 123, 456) for i in range(n)]
+            assert a != list(range(n))
+    # distributions of the restated draws: uniform integers / unit reals
+    words = [R.philox4x32_10(i, 0, 0, 9, 1, 2)[0] for i in range(4000)]
+    below = np.array([R.draw_below(w, 23) for w in words])
+    assert below.min() == 0 and below.max() == 22 and abs(below.mean() - 11.0) < 0.5
+    unit = np.array([R.draw_unit(w) for w in words])
+    assert 0.0 <= unit.min() and unit.max() < 1.0 and abs(unit.mean() - 0.5) < 0.02

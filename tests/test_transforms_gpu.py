@@ -643,6 +643,116 @@ def test_sj_train_main_two_epochs(dev, tmp_path, monkeypatch):
     assert len(rows) == 1 and math.isfinite(float(rows[0]['loss'])) and math.isfinite(float(rows[0]['val_loss']))
 
 
+def test_device_side_draws_match_the_oracle_restatement(dev):
+    """iris_mix_draw / iris_augment_draw (the random half of a batch drawn on the device, k_draw.h): every integer the
+    kernels write - sources picked from the shuffled streams, crop offsets, voice / noise counts, pads, band offsets and
+    sizes - equals the oracle's NumPy restatement of the Philox generator bit for bit over several consecutive calls
+    (the call counter and stream positions live on the device); gains agree to the rounding of 10^x; the batch mixed
+    from those records equals the oracle's apply bit for bit, in both the spectrum and the waveform domain."""
+    from challenge_amd.mixer import DeviceMixer, WaveMixer, KIND_VOICE, KIND_NOISE, KIND_UNUSED
+    from challenge_amd.data_utils import DeviceAugmentDraw
+    rng = np.random.default_rng(31)
+    C, hop, n_fft, n_frame, n_classes, V, Nn, B, seed = 2, 64, 256, 48, 3, 4, 3, 16, 0x1234567890ABCDEF
+
+    def clip(n, silent_from=None):
+        x = (rng.standard_normal((C, n)) * 0.3).astype(np.float32)
+        if silent_from is not None:
+            x[:, silent_from:] = 0
+        return x
+    backgrounds = [clip(n) for n in (hop * 20 + 7, hop * 90, hop * 48 + 33)]
+    voices = [clip(n, s) for n, s in ((hop * 30, hop * 20), (hop * 55 + 5, None), (hop * 41, hop * 5), (hop * 64, hop * 50),
+                                      (hop * 25 + 60, None), (hop * 48, hop * 30), (hop * 36, None))]
+    labels = np.eye(n_classes, dtype=np.float32)[rng.integers(0, n_classes, len(voices))]
+    noises = [clip(n) for n in (hop * 18, hop * 90 + 9, hop * 40, hop * 52)]
+    mixer = WaveMixer(backgrounds, voices, labels, noises, n_frame=n_frame, n_fft=n_fft, hop=hop, max_voices=V,
+                      max_noises=Nn, n_classes=n_classes, device=dev, min_ratio=1, seed=5)
+    mixer.enable_device_draw(seed)
+    state = [0, 0, 0, 0]
+    epochs_v = []
+    for call in range(4):
+        wav, lab = mixer.mix(B)
+        table = mixer.last_table(B)
+        want = R.mix_draw_device(mixer._bg_T, mixer._v_T, mixer._n_T, B, n_frame, V, Nn, 1.0, 0.5, -20.0, seed, state)
+        draws = mixer.table_to_draws(table)
+        for i, (w, d) in enumerate(zip(want, draws)):
+            assert (d["bg"], d["bg_offset"], d["n_voices"], d["n_noises"]) == (w["bg"], w["bg_offset"], w["n_voices"], w["n_noises"])
+            assert d["voices"] == w["voices"] and d["noises"] == w["noises"]
+            assert d["v_offset"] == w["v_offset_all"][:w["n_voices"]] and d["n_offset"] == w["n_offset_all"][:w["n_noises"]]
+            assert list(table[i]["off"][1:1 + V]) == w["v_offset_all"] and list(table[i]["off"][1 + V:]) == w["n_offset_all"]
+            assert np.all(table[i]["pad"][1:1 + V] == w["v_pad"]) and np.all(table[i]["pad"][1 + V:] == w["n_pad"])
+            assert np.allclose(table[i]["gain"][1:1 + V], w["v_gain_all"], rtol=2e-6)
+            assert np.allclose(table[i]["gain"][1 + V:], w["n_gain_all"], rtol=2e-6)
+            assert list(table[i]["kind"]) == [0] + [KIND_VOICE] * w["n_voices"] + [KIND_UNUSED] * (V - w["n_voices"]) + \
+                [KIND_NOISE] * w["n_noises"] + [KIND_UNUSED] * (Nn - w["n_noises"])
+            assert 1 <= d["n_voices"] <= V - 1 and 0 <= d["n_noises"] <= Nn - 1
+        epochs_v += [k for d in draws for k in d["voices"]]
+        wav_h, lab_h = wav.cpu().numpy(), lab.cpu().numpy()
+        for i, d in enumerate(draws):
+            ref_wav, ref_lab = R.mix_waves_apply(backgrounds[d["bg"]], [voices[k] for k in d["voices"]], labels[d["voices"]],
+                                                 [noises[k] for k in d["noises"]], d, n_frame=n_frame, n_classes=n_classes,
+                                                 hop=hop, n_fft=n_fft, min_ratio=1)
+            assert np.array_equal(wav_h[i], ref_wav) and np.array_equal(lab_h[i], ref_lab), (call, i)
+    assert state[0] == 4 and mixer._dd["state"].cpu().tolist() == state
+    nv = len(voices)                                   # shuffled, repeated stream: every epoch is a permutation
+    for e in range(len(epochs_v) // nv):
+        assert sorted(epochs_v[e * nv:(e + 1) * nv]) == list(range(nv))
+    # the spectrum-domain mixer takes the same kernel (no `len` column)
+    to_spec = lambda w: R.to_ref_layout(R.stft(w, n_fft, hop))  # noqa: E731
+    smix = DeviceMixer([to_spec(b) for b in backgrounds], [to_spec(v) for v in voices], labels, [to_spec(n) for n in noises],
+                       n_frame=n_frame, max_voices=V, max_noises=Nn, n_classes=n_classes, device=dev, min_ratio=1, seed=5)
+    smix.enable_device_draw(seed)
+    spec, slab = smix.mix(B)
+    st2 = [0, 0, 0, 0]
+    want = R.mix_draw_device(smix._bg_T, smix._v_T, smix._n_T, B, n_frame, V, Nn, 1.0, 0.5, -20.0, seed, st2)
+    d0 = smix.table_to_draws(smix.last_table(B))
+    assert [d["voices"] for d in d0] == [w["voices"] for w in want] and [d["bg_offset"] for d in d0] == [w["bg_offset"] for w in want]
+    F = n_fft // 2 + 1
+    for i, d in enumerate(d0[:6]):
+        def padded(bank, idx, length):
+            out = np.zeros((len(idx), F, length, 2 * C), np.float32)
+            for j, k in enumerate(idx):
+                sp = to_spec(bank[k])
+                out[j, :, :sp.shape[1]] = sp
+            return out
+        ref_spec, ref_lab = R.merge_complex_specs_apply(to_spec(backgrounds[d["bg"]]), padded(voices, d["voices"], d["v_len"]),
+                                                        labels[d["voices"]], padded(noises, d["noises"], d["n_len"]), d,
+                                                        n_frame=n_frame, n_classes=n_classes, min_ratio=1)
+        assert np.array_equal(spec[i].cpu().numpy(), ref_spec) and np.array_equal(slab[i].cpu().numpy(), ref_lab)
+    # SpecAugment bands: exact integers, and the reference's support (the last index is never masked when size > 0)
+    aug = DeviceAugmentDraw(dev, seed=77, filter_bins=3)
+    ast = [0]
+    for _ in range(3):
+        tb, fb = aug(B, 512, 257)
+        wt, wf = R.augment_draw_device(B, 512, 6, 24, 257, 1, 16, 77, ast)
+        assert np.array_equal(tb.cpu().numpy(), wt) and np.array_equal(fb[:, :1].cpu().numpy(), wf)
+        assert np.array_equal(fb[:, 1].cpu().numpy(), np.tile(np.array([1, 3], np.int32), (B, 1)))
+        t = tb.cpu().numpy()
+        assert t[..., 1].max() <= 23 and np.all(t[..., 0] + t[..., 1] <= 511) and t.min() >= 0
+    with pytest.raises(ValueError):
+        N = __import__("challenge_amd._native", fromlist=["x"])
+        N.check(N.lib().iris_augment_draw(4, 10, 6, 24, 257, 1, 16, 0, aug.state.data_ptr(), tb.data_ptr(), fb.data_ptr(), None),
+                "iris_augment_draw")                   # a 24-frame mask on a 10-frame axis: the reference errors too
+
+
+def test_device_drawn_datasets_run_and_are_reproducible(dev):
+    """make_wave_dataset / make_device_dataset with device_draw=True: shapes as the host-drawn datasets, finite values,
+    same seed -> same batches, different seed -> different batches."""
+    from challenge_amd import sj_train as S
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '40', '--n_frame', '64', '--n_chan', '2', '--batch_size', '6', '--name', 'r_filter'])
+    srcs = S.synthetic_wave_sources(2, 3, 256, n_bg=4, n_voice=9, n_noise=5, seed=2)
+
+    def first(n, seed, fn, sources, **kw):
+        it = iter(fn(cfg, True, sources=sources, device=dev, seed=seed, device_draw=True, **kw))
+        return [next(it) for _ in range(n)]
+    a, b, c = first(3, 7, S.make_wave_dataset, srcs), first(3, 7, S.make_wave_dataset, srcs), first(3, 8, S.make_wave_dataset, srcs)
+    for (x, y), (x2, y2), (x3, _) in zip(a, b, c):
+        assert tuple(x.shape) == (6, 40, 64, 2) and tuple(y.shape) == (6, 2, 3) and torch.isfinite(x).all()
+        assert torch.equal(x, x2) and torch.equal(y, y2) and not torch.equal(x, x3)
+    ssrc = S.synthetic_sources(2, 3, n_bg=4, n_voice=9, n_noise=5, seed=2)
+    d = first(2, 3, S.make_device_dataset, ssrc)
+    assert tuple(d[0][0].shape) == (6, 40, 64, 2) and torch.isfinite(d[0][0]).all() and not torch.equal(d[0][0], d[1][0])
+
+
 def test_channel_helpers_on_device_match_oracle(dev):
     """R7 on the device against the oracle (data_utils.py:73-117): stereo_mono, mono_chan (both call forms, the
     broadcast-add quirk included), random_merge_aug through its deterministic half with the drawn factor replayed."""
