@@ -27,8 +27,9 @@ using namespace iris;
 #ifndef IRIS_DIRECT_LOAD
 #define IRIS_DIRECT_LOAD 1
 #endif
-// diagnostic buffer: [4] header, [3 * 4096] per-workgroup stamps, [4096 * 16 * 16] per-wave phase cycles
-static constexpr int kDbgPhase0 = 4 + 3 * 4096, kDbgWords = kDbgPhase0 + 4096 * 16 * 16;
+// diagnostic buffer: [4] header, [kDbgWg * 4096] per-workgroup stamps (entry, loop start, exit, tile complete, clip
+// range known, spare), [4096 * 16 * 16] per-wave phase cycles
+static constexpr int kDbgWg = 6, kDbgPhase0 = 4 + kDbgWg * 4096, kDbgWords = kDbgPhase0 + 4096 * 16 * 16;
 #if IRIS_DIAG
 #define PH_BEGIN() do { if (ABL(4096)) ph_t = __builtin_amdgcn_s_memtime(); } while (0)
 #define PH_MARK(i) do { if (ABL(4096)) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph[i] += n_ - ph_t; ph_t = n_; } } while (0)
@@ -193,6 +194,18 @@ __device__ __forceinline__ void block_minmax(float& mn, float& mx, float* red /*
         mn = fminf(mn, red[i]);
         mx = fmaxf(mx, red[16 + i]);
     }
+}
+
+// One value through per-sample min-max and log (data_utils.py:37-55): (v - mn) * inv with inv = 1 / max(mx - mn, 1e-8)
+// formed ONCE per sample by an IEEE division, and ln as the hardware log2 (v_log_f32) times ln 2.  Against the fp64
+// oracle this is as accurate as IEEE division per element + libm logf (max abs error 2.4e-6 vs 3.0e-6 on ln, 1.1e-7 on
+// the [0, 1] value either way: the fp32 rounding of the inputs dominates; scripts/microbench/log_accuracy.hip,
+// profiles/r3/log_accuracy.log) at a fifth of the instructions - the min-max / log epilogue is issue-bound.  Shared by
+// the fused kernel's epilogue and k_minmax_log_apply, so both forms of the step give identical bits.
+__device__ __forceinline__ float minmax_log_value(float v, float mn, float inv, int do_minmax, int do_log, float eps_log) {
+    if (do_minmax) v = (v - mn) * inv;
+    if (do_log) v = __builtin_amdgcn_logf(v + eps_log) * 0.69314718055994530942f;
+    return v;
 }
 
 // Consecutive logical workgroup ids land on the same XCD (blocks b and b+8 share

@@ -589,18 +589,19 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
 
     }
     if (p->d_dbg && (p->ablate & 512)) {
-        std::vector<unsigned long long> h(4 + 3 * 4096, 0);
+        std::vector<unsigned long long> h(4 + kDbgWg * 4096, 0);
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h.data(), p->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         fprintf(stderr, "[iris dbg] workgroup 0: %llu shader cycles, %llu x 10 ns -> %.3f GHz\n", h[0], h[1],
                 h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0.0);
         unsigned long long e0 = ~0ull, e1 = 0, l0 = ~0ull, l1 = 0, x0 = ~0ull, x1 = 0;
-        double pro = 0, loop = 0;
-        int n = 0;
+        double pro = 0, loop = 0, tile_done = 0, xchg = 0, wout = 0;
+        int n = 0, n_epi = 0;
         for (int i = 0; i < 4096; ++i) {
-            const unsigned long long* r = &h[4 + 3 * i];
+            const unsigned long long* r = &h[4 + kDbgWg * i];
             if (!r[0]) continue;
             ++n;
+            if (r[3]) { tile_done += (double)(r[3] - r[1]); xchg += (double)(r[4] - r[3]); wout += (double)(r[2] - r[4]); ++n_epi; }
             e0 = std::min(e0, r[0]); e1 = std::max(e1, r[0]);
             l0 = std::min(l0, r[1]); l1 = std::max(l1, r[1]);
             x0 = std::min(x0, r[2]); x1 = std::max(x1, r[2]);
@@ -609,7 +610,7 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
         if (const char* path = getenv("IRIS_DBG_DUMP")) {
             if (FILE* fp = fopen(path, "w")) {
                 for (int i = 0; i < 4096; ++i) {
-                    const unsigned long long* r = &h[4 + 3 * i];
+                    const unsigned long long* r = &h[4 + kDbgWg * i];
                     if (r[0]) fprintf(fp, "%d %llu %llu %llu\n", i, r[0] - e0, r[1] - e0, r[2] - e0);
                 }
                 fclose(fp);
@@ -620,6 +621,10 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
                     "exit spread %.2f us, first entry -> last exit %.2f us, mean prologue %.2f us, mean loop %.2f us\n",
                     n, (e1 - e0) * 0.01, (l1 - l0) * 0.01, (x1 - x0) * 0.01, (x1 - e0) * 0.01, pro / n * 0.01,
                     loop / n * 0.01);
+        if (n_epi)
+            fprintf(stderr, "[iris dbg] fused epilogue (last chunk of %d workgroups): loop start -> tile complete %.2f us, "
+                    "-> clip range known %.2f us, -> write-out done %.2f us\n", n_epi, tile_done / n_epi * 0.01,
+                    xchg / n_epi * 0.01, wout / n_epi * 0.01);
     }
     (void)hipFree(p->d_dbg);
 #endif

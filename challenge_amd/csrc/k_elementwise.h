@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_minmax_log_apply(float* x, const float*
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (vec && iv < end) v = *reinterpret_cast<const float4*>(p + iv);
 
-    float mn = 0.f, den = 1.f;
+    float mn = 0.f, inv = 1.f;
     if (do_minmax) {
         float lo = INFINITY, hi = -INFINITY;
         if (n_part <= 256) {  // few partials: every wave folds them itself (no barrier)
@@ -59,27 +59,17 @@ __global__ __launch_bounds__(256) void k_minmax_log_apply(float* x, const float*
             block_minmax(lo, hi, red);
         }
         mn = lo;
-        den = fmaxf(hi - lo, eps_div);
+        inv = 1.0f / fmaxf(hi - lo, eps_div);
     }
     if (vec) {
         if (iv < end) {
             float* e = reinterpret_cast<float*>(&v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float y = e[j];
-                if (do_minmax) y = (y - mn) / den;
-                if (do_log) y = logf(y + eps_log);
-                e[j] = y;
-            }
+            for (int j = 0; j < 4; ++j) e[j] = minmax_log_value(e[j], mn, inv, do_minmax, do_log, eps_log);
             *reinterpret_cast<float4*>(p + iv) = v;
         }
     } else {
-        for (size_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
-            float y = p[i];
-            if (do_minmax) y = (y - mn) / den;
-            if (do_log) y = logf(y + eps_log);
-            p[i] = y;
-        }
+        for (size_t i = beg + threadIdx.x; i < end; i += blockDim.x) p[i] = minmax_log_value(p[i], mn, inv, do_minmax, do_log, eps_log);
     }
 }
 

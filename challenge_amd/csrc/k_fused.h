@@ -643,6 +643,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
                 red[kFusedWaves + wv] = mx;
             }
             __syncthreads();  // tile complete, wave ranges visible
+            if (ABL(512) && threadIdx.x == 0 && a.dbg) a.dbg[4 + kDbgWg * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
             if (wv == 0) {
                 float lo = le < kFusedWaves ? red[le] : INFINITY, hi = le < kFusedWaves ? red[kFusedWaves + le] : -INFINITY;
                 lo = wave_min(lo);
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
                             failed = 1;
                             break;
                         }
-                        __builtin_amdgcn_s_sleep(4);
+                        __builtin_amdgcn_s_sleep(1);
                     }
                 }
                 if (lane == 0) {
@@ -687,20 +688,36 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
                 }
             }
             __syncthreads();
+            if (ABL(512) && threadIdx.x == 0 && a.dbg) a.dbg[4 + kDbgWg * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();
             const float cmn = red[2 * kFusedWaves], cmx = red[2 * kFusedWaves + 1];
             const bool failed = __float_as_uint(red[2 * kFusedWaves + 2]) != 0;
-            const float den = fmaxf(cmx - cmn, 1e-8f);
+            const float inv = 1.0f / fmaxf(cmx - cmn, 1e-8f);
             const int mm = a.do_minmax, lg = a.do_log;
-            for (int m = wv; m < a.M; m += kFusedWaves) {  // wave-uniform row; lanes run along the row
-                const float* trow = tile + __umul24((unsigned)m, (unsigned)a.pitch);
-                float* orow = chunk_out + (size_t)m * a.T * a.C;
-                for (int f0 = le; f0 < nwf; f0 += kWave) {
-                    float y = trow[f0];
-                    if (mm) y = (y - cmn) / den;
-                    if (lg) y = logf(y + 1e-8f);
-                    if (failed) y = NAN;
-                    asm volatile("global_store_dword %0, %1, %2" ::"v"((unsigned)f0 * 4u), "v"(y), "s"(orow) : "memory");
+            // wave w owns rows w, w + W, ... of the tile and walks them as ONE flat run of (rows x nwf) elements, 64 at a
+            // time, so that no lane idles on a row's ragged tail (79 columns = 64 + 15); (row, column) advance without a
+            // division: 64 = q nwf + r
+            int we = wv;  // the wave index, hidden from loop-invariant code motion like `le` (row offsets would otherwise be
+            asm volatile("" : "+s"(we));  // precomputed into scalar registers that the frame loop has none to spare for)
+            const int rows_w = (a.M - we + kFusedWaves - 1) / kFusedWaves;
+            const int total = rows_w * nwf, q64 = kWave / nwf, r64 = kWave - q64 * nwf;
+            int jr = le / nwf, f0 = le - jr * nwf;
+            // software-pipelined by one element: the next LDS read is in flight behind this element's math and store
+            unsigned m = (unsigned)(we + jr * kFusedWaves);
+            float cur = le < total ? tile[__umul24(m, (unsigned)a.pitch) + f0] : 0.f;
+            for (int e = le; e < total; e += kWave) {
+                const unsigned off = m * rowpitch_b + (unsigned)f0 * 4u;  // byte offset m * row pitch + 4 f0 < 2^32 (host check)
+                f0 += r64;
+                jr += q64;
+                if (f0 >= nwf) {
+                    f0 -= nwf;
+                    ++jr;
                 }
+                m = (unsigned)(we + jr * kFusedWaves);
+                const float nxt = e + kWave < total ? tile[__umul24(m, (unsigned)a.pitch) + f0] : 0.f;
+                float y = minmax_log_value(cur, cmn, inv, mm, lg, 1e-8f);
+                if (failed) y = NAN;
+                asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(y), "s"(chunk_out) : "memory");
+                cur = nxt;
             }
         }
         if (chunk + (int)gridDim.x < a.n_chunks) {  // another chunk follows: restart the queue
@@ -726,8 +743,8 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
             a.dbg[0] = __builtin_amdgcn_s_memtime() - stamp0;
             a.dbg[1] = __builtin_amdgcn_s_memrealtime() - real0;
         }
-        a.dbg[4 + 3 * blockIdx.x + 0] = real_entry;
-        a.dbg[4 + 3 * blockIdx.x + 1] = real0;
-        a.dbg[4 + 3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+        a.dbg[4 + kDbgWg * blockIdx.x + 0] = real_entry;
+        a.dbg[4 + kDbgWg * blockIdx.x + 1] = real0;
+        a.dbg[4 + kDbgWg * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     }
 }
