@@ -229,6 +229,15 @@ class FrontendPlan:
         N.check(rc, "iris_wav_to_logmel")
         return out
 
+    # ---- prepared launches ------------------------------------------------------
+    def prepare(self, wav: torch.Tensor, out: Optional[torch.Tensor] = None, minmax: bool = True, log: bool = True,
+                normalize: bool = False, t_bands=None, f_bands=None) -> "PreparedCall":
+        """Validate once, launch many times: returns an object whose `.launch()` is nothing but the C-ABI call of
+        `wav_to_logmel(wav, out=out, ...)` with pre-converted arguments (about 3 us of host time instead of ~12 us for the
+        checked path) - for steady-state loops over long-lived buffers (serving, benchmarks).  Tensors are bound BY
+        ADDRESS (refill them in place); launches go to the stream that is current NOW; not thread-safe."""
+        return PreparedCall(self, wav, out, minmax, log, normalize, t_bands, f_bands)
+
     # ---- hipGraph ------------------------------------------------------------
     def capture(self, wav: torch.Tensor, out: Optional[torch.Tensor] = None, **kwargs) -> "CapturedStep":
         """Capture `wav_to_logmel(wav, out=out, **kwargs)` into a hipGraph (torch.cuda.CUDAGraph) once and return an
@@ -260,6 +269,34 @@ class FrontendPlan:
         N.check(N.lib().iris_timing_samples(self._handle, int(kernel), buf.ctypes.data_as(C.POINTER(C.c_float)), cap,
                                             C.byref(n)), "iris_timing_samples")
         return buf[:min(n.value, cap)].copy()
+
+
+class PreparedCall:
+    """One fused frontend call with its arguments converted once (see FrontendPlan.prepare)."""
+    __slots__ = ("out", "_fn", "_args", "_keep")
+
+    def __init__(self, plan: FrontendPlan, wav, out, minmax, log, normalize, t_bands, f_bands):
+        wav, b, length = plan._check_wav(wav)
+        t = plan.num_frames(length)
+        if out is None:
+            out = torch.empty((b, plan.n_mel, t, plan.channels), dtype=torch.float32, device=plan.device)
+        else:
+            out = _require_device_f32(out, "out")
+            if tuple(out.shape) != (b, plan.n_mel, t, plan.channels):
+                raise ValueError(f"out must be {(b, plan.n_mel, t, plan.channels)}, got {tuple(out.shape)}")
+        tb, tbp, ntb = _bands_arg(t_bands, b, plan.device, "t_bands")
+        fb, fbp, nfb = _bands_arg(f_bands, b, plan.device, "f_bands")
+        flags = (N.IRIS_F_MINMAX if minmax else 0) | (N.IRIS_F_LOG if log else 0) | (N.IRIS_F_NORMALIZE if normalize else 0)
+        self.out, self._keep = out, (plan, wav, tb, fb)     # keep everything the raw pointers refer to alive
+        self._fn = N.lib().iris_wav_to_logmel
+        self._args = (plan._handle, C.c_void_p(wav.data_ptr()), C.c_void_p(out.data_ptr()), b, length, flags, tbp, ntb, fbp, nfb,
+                      _stream_ptr(plan.device))
+
+    def launch(self) -> torch.Tensor:
+        rc = self._fn(*self._args)
+        if rc:
+            N.check(rc, "iris_wav_to_logmel")
+        return self.out
 
 
 class CapturedStep:

@@ -480,6 +480,25 @@ def test_timing_sampler_skips_first_launches_and_reads_both_kernels(dev):
     assert plan.fused_kernel_name(True).startswith("k_wav_to_mel<10,0,false,true")
 
 
+def test_prepared_call_equals_checked_call(dev):
+    """FrontendPlan.prepare: arguments converted once, `.launch()` = the bare C-ABI call; same bits as the checked path,
+    follows in-place changes of its input, and still validates at prepare time."""
+    rng = np.random.default_rng(6)
+    plan = FE().FrontendPlan(1024, 256, 64, 16000, 1, 6, 40000, dev)
+    x = torch.from_numpy((rng.standard_normal((6, 1, 40000)) * 0.1).astype(np.float32)).to(dev)
+    tb = torch.tensor(np.tile(np.array([[[3, 5], [40, 2]]], np.int32), (6, 1, 1)), device=dev)
+    call = plan.prepare(x, t_bands=tb)
+    assert torch.equal(call.launch(), plan.wav_to_logmel(x, t_bands=tb))
+    x.mul_(0.7)
+    want = plan.wav_to_logmel(x, t_bands=tb).clone()
+    for _ in range(3):
+        assert torch.equal(call.launch(), want)
+    with pytest.raises(ValueError):
+        plan.prepare(x, out=torch.empty(6, 64, 10, 1, device=dev))
+    with pytest.raises(RuntimeError):
+        plan.prepare(x.cpu())
+
+
 def test_captured_step_replays_bit_exact(dev):
     """FrontendPlan.capture: the fused call as a hipGraph; replays equal the eager call bit for bit, follow in-place
     changes of the captured input / bands, and keep doing so after other launches on the same plan."""
