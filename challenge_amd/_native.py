@@ -51,6 +51,8 @@ SIGNATURES = {
     "iris_augment_draw": (_i, [_i, _i, _i, _i, _i, _i, _i, C.c_uint64, _vp, _vp, _vp, _vp]),
     "iris_bias_relu": (_i, [_vp, _vp, _sz, _i, _vp]),
     "iris_bias_relu_maxpool": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "iris_bias_relu_nchw": (_i, [_vp, _vp, _sz, _i, _sz, _vp]),
+    "iris_bias_relu_maxpool_nchw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "iris_plan_kernel_name": (_i, [_vp, _i, C.c_char_p, _i]),
     "iris_timing_enable": (_i, [_vp, _i]),
     "iris_timing_read": (_i, [_vp, C.POINTER(_i), _fp]),

@@ -434,6 +434,33 @@ extern "C" int iris_bias_relu_maxpool(const float* x, const float* bias, float* 
     return IRIS_OK;
 }
 
+extern "C" int iris_bias_relu_nchw(float* x, const float* bias, size_t batch, int channels, size_t inner, void* stream) {
+    if (!x || !bias) return fail(IRIS_E_INVALID, "iris_bias_relu_nchw: NULL argument");
+    if (channels <= 0 || inner == 0 || (inner & 3)) return fail(IRIS_E_UNSUPPORTED, "iris_bias_relu_nchw: inner size %zu must be a positive multiple of 4", inner);
+    if (reinterpret_cast<uintptr_t>(x) & 15) return fail(IRIS_E_INVALID, "iris_bias_relu_nchw: x must be 16-byte aligned");
+    if (batch == 0) return IRIS_OK;
+    const size_t n4 = batch * (size_t)channels * (inner / 4);
+    k_bias_relu_nchw<<<grid_for(n4), 256, 0, (hipStream_t)stream>>>(x, bias, n4, inner / 4, channels);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_bias_relu_maxpool_nchw(const float* x, const float* bias, float* y, int batch, int height, int width,
+                                           int channels, void* stream) {
+    if (!x || !bias || !y) return fail(IRIS_E_INVALID, "iris_bias_relu_maxpool_nchw: NULL argument");
+    if (batch <= 0 || height <= 0 || width <= 0 || channels <= 0) return fail(IRIS_E_INVALID, "iris_bias_relu_maxpool_nchw: empty tensor");
+    int tile_w = 64;
+    while (tile_w > 1 && (size_t)tile_w * (channels + 1) * sizeof(float) > 48 * 1024) tile_w >>= 1;
+    const size_t lds = (size_t)tile_w * (channels + 1) * sizeof(float);
+    if (lds > 48 * 1024 || batch > 65535 || (height + 1) / 2 > 65535)
+        return fail(IRIS_E_UNSUPPORTED, "iris_bias_relu_maxpool_nchw: %d channels / batch %d / height %d out of range", channels, batch, height);
+    const int Wo = (width + 1) / 2;
+    k_bias_relu_pool_nchw<<<dim3((Wo + tile_w - 1) / tile_w, (height + 1) / 2, batch), 256, lds, (hipStream_t)stream>>>(
+        x, bias, y, height, width, channels, tile_w);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
 extern "C" int iris_plan_kernel_name(const iris_plan* p, int with_bands, char* out, int capacity) {
     if (!p || !out || capacity <= 0) return fail(IRIS_E_INVALID, "iris_plan_kernel_name: bad argument");
     if (p->mel_only) return fail(IRIS_E_UNSUPPORTED, "iris_plan_kernel_name: mel-only plan");

@@ -256,3 +256,49 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool(const float* x, const fl
         y4[i] = m;
     }
 }
+
+// The same epilogues for a CONTIGUOUS (NCHW) activation - block 1 of the CRNN runs its 32 -> 32 convolution in that
+// layout (MIOpen's NCHW solvers take 415 us for it against 683 us for the NHWC implicit GEMM; every other layer is
+// faster in NHWC): x [B, C, inner] in place, and the pooling variant reads NCHW and writes the pooled tensor
+// channels-last [B, Ho, Wo, C] through an LDS transpose (reads coalesced along w, writes along c).
+__global__ __launch_bounds__(256) void k_bias_relu_nchw(float* x, const float* bias, size_t n_vec4, size_t inner4, int C) {
+    float4* x4 = reinterpret_cast<float4*>(x);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x) {
+        const float b = bias[(i / inner4) % C];
+        float4 v = x4[i];
+        v.x = fmaxf(v.x + b, 0.f);
+        v.y = fmaxf(v.y + b, 0.f);
+        v.z = fmaxf(v.z + b, 0.f);
+        v.w = fmaxf(v.w + b, 0.f);
+        x4[i] = v;
+    }
+}
+
+// tile_w pooled columns per block (<= 64: one lane each), sized by the host so that the tile fits 48 KB of LDS
+__global__ __launch_bounds__(256) void k_bias_relu_pool_nchw(const float* x, const float* bias, float* y, int H, int W, int C,
+                                                             int tile_w) {
+    extern __shared__ float tile[];  // [tile_w][C + 1]
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int wo0 = blockIdx.x * tile_w, ho = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wo = wo0 + lane, h0 = 2 * ho, w0 = 2 * wo;
+    const bool h1 = h0 + 1 < H, w1 = w0 + 1 < W, in = wo < Wo && lane < tile_w;
+    for (int c = wv; c < C; c += 4) {
+        const float* p = x + (((size_t)b * C + c) * H + h0) * W + w0;
+        float m = -INFINITY;
+        if (in) {
+            m = p[0];
+            if (w1) m = fmaxf(m, p[1]);
+            if (h1) {
+                m = fmaxf(m, p[W]);
+                if (w1) m = fmaxf(m, p[W + 1]);
+            }
+            m = fmaxf(m + bias[c], 0.f);
+        }
+        if (lane < tile_w) tile[lane * (C + 1) + c] = m;
+    }
+    __syncthreads();
+    const int n_w = min(tile_w, Wo - wo0);
+    float* o = y + (((size_t)b * Ho + ho) * Wo + wo0) * C;  // [n_w][C] contiguous
+    for (int i = threadIdx.x; i < n_w * C; i += blockDim.x) o[i] = tile[(i / C) * (C + 1) + (i % C)];
+}

@@ -344,6 +344,30 @@ def bias_relu_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def bias_relu_nchw_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """In place max(x + bias[c], 0) on a CONTIGUOUS [B, C, H, W] activation (iris_bias_relu_nchw)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        raise ValueError("bias_relu_nchw_: x must be a contiguous float32 [B, C, H, W] tensor on a ROCm device")
+    b, c, h, w = (int(v) for v in x.shape)
+    with torch.cuda.device(x.device):
+        rc = N.lib().iris_bias_relu_nchw(x.data_ptr(), bias.data_ptr(), b, c, h * w, _stream_ptr(x.device))
+    N.check(rc, "iris_bias_relu_nchw")
+    return x
+
+
+def bias_relu_maxpool_nchw(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """maxpool2x2('same')(relu(x + bias)) reading a CONTIGUOUS [B, C, H, W] activation and returning the pooled tensor in
+    channels_last memory format (iris_bias_relu_maxpool_nchw): the hand-over from an NCHW block to the NHWC rest."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        raise ValueError("bias_relu_maxpool_nchw: x must be a contiguous float32 [B, C, H, W] tensor on a ROCm device")
+    b, c, h, w = (int(v) for v in x.shape)
+    y = torch.empty((b, c, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = N.lib().iris_bias_relu_maxpool_nchw(x.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w, c, _stream_ptr(x.device))
+    N.check(rc, "iris_bias_relu_maxpool_nchw")
+    return y
+
+
 def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """maxpool2x2('same')(relu(x + bias)) for a channels_last [B, C, H, W] activation in ONE pass (iris_bias_relu_maxpool):
     reads x once, writes a quarter of it.  Returns a channels_last [B, C, ceil(H/2), ceil(W/2)] tensor."""

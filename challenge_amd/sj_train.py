@@ -705,13 +705,24 @@ class _ConvBiasReLU(nn.Module):
     bias + ReLU (iris_bias_relu) - or, for the last convolution of a block, bias + ReLU + the block's 2x2 max-pool
     (iris_bias_relu_maxpool) - instead of separate add / clamp / pooling kernels over the activation."""
 
-    def __init__(self, conv: nn.Conv2d, pool: bool):
+    def __init__(self, conv: nn.Conv2d, pool: bool, nchw: bool = False):
         super().__init__()
-        self.weight = nn.Parameter(conv.weight.detach().clone(memory_format=torch.channels_last), requires_grad=False)
+        fmt = torch.contiguous_format if nchw else torch.channels_last
+        self.weight = nn.Parameter(conv.weight.detach().clone(memory_format=fmt), requires_grad=False)
         self.bias = nn.Parameter(conv.bias.detach().clone(), requires_grad=False)
-        self.padding, self.pool = conv.padding, pool
+        self.padding, self.pool, self.nchw = conv.padding, pool, nchw
 
     def forward(self, x):
+        if self.nchw:  # contiguous in, contiguous out - or, with the block's pooling, channels_last out
+            if x.shape[1] == 1:  # one channel: NHWC and NCHW coincide in memory; give the view plain NCHW strides, or the
+                b, c, h, w = x.shape  # convolution is dispatched as channels_last and its output has to be copied back
+                x = x.as_strided((b, c, h, w), (h * w, h * w, w, 1)) if x.stride(3) == 1 and x.stride(2) == w else x.contiguous()
+            else:
+                x = x.contiguous()
+            y = torch.nn.functional.conv2d(x, self.weight, None, padding=self.padding)
+            if not y.is_contiguous():
+                y = y.contiguous()
+            return _fe.bias_relu_maxpool_nchw(y, self.bias) if self.pool else _fe.bias_relu_nchw_(y, self.bias)
         y = torch.nn.functional.conv2d(x, self.weight, None, padding=self.padding)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)
@@ -721,27 +732,32 @@ class _ConvBiasReLU(nn.Module):
 class InferenceEngine:
     """Inference-only execution of a CustomModel (the c3 path: HIP frontend + SpecAugment + CRNN forward):
       * eval-mode BatchNorm folded into the layer in front of it (`fold_batchnorm`);
-      * every Conv2D + bias + ReLU (+ MaxPool) of the conv stack as MIOpen convolution + one HIP epilogue pass;
+      * every Conv2D + bias + ReLU (+ MaxPool) of the conv stack as MIOpen convolution + one HIP epilogue pass; block 1
+        (1 or 2 -> 32 -> 32 channels at full resolution) runs in NCHW, where MIOpen's solvers are 40 % faster for the
+        32 -> 32 layer, and hands over in NHWC through the pooling epilogue;
       * frontend + forward captured into ONE hipGraph (`replay`), when a frontend and an example batch are given.
     Same function as `model.eval()(x)` up to fp32 rounding (GPU test: <= 1e-4 on the sigmoid outputs).  The model
     stays on PyTorch-ROCm (MIOpen / hipBLASLt); only the elementwise epilogues are this repository's kernels."""
 
     def __init__(self, model: "CustomModel", frontend: Optional["WaveFrontend"] = None,
-                 example_wav: Optional[torch.Tensor] = None, fuse_epilogues: bool = True):
+                 example_wav: Optional[torch.Tensor] = None, fuse_epilogues: bool = True, block1_nchw: bool = True):
         self.model = fold_batchnorm(model)
         self.fused_convs = 0
         dev = next(self.model.parameters()).device
         if fuse_epilogues and dev.type == 'cuda':
+            first = True
             for blk in self.model.features:
                 if not isinstance(blk, ConvMPBlock):
                     continue
+                nchw, first = first and block1_nchw, False
                 convs = list(blk.convs)
                 has_pool = isinstance(blk.pool, nn.MaxPool2d)
                 ok = all(len(m) == 3 and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.Identity) and
                          m[0].out_channels % 4 == 0 for m in convs)
                 if not ok:
                     continue
-                blk.convs = nn.Sequential(*[_ConvBiasReLU(m[0], has_pool and i == len(convs) - 1)
+                nchw = nchw and has_pool  # the hand-over to NHWC happens in the pooling epilogue
+                blk.convs = nn.Sequential(*[_ConvBiasReLU(m[0], has_pool and i == len(convs) - 1, nchw)
                                             for i, m in enumerate(convs)])
                 if has_pool:
                     blk.pool = nn.Identity()

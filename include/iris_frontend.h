@@ -249,6 +249,12 @@ int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float clip_factor
  * channels must be a multiple of 4; x, y, bias DEVICE, 16-byte aligned.  Run on the current HIP device.
  */
 int iris_bias_relu(float* x, const float* bias, size_t n_outer, int channels, void* stream);
+/* the same on a CONTIGUOUS (NCHW) activation x [batch, channels, inner] (inner = H * W, a multiple of 4), and the pooling
+ * variant reading NCHW x [B, C, H, W] and writing the pooled tensor channels-last y [B, ceil(H/2), ceil(W/2), C]: block 1 of
+ * the CRNN runs its convolutions in NCHW (MIOpen is faster there for 32 -> 32 channels at 64 x 512) and hands over in NHWC */
+int iris_bias_relu_nchw(float* x, const float* bias, size_t batch, int channels, size_t inner, void* stream);
+int iris_bias_relu_maxpool_nchw(const float* x, const float* bias, float* y, int batch, int height, int width, int channels,
+                                void* stream);
 int iris_bias_relu_maxpool(const float* x, const float* bias, float* y, int batch, int height, int width, int channels,
                            void* stream);
 

@@ -11,3 +11,13 @@ find $OUT/driver -name "*kernel_trace.csv" -delete
 PMC_OUT=r3final/pmc bash scripts/gpu_pmc.sh "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" > $OUT/pmc.log 2>&1; tail -3 $OUT/pmc.log
 timeout -k 10 300 python3 scripts/gpu_shapes.py 2>&1 | grep -v amdgpu.ids | tee $OUT/shapes.log
 timeout -k 10 900 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "full bench rc $?"; cut -c1-300 $OUT/bench_default.json; tail -3 $OUT/bench_default.err
+for mode in module engine graph; do
+  timeout -k 10 300 python3 scripts/gpu_fwdprof.py 20 $mode > $OUT/c3_$mode.pre.log 2>&1; tail -1 $OUT/c3_$mode.pre.log
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_$mode -o c3 -- python3 scripts/gpu_fwdprof.py 20 $mode > $OUT/c3_$mode.log 2>&1; grep "fwd\[" $OUT/c3_$mode.log
+  python3 scripts/trace_steps.py $OUT/c3_$mode/c3_kernel_trace.csv k_wav_to_mel 12 $OUT/c3_${mode}_step_kernel_stats.csv
+  find $OUT/c3_$mode -name "*kernel_trace.csv" -delete
+done
+timeout -k 10 300 python3 scripts/gpu_c4prof.py 10 > $OUT/c4.pre.log 2>&1; tail -1 $OUT/c4.pre.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -o c4 -- python3 scripts/gpu_c4prof.py 10 > $OUT/c4.log 2>&1; grep "train step" $OUT/c4.log
+python3 scripts/trace_steps.py $OUT/c4/c4_kernel_trace.csv k_wav_to_mel 6 $OUT/c4_step_kernel_stats.csv
+find $OUT/c4 -name "*kernel_trace.csv" -delete

@@ -802,6 +802,11 @@ def test_bias_relu_epilogues_match_torch(dev):
         assert got_p.is_contiguous(memory_format=torch.channels_last) and torch.equal(got_p, pooled)
         got = FEm.bias_relu_(x.clone(memory_format=torch.channels_last), bias)
         assert torch.equal(got, want)
+        xc = x.contiguous()                                  # the NCHW twins (block 1 of the inference engine)
+        got_pn = FEm.bias_relu_maxpool_nchw(xc, bias)
+        assert got_pn.is_contiguous(memory_format=torch.channels_last) and torch.equal(got_pn, pooled)
+        if (h * w) % 4 == 0:
+            assert torch.equal(FEm.bias_relu_nchw_(xc.clone(), bias), want)
     with pytest.raises(ValueError):
         FEm.bias_relu_maxpool(torch.zeros(1, 6, 4, 4, device=dev).contiguous(memory_format=torch.channels_last),
                               torch.zeros(6, device=dev))
