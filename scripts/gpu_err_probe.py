@@ -46,3 +46,12 @@ for n_fft, hop, m, c, b, length in [(1024, 256, 64, 1, 40, 25600), (512, 256, 80
         extra = f" | torch.stft fp32 vs fp64 {rel_err(t32, ref64):.2e}" if not kw else ""
         print(f"test input n_fft {n_fft} M {m} C {c} [{name}]: HIP vs fp64 {rel_err(hip, ref64):.2e} | numpy fp32 vs fp64 "
               f"{rel_err(ref32, ref64):.2e}{extra}")
+
+# the three inputs of tests/test_frontend_gpu.py::test_fp16_mfma_mel_variant (fp32 path)
+for n_fft, hop, m, c, sr, b, length in [(2048, 512, 128, 2, 22050, 3, 33075), (1024, 256, 64, 1, 16000, 5, 40000), (512, 256, 80, 2, 16000, 4, 20000)]:
+    rng = np.random.default_rng(n_fft + m)
+    wav = R.normalize((rng.standard_normal((b, c * length)) * 0.3).astype(np.float32)).reshape(b, c, length)
+    plan = FrontendPlan(n_fft, hop, m, sr, c, b, length, dev)
+    hip = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), minmax=False, log=False).cpu().numpy()
+    ref64 = R.wav_to_mel(wav, n_fft, hop, m, sr, dtype=np.float64)
+    print(f"mfma-test input n_fft {n_fft} M {m} C {c}: fp32 HIP vs fp64 {rel_err(hip, ref64):.2e} | numpy fp32 vs fp64 {rel_err(R.wav_to_mel(wav, n_fft, hop, m, sr), ref64):.2e}")

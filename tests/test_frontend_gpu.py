@@ -414,7 +414,9 @@ def test_fp16_mfma_mel_variant(dev, n_fft, hop, m, c, sr, b, length):
     ref64 = R.wav_to_mel(wav, n_fft, hop, m, sr, dtype=np.float64)
     err = rel_err(got.cpu().numpy(), ref64)
     assert 1e-6 < err <= 2e-3, err                              # really the fp16 path (not bit-equal to fp32), within its tolerance
-    assert rel_err(fp32.cpu().numpy(), ref64) <= max(1e-5, 0.05 * err)
+    # the fp32 kernel on the same input, at its fixed constants (n_fft 512 / 80 mel / stereo: 2e-5, measured 1.52e-5 - the
+    # narrow-low-band shape of DESIGN.md section 2; the other two 1e-5, measured 1.4e-6 and 8.1e-7)
+    assert rel_err(fp32.cpu().numpy(), ref64) <= (2e-5 if n_fft == 512 else 1e-5)
     # min-max + log on top of it (per-wave partials from the MFMA kernel feed the same second kernel)
     full = plan.wav_to_logmel(x).cpu().numpy()
     ref = R.wav_to_logmel(wav, n_fft, hop, m, sr)
