@@ -1,14 +1,14 @@
-# round 3, measurement set for profiles/r3: driver command (plain and under rocprofv3), PMC passes, shapes, full bench
+# measurement set for profiles/r<N>: driver command (plain and under rocprofv3), PMC passes, shapes, full bench
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r3final
+OUT=$GRAFT_REPO_ROOT/gpurun_out/measure
 rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -3 $OUT/pytest_gpu.log
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_driver_cmd.json 2>/dev/null; cut -c1-200 $OUT/bench_driver_cmd.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/driver -o bench -- python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_driver_cmd_rocprof.json 2> $OUT/bench_driver_cmd_rocprof.err; echo "rocprof rc $?"
 grep -E "k_wav_to_mel|k_minmax" $OUT/driver/*kernel_stats.csv | cut -c1-160
 find $OUT/driver -name "*kernel_trace.csv" -delete
-PMC_OUT=r3final/pmc bash scripts/gpu_pmc.sh "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" > $OUT/pmc.log 2>&1; tail -3 $OUT/pmc.log
+PMC_OUT=measure/pmc bash scripts/gpu_pmc.sh "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" > $OUT/pmc.log 2>&1; tail -3 $OUT/pmc.log
 timeout -k 10 300 python3 scripts/gpu_shapes.py 2>&1 | grep -v amdgpu.ids | tee $OUT/shapes.log
 timeout -k 10 900 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "full bench rc $?"; cut -c1-300 $OUT/bench_default.json; tail -3 $OUT/bench_default.err
 for mode in module engine graph; do
