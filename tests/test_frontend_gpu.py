@@ -557,3 +557,24 @@ def test_fused_epilogue_equals_two_kernels(dev, monkeypatch, n_fft, hop, m, c, b
     assert fused.status() == 0
     ref = R.wav_to_logmel(wav[:2], n_fft, hop, m, 16000)
     assert np.abs(np.exp(a[:2].cpu().numpy()) - np.exp(ref)).max() <= 5e-6
+
+
+def test_fused_epilogue_plans_on_two_streams_complete(dev):
+    """Two plans with the fused epilogue launched concurrently on two streams (more than the header recommends: the
+    documented mode for such pipelines is the two-kernel form): every in-kernel wait still completes - workgroups publish
+    before they wait and dispatch is in order, so partially resident launches drain - and the outputs are right.  Were a
+    wait ever to time out the kernel would fill the clip with NaN and set the status word; nothing here can hang."""
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy((rng.standard_normal((32, 1, 40000)) * 0.1).astype(np.float32)).to(dev)
+    plans = [FE().FrontendPlan(1024, 256, 64, 16000, 1, 32, 40000, dev) for _ in range(2)]
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    want = plans[0].wav_to_logmel(x).clone()
+    outs = [torch.empty_like(want) for _ in range(2)]
+    torch.cuda.synchronize()
+    for it in range(150):
+        for p, s, o in zip(plans, streams, outs):
+            with torch.cuda.stream(s):
+                p.wav_to_logmel(x, out=o)
+    torch.cuda.synchronize()
+    assert all(p.status() == 0 for p in plans)
+    assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
