@@ -222,7 +222,7 @@ static int fused_config(iris_plan* p, fused_kernel_t kernel, int batch, int T, i
     }
     int resident = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
-                                                                64 * fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse), *lds);
+                                                                64 * fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse, p->mel_mode), *lds);
     if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
     if (resident < 1) return fail(IRIS_E_UNSUPPORTED, "fused kernel does not fit one workgroup per CU (LDS %zu B)", *lds);
     p->geom_cache.push_back({(const void*)kernel, batch, T, *chunk_frames, *chunks_per_clip, *grid, *lds});
@@ -328,7 +328,7 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     a.n_chunks = batch * a.chunks_per_clip;
     a.chunk_base = a.T / a.chunks_per_clip;
     a.chunk_rem = a.T % a.chunks_per_clip;
-    const int waves = mfma ? kMfmaWaves : fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse);
+    const int waves = mfma ? kMfmaWaves : fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse, p->mel_mode);
     const int parts_per_chunk = waves;
     const size_t n_partial = 2 * (size_t)a.n_chunks * parts_per_chunk;
     a.partial = p->d_ws;

@@ -157,13 +157,13 @@ static int plan_streams(const iris_plan* p) {
 // staged through the exchange area once), the frame queue, the MELMODE 1 tables
 static size_t fused_lds_bytes(const iris_plan* p, int streams, bool bands, int chunk_frames = 0, bool fuse = false) {
     const size_t xbuf = (wave_buf_bytes(p->log2n) + 15) & ~(size_t)15;
-    const size_t waves = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse) * streams;
+    const size_t waves = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse, p->mel_mode) * streams;
     const size_t stage = (size_t)const_nv4(p->log2n) * 64 * 16;
     const size_t land = fused_direct(p->log2n) ? ((stage + 15) & ~(size_t)15) : waves * (size_t)p->n_fft * 4;
     size_t bytes = land + std::max(waves * xbuf, stage) + 16;
     if (p->mel_mode == 1) bytes += ((size_t)p->rows * p->n_mel + p->n_mel) * 4;
     // time-band bitmap of a chunk, written 2 words per wave per pass over the chunk's frames
-    const size_t pass = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse) * 64;
+    const size_t pass = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse, p->mel_mode) * 64;
     bytes += (((size_t)chunk_frames + pass - 1) / pass * pass / 32 + 2) * 4;
     return bytes;
 }
@@ -171,7 +171,7 @@ static size_t fused_lds_bytes(const iris_plan* p, int streams, bool bands, int c
 static int fused_tile_pitch(const iris_plan* p, int chunk_frames) { return (chunk_frames * p->channels) | 1; }
 static size_t fused_tile_off(size_t lds_without_tile) { return (lds_without_tile + 15) & ~(size_t)15; }
 static size_t fused_tile_bytes(const iris_plan* p, int streams, bool bands, int chunk_frames) {
-    const size_t waves = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, true);
+    const size_t waves = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, true, p->mel_mode);
     return ((size_t)p->n_mel * fused_tile_pitch(p, chunk_frames) + 2 * waves + 4) * 4;
 }
 

@@ -54,11 +54,15 @@
 #endif
 constexpr bool fused_direct(int log2n) { return IRIS_DIRECT_LOAD && log2n <= IRIS_DIRECT_MAX; }
 // hi: the variant computes both halves of the untangle (n_fft 2048: 12 waves would spill, so 8)
-// fuse: the variant applies min-max / log itself (its epilogue needs a few registers more: at n_fft 2048 twelve waves
-// would spill, so 8 there)
-constexpr int fused_waves(int log2n, int streams = 1, bool bands = false, bool hi = false, bool fuse = false) {
+#ifndef IRIS_FUSE2048_12
+#define IRIS_FUSE2048_12 1
+#endif
+#define IRIS_FUSE12(fuse, mel_mode) (!(fuse) || (IRIS_FUSE2048_12 && (mel_mode) != 2))
+// fuse: the variant applies min-max / log itself; its epilogue-only kernel arguments are loaded late (late_arg*), which
+// keeps twelve waves at n_fft 2048 free of scratch - except with the global band table (mel_mode 2), which stays at 8
+constexpr int fused_waves(int log2n, int streams = 1, bool bands = false, bool hi = false, bool fuse = false, int mel_mode = 1) {
     return streams > 1 ? IRIS_S2_WAVES
-                       : (log2n >= 11 ? ((IRIS_W2048 == 0 && fused_direct(11) && !bands && !hi && !fuse) ? 12 : (IRIS_W2048 ? IRIS_W2048 : 8))
+                       : (log2n >= 11 ? ((IRIS_W2048 == 0 && fused_direct(11) && !bands && !hi && IRIS_FUSE12(fuse, mel_mode)) ? 12 : (IRIS_W2048 ? IRIS_W2048 : 8))
                                       : (log2n == 10 ? (bands ? 12 : IRIS_W1024) : 16));
 }
 
@@ -177,11 +181,30 @@ __device__ __forceinline__ void dma_frame(const float* clip, int len, int start,
 }
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+// Kernel arguments that only the epilogue reads, fetched from the kernarg segment WHERE THEY ARE USED: the compiler
+// loads every field of the by-value argument struct at kernel entry and keeps it in scalar registers across the frame
+// loop, which has none to spare (spilled SGPRs take a VGPR, and at n_fft 2048 that VGPR pushed mel weights to scratch).
+// `asm volatile` keeps the load out of reach of loop-invariant code motion.
+__device__ __forceinline__ unsigned late_arg32(unsigned offset) {
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "s"(offset) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned long long late_arg64(unsigned offset) {
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "s"(offset) : "memory");
+    return v;
+}
+#define LATE32(field) late_arg32((unsigned)offsetof(FusedArgs, field))
+#define LATE64(field) late_arg64((unsigned)offsetof(FusedArgs, field))
 constexpr unsigned long long kEpilogueTimeoutTicks = 200000000ull;  // s_memrealtime runs at 100 MHz: 2 s
 
 template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S, bool FUSE>
-__global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_waves(LOG2N, S, BANDS, HI, FUSE) / 4) void k_wav_to_mel(const FusedArgs a) {
-    constexpr int kFusedWaves = fused_waves(LOG2N, S, BANDS, HI, FUSE);
+__global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE), fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE) / 4) void k_wav_to_mel(const FusedArgs a) {
+    constexpr int kFusedWaves = fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the wave index is uniform: keep it (and everything derived from it) in SGPRs
@@ -406,8 +429,8 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
         // (the whole output is a few MB).  No LDS tile, no workgroup barrier, no write-out phase:
         // after the prologue the waves only share the frame queue.
         // address = (uniform) out + ((b M T + t0) C + f) * 4  +  (per lane) m * T * C * 4
-        const unsigned rowpitch_b = (unsigned)a.T * (unsigned)a.C * 4u;
-        float* const chunk_out = a.out + ((size_t)b * a.M * a.T + t0) * a.C;
+        const unsigned rowpitch_b = FUSE ? 0u : (unsigned)a.T * (unsigned)a.C * 4u;
+        float* const chunk_out = FUSE ? nullptr : a.out + ((size_t)b * a.M * a.T + t0) * a.C;
         // FUSE: the value goes to the chunk's LDS tile [M][pitch] instead (pitch is odd: the 64 lanes of a frame hit
         // 64 different banks); min-max / log and the coalesced write-out follow once the clip's range is known
         float* const tile = reinterpret_cast<float*>(smem + a.tile_off);
@@ -649,9 +672,10 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
                 lo = wave_min(lo);
                 hi = wave_max(hi);
                 unsigned failed = 0;
-                if (a.do_minmax && a.chunks_per_clip > 1) {
-                    gu64* slots = (gu64*)opaque(a.slots) + 2 * (size_t)b * a.chunks_per_clip;
-                    const unsigned long long tag = (unsigned long long)a.epoch << 32;
+                if (LATE32(do_minmax) && a.chunks_per_clip > 1) {
+                    gu64* slots = (gu64*)LATE64(slots) + 2 * (size_t)b * a.chunks_per_clip;
+                    const unsigned epoch = LATE32(epoch);
+                    const unsigned long long tag = (unsigned long long)epoch << 32;
                     if (lane == 0) {
                         const int ci = chunk - b * a.chunks_per_clip;
                         __hip_atomic_store(slots + 2 * ci, tag | __float_as_uint(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -664,7 +688,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
                         for (int i = le; i < a.chunks_per_clip; i += kWave) {
                             const unsigned long long g0v = __hip_atomic_load(slots + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             const unsigned long long g1v = __hip_atomic_load(slots + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = ok && ((g0v >> 32) == a.epoch) && ((g1v >> 32) == a.epoch);
+                            ok = ok && ((g0v >> 32) == epoch) && ((g1v >> 32) == epoch);
                             l2 = fminf(l2, __uint_as_float((unsigned)g0v));
                             h2 = fmaxf(h2, __uint_as_float((unsigned)g1v));
                         }
@@ -684,7 +708,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
                     red[2 * kFusedWaves + 0] = lo;
                     red[2 * kFusedWaves + 1] = hi;
                     red[2 * kFusedWaves + 2] = __uint_as_float(failed);
-                    if (failed) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (failed) __hip_atomic_store((unsigned*)LATE64(status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             __syncthreads();
@@ -692,7 +716,9 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
             const float cmn = red[2 * kFusedWaves], cmx = red[2 * kFusedWaves + 1];
             const bool failed = __float_as_uint(red[2 * kFusedWaves + 2]) != 0;
             const float inv = 1.0f / fmaxf(cmx - cmn, 1e-8f);
-            const int mm = a.do_minmax, lg = a.do_log;
+            const int mm = (int)LATE32(do_minmax), lg = (int)LATE32(do_log);
+            const unsigned rowpitch_e = (unsigned)a.T * (unsigned)a.C * 4u;
+            float* const out_e = (float*)LATE64(out) + ((size_t)b * a.M * a.T + t0) * a.C;
             // wave w owns rows w, w + W, ... of the tile and walks them as ONE flat run of (rows x nwf) elements, 64 at a
             // time, so that no lane idles on a row's ragged tail (79 columns = 64 + 15); (row, column) advance without a
             // division: 64 = q nwf + r
@@ -705,7 +731,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
             unsigned m = (unsigned)(we + jr * kFusedWaves);
             float cur = le < total ? tile[__umul24(m, (unsigned)a.pitch) + f0] : 0.f;
             for (int e = le; e < total; e += kWave) {
-                const unsigned off = m * rowpitch_b + (unsigned)f0 * 4u;  // byte offset m * row pitch + 4 f0 < 2^32 (host check)
+                const unsigned off = m * rowpitch_e + (unsigned)f0 * 4u;  // byte offset m * row pitch + 4 f0 < 2^32 (host check)
                 f0 += r64;
                 jr += q64;
                 if (f0 >= nwf) {
@@ -716,7 +742,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE), fused_
                 const float nxt = e + kWave < total ? tile[__umul24(m, (unsigned)a.pitch) + f0] : 0.f;
                 float y = minmax_log_value(cur, cmn, inv, mm, lg, 1e-8f);
                 if (failed) y = NAN;
-                asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(y), "s"(chunk_out) : "memory");
+                asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(y), "s"(out_e) : "memory");
                 cur = nxt;
             }
         }
