@@ -461,14 +461,83 @@ extern "C" int iris_bias_relu_maxpool_nchw(const float* x, const float* bias, fl
     return IRIS_OK;
 }
 
+static int bn_check(const void* a, const void* b, size_t rows, int channels, const char* who) {
+    if (!a || !b) return fail(IRIS_E_INVALID, "%s: NULL argument", who);
+    if (rows == 0 || channels <= 0 || (channels & 3) || channels > 4096)
+        return fail(IRIS_E_UNSUPPORTED, "%s: rows %zu, channels %d (a positive multiple of 4, <= 4096)", who, rows, channels);
+    return IRIS_OK;
+}
+static unsigned bn_reduce_grid(size_t rows, int C4) {
+    const int cols = std::min(C4, 256), tys = 256 / cols;
+    return (unsigned)((rows + (size_t)kBnRows * tys - 1) / ((size_t)kBnRows * tys));
+}
+static size_t bn_reduce_lds(int C4) {
+    const int cols = std::min(C4, 256), tys = 256 / cols;
+    return (size_t)tys * 2 * cols * 4 * sizeof(float);
+}
+
+extern "C" int iris_bn_stats(const float* z, size_t rows, int channels, double* sums_zeroed, void* stream) {
+    int rc = bn_check(z, sums_zeroed, rows, channels, "iris_bn_stats");
+    if (rc) return rc;
+    const int C4 = channels / 4;
+    k_bn_reduce<false><<<bn_reduce_grid(rows, C4), 256, bn_reduce_lds(C4), (hipStream_t)stream>>>(z, nullptr, rows, C4, nullptr, nullptr,
+                                                                                             nullptr, nullptr, sums_zeroed);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_bn_relu_apply(const float* z, float* y, size_t rows, int channels, const double* sums, const float* gamma,
+                                  const float* beta, const float* conv_bias, float eps, float momentum, float* running_mean,
+                                  float* running_var, float* save_mean, float* save_rstd, void* stream) {
+    int rc = bn_check(z, y, rows, channels, "iris_bn_relu_apply");
+    if (rc) return rc;
+    if (!sums || !gamma || !beta || !running_mean || !running_var || !save_mean || !save_rstd)
+        return fail(IRIS_E_INVALID, "iris_bn_relu_apply: NULL argument");
+    const size_t n4 = rows * (size_t)(channels / 4);
+    const double m = (double)rows;
+    k_bn_relu_apply<<<grid_for(n4), 256, 2 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(z, y, n4, channels / 4, 1.0 / m, rows > 1 ? m / (m - 1.0) : 1.0, sums,
+                                                                   gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
+                                                                   save_mean, save_rstd);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_bn_relu_bwd_reduce(const float* z, const float* dy, size_t rows, int channels, const float* save_mean,
+                                       const float* save_rstd, const float* gamma, const float* beta, double* sums_zeroed,
+                                       void* stream) {
+    int rc = bn_check(z, sums_zeroed, rows, channels, "iris_bn_relu_bwd_reduce");
+    if (rc) return rc;
+    if (!dy || !save_mean || !save_rstd || !gamma || !beta) return fail(IRIS_E_INVALID, "iris_bn_relu_bwd_reduce: NULL argument");
+    const int C4 = channels / 4;
+    k_bn_reduce<true><<<bn_reduce_grid(rows, C4), 256, bn_reduce_lds(C4), (hipStream_t)stream>>>(z, dy, rows, C4, save_mean, save_rstd, gamma,
+                                                                                            beta, sums_zeroed);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_bn_relu_bwd_dx(const float* z, const float* dy, float* dz, size_t rows, int channels, const float* save_mean,
+                                   const float* save_rstd, const float* gamma, const float* beta, const double* sums,
+                                   float* dgamma, float* dbeta, void* stream) {
+    int rc = bn_check(z, dz, rows, channels, "iris_bn_relu_bwd_dx");
+    if (rc) return rc;
+    if (!dy || !save_mean || !save_rstd || !gamma || !beta || !sums || !dgamma || !dbeta)
+        return fail(IRIS_E_INVALID, "iris_bn_relu_bwd_dx: NULL argument");
+    const size_t n4 = rows * (size_t)(channels / 4);
+    k_bn_relu_bwd_dx<<<grid_for(n4), 256, 4 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
+        z, dy, dz, n4, channels / 4, (float)(1.0 / (double)rows), save_mean, save_rstd, gamma, beta, sums, dgamma, dbeta);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
 extern "C" int iris_plan_kernel_name(const iris_plan* p, int with_bands, char* out, int capacity) {
     if (!p || !out || capacity <= 0) return fail(IRIS_E_INVALID, "iris_plan_kernel_name: bad argument");
     if (p->mel_only) return fail(IRIS_E_UNSUPPORTED, "iris_plan_kernel_name: mel-only plan");
     if (p->mel_precision == 1 && !with_bands)
         snprintf(out, (size_t)capacity, "k_wav_to_mel_mfma<%d>", p->log2n);
     else
-        snprintf(out, (size_t)capacity, "k_wav_to_mel<%d,%d,%s,%s,1>", p->log2n, p->mel_mode,
-                 (p->need_hi && p->mel_mode != 0 && p->mel_mode != 3) ? "true" : "false", with_bands ? "true" : "false");
+        snprintf(out, (size_t)capacity, "k_wav_to_mel<%d,%d,%s,%s,1,%s>", p->log2n, p->mel_mode,
+                 (p->need_hi && p->mel_mode != 0 && p->mel_mode != 3) ? "true" : "false", with_bands ? "true" : "false",
+                 p->epilogue == IRIS_EPILOGUE_FUSED ? "true" : "false");
     return IRIS_OK;
 }
 

@@ -302,3 +302,152 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool_nchw(const float* x, con
     float* o = y + (((size_t)b * Ho + ho) * Wo + wo0) * C;  // [n_w][C] contiguous
     for (int i = threadIdx.x; i < n_w * C; i += blockDim.x) o[i] = tile[(i / C) * (C + 1) + (i % C)];
 }
+
+// ---------------------------------------------------------------------------
+// Training-mode Conv2D bias + BatchNormalization + ReLU of ConvMPBlock (sj_train.py:191-201) in two passes each way, on the
+// channels-last convolution output z [rows = N H W, C] (the convolution itself stays MIOpen; its bias is NOT added by a
+// separate pass: batch normalisation subtracts the batch mean, so y does not depend on the bias - it only shifts the
+// running mean, which is accounted for here - and its gradient is identically zero):
+//   forward   k_bn_stats        per-channel sum, sum of squares of z (fp32 per thread over <= 64 rows, fp64 atomics per block)
+//             k_bn_relu_apply   y = max(gamma (z - mean) rstd + beta, 0); block 0 updates the running statistics
+//   backward  k_bn_reduce<true>      g = dy [y > 0]; sum g, sum g xhat per channel (same reduction scheme)
+//             k_bn_relu_bwd_dx       dz = gamma rstd (g - sum_g / M - xhat sum_gx / M); block 0 writes dgamma, dbeta
+// Instead of bias add, mean / variance, normalise, ReLU (7 passes over the activation) and ReLU', dscale / dbias, dx, bias
+// gradient (9 passes): 3 forward (read, read + write) and 5 backward (z and dy read twice, dz written; y is never read).  Thread layout: a block of 256 threads covers kBnRows rows x (C / 4) float4 columns.
+// ---------------------------------------------------------------------------
+constexpr int kBnRows = 64;  // rows per thread-row pass
+
+// (backward: the ReLU mask [y > 0] is recomputed from z with the forward's own scale / shift - bit-identical to testing
+// the stored y - so that y is not read at all)
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_bn_reduce(const float* z, const float* dy, size_t rows, int C4, const float* mean,
+                                                   const float* rstd, const float* gamma, const float* beta,
+                                                   double* sums /*[2][4 C4]*/) {
+    // threads: tx = threadIdx.x % C4g walks the float4 columns (C4g = min(C4, 256) columns per pass), ty the rows
+    extern __shared__ float red[];  // [ty][2][4 * cols]
+    const int cols = min(C4, 256), tys = 256 / cols;
+    const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    const float4* d4 = reinterpret_cast<const float4*>(dy);
+    for (int c0 = 0; c0 < C4; c0 += cols) {
+        const int c = c0 + tx;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        float4 mu = s0, rs = s0, sc = s0, sh = s0;
+        if (BWD && c < C4) {
+            mu = reinterpret_cast<const float4*>(mean)[c];
+            rs = reinterpret_cast<const float4*>(rstd)[c];
+            const float4 ga = reinterpret_cast<const float4*>(gamma)[c], be = reinterpret_cast<const float4*>(beta)[c];
+            sc = make_float4(ga.x * rs.x, ga.y * rs.y, ga.z * rs.z, ga.w * rs.w);  // as k_bn_relu_apply forms them
+            sh = make_float4(be.x - mu.x * sc.x, be.y - mu.y * sc.y, be.z - mu.z * sc.z, be.w - mu.w * sc.w);
+        }
+        const size_t r_begin = (size_t)blockIdx.x * kBnRows * tys, r_end = min(r_begin + (size_t)kBnRows * tys, rows);
+        if (c < C4 && ty < tys) {
+            for (size_t r = r_begin + ty; r < r_end; r += tys) {
+                const float4 v = z4[r * C4 + c];
+                if constexpr (!BWD) {
+                    s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+                    s1.x = fmaf(v.x, v.x, s1.x); s1.y = fmaf(v.y, v.y, s1.y); s1.z = fmaf(v.z, v.z, s1.z); s1.w = fmaf(v.w, v.w, s1.w);
+                } else {
+                    const float4 d = d4[r * C4 + c];
+                    const float gx = fmaf(v.x, sc.x, sh.x) > 0.f ? d.x : 0.f, gy = fmaf(v.y, sc.y, sh.y) > 0.f ? d.y : 0.f;
+                    const float gz = fmaf(v.z, sc.z, sh.z) > 0.f ? d.z : 0.f, gw = fmaf(v.w, sc.w, sh.w) > 0.f ? d.w : 0.f;
+                    s0.x += gx; s0.y += gy; s0.z += gz; s0.w += gw;
+                    s1.x = fmaf(gx, (v.x - mu.x) * rs.x, s1.x); s1.y = fmaf(gy, (v.y - mu.y) * rs.y, s1.y);
+                    s1.z = fmaf(gz, (v.z - mu.z) * rs.z, s1.z); s1.w = fmaf(gw, (v.w - mu.w) * rs.w, s1.w);
+                }
+            }
+        }
+        __syncthreads();
+        if (ty < tys) {
+            float* p = red + ((size_t)ty * 2 * cols + tx) * 4;
+            p[0] = s0.x; p[1] = s0.y; p[2] = s0.z; p[3] = s0.w;
+            float* q = p + (size_t)cols * 4;
+            q[0] = s1.x; q[1] = s1.y; q[2] = s1.z; q[3] = s1.w;
+        }
+        __syncthreads();
+        // fold the tys row-threads: 2 * 4 * cols values, one per thread (cols <= 256 -> up to 2048 values: loop)
+        for (int i = threadIdx.x; i < 2 * 4 * cols; i += blockDim.x) {
+            const int which = i / (4 * cols), j = i - which * 4 * cols;  // j = tx * 4 + component
+            double acc = 0.0;
+            for (int t = 0; t < tys; ++t) acc += (double)red[((size_t)t * 2 * cols) * 4 + (size_t)which * cols * 4 + j];
+            const int cc = c0 * 4 + j;
+            if (cc < 4 * C4) atomicAdd(sums + (size_t)which * 4 * C4 + cc, acc);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_relu_apply(const float* z, float* y, size_t n_vec4, int C4, double inv_m, double unbias,
+                                                       const double* sums, const float* gamma, const float* beta,
+                                                       const float* conv_bias, float eps, float momentum, float* running_mean,
+                                                       float* running_var, float* save_mean, float* save_rstd) {
+    extern __shared__ float coef[];  // [2][C]: scale = gamma rstd, shift = beta - mean scale  (y = max(z scale + shift, 0))
+    const int C = 4 * C4;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double m = sums[c] * inv_m, var = fmax(sums[C + c] * inv_m - m * m, 0.0);
+        const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+        coef[c] = gamma[c] * rs;
+        coef[C + c] = beta[c] - mu * (gamma[c] * rs);
+        if (blockIdx.x == 0) {  // statistics for backward and the running estimates (unbiased variance, Keras / torch rule)
+            save_mean[c] = mu;
+            save_rstd[c] = rs;
+            const float bias = conv_bias ? conv_bias[c] : 0.f;  // the convolution's bias only moves the mean
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (mu + bias);
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+        }
+    }
+    __syncthreads();
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    const float4* sc4 = reinterpret_cast<const float4*>(coef);
+    const float4* sh4 = reinterpret_cast<const float4*>(coef + C);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const float4 v = z4[i], sc = sc4[c], sh = sh4[c];
+        float4 r;
+        r.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+        r.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+        r.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+        r.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        y4[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_relu_bwd_dx(const float* z, const float* dy, float* dz, size_t n_vec4, int C4,
+                                                        float inv_m, const float* mean, const float* rstd, const float* gamma,
+                                                        const float* beta, const double* sums, float* dgamma, float* dbeta) {
+    // dz = a g + b z + d  with  a = gamma rstd,  b = -a rstd sum_gx / M,  d = -a sum_g / M - b mean   (per channel);
+    // g = dy where z a + (beta - mean a) > 0 (the forward's expression: the stored y is not read)
+    extern __shared__ float coef[];  // [4][C]
+    const int C = 4 * C4;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float sg = (float)sums[c], sgx = (float)sums[C + c];
+        const float a = gamma[c] * rstd[c], b = -a * rstd[c] * sgx * inv_m;
+        coef[c] = a;
+        coef[C + c] = b;
+        coef[2 * C + c] = -a * sg * inv_m - b * mean[c];
+        coef[3 * C + c] = beta[c] - mean[c] * a;
+        if (blockIdx.x == 0) {
+            dbeta[c] = sg;
+            dgamma[c] = sgx;
+        }
+    }
+    __syncthreads();
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    const float4* d4 = reinterpret_cast<const float4*>(dy);
+    float4* o4 = reinterpret_cast<float4*>(dz);
+    const float4* a4 = reinterpret_cast<const float4*>(coef);
+    const float4* b4 = reinterpret_cast<const float4*>(coef + C);
+    const float4* c4 = reinterpret_cast<const float4*>(coef + 2 * C);
+    const float4* h4 = reinterpret_cast<const float4*>(coef + 3 * C);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const float4 v = z4[i], d = d4[i], a = a4[c], b = b4[c], k = c4[c], h = h4[c];
+        float4 r;
+        r.x = fmaf(a.x, fmaf(v.x, a.x, h.x) > 0.f ? d.x : 0.f, fmaf(b.x, v.x, k.x));
+        r.y = fmaf(a.y, fmaf(v.y, a.y, h.y) > 0.f ? d.y : 0.f, fmaf(b.y, v.y, k.y));
+        r.z = fmaf(a.z, fmaf(v.z, a.z, h.z) > 0.f ? d.z : 0.f, fmaf(b.z, v.z, k.z));
+        r.w = fmaf(a.w, fmaf(v.w, a.w, h.w) > 0.f ? d.w : 0.f, fmaf(b.w, v.w, k.w));
+        o4[i] = r;
+    }
+}

@@ -494,6 +494,66 @@ class FusedAGC:
 # ---------------------------------------------------------------------------
 # model                                                     sj_train.py:191-255
 # ---------------------------------------------------------------------------
+# Training-mode Conv2D bias + BatchNorm + ReLU through the HIP kernels iris_bn_* (two passes over the activation each way
+# instead of seven forward / nine backward); IRIS_FUSED_BN=0 keeps the stock torch / MIOpen ops.
+FUSED_BN_RELU = os.environ.get("IRIS_FUSED_BN", "1") != "0"
+
+
+class _FusedBiasBNReLU(torch.autograd.Function):
+    """y = relu(batch_norm(z + conv_bias)) in training mode on a channels_last fp32 convolution output z (sj_train.py:191-201).
+    The bias never touches the activation: batch normalisation subtracts the batch mean, so y does not depend on it (it
+    only shifts the running mean, which iris_bn_relu_apply accounts for) and its gradient is identically zero."""
+
+    @staticmethod
+    def forward(ctx, z, conv_bias, gamma, beta, running_mean, running_var, eps, momentum):
+        import ctypes as C
+        from . import _native as N
+        c = int(z.shape[1])
+        rows = z.numel() // c
+        dev = z.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        sums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+        y = torch.empty_like(z)  # preserves channels_last
+        save_mean = torch.empty(c, dtype=torch.float32, device=dev)
+        save_rstd = torch.empty(c, dtype=torch.float32, device=dev)
+        lib = N.lib()
+        with torch.cuda.device(dev):
+            N.check(lib.iris_bn_stats(z.data_ptr(), rows, c, sums.data_ptr(), stream), "iris_bn_stats")
+            N.check(lib.iris_bn_relu_apply(z.data_ptr(), y.data_ptr(), rows, c, sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           conv_bias.data_ptr() if conv_bias is not None else None, float(eps), float(momentum),
+                                           running_mean.data_ptr(), running_var.data_ptr(), save_mean.data_ptr(),
+                                           save_rstd.data_ptr(), stream), "iris_bn_relu_apply")
+        ctx.save_for_backward(z, gamma, beta, save_mean, save_rstd)  # y is not needed: the mask is recomputed from z
+        ctx.has_bias = conv_bias is not None
+        ctx.mark_non_differentiable(running_mean, running_var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        from . import _native as N
+        z, gamma, beta, save_mean, save_rstd = ctx.saved_tensors
+        c = int(z.shape[1])
+        rows = z.numel() // c
+        dev = z.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        sums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        lib = N.lib()
+        with torch.cuda.device(dev):
+            N.check(lib.iris_bn_relu_bwd_reduce(z.data_ptr(), dy.data_ptr(), rows, c, save_mean.data_ptr(), save_rstd.data_ptr(),
+                                                gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), stream), "iris_bn_relu_bwd_reduce")
+            N.check(lib.iris_bn_relu_bwd_dx(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, c, save_mean.data_ptr(),
+                                            save_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(),
+                                            dgamma.data_ptr(), dbeta.data_ptr(), stream), "iris_bn_relu_bwd_dx")
+        dbias = torch.zeros(c, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        return dz, dbias, dgamma, dbeta, None, None, None, None
+
+
 class _ConvBNReLU(nn.Sequential):
     def __init__(self, cin, cout, k=3, bn=True):
         layers = [nn.Conv2d(cin, cout, k, padding=k // 2)]
@@ -501,6 +561,19 @@ class _ConvBNReLU(nn.Sequential):
             layers.append(nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01))  # Keras BN defaults
         layers.append(nn.ReLU(inplace=True))
         super().__init__(*layers)
+
+    def forward(self, x):
+        if (FUSED_BN_RELU and self.training and x.is_cuda and len(self) == 3 and isinstance(self[1], nn.BatchNorm2d)
+                and not torch.is_autocast_enabled()):
+            conv, bn = self[0], self[1]
+            if x.dtype == torch.float32 and conv.out_channels % 4 == 0 and bn.track_running_stats and bn.momentum is not None:
+                z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+                if z.is_contiguous(memory_format=torch.channels_last):
+                    bn.num_batches_tracked.add_(1)
+                    return _FusedBiasBNReLU.apply(z, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                  bn.eps, bn.momentum)
+                return self[2](bn(z + conv.bias.view(1, -1, 1, 1) if conv.bias is not None else z))
+        return super().forward(x)
 
 
 class ConvMPBlock(nn.Module):

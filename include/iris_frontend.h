@@ -133,7 +133,7 @@ int iris_plan_set_epilogue(iris_plan* plan, int mode);
 int iris_plan_status(iris_plan* plan, int* status_out);
 
 /* Name of the fused kernel iris_wav_to_logmel launches for this plan (with / without SpecAugment bands), as rocprofv3
- * prints it without the argument list, e.g. "k_wav_to_mel<10,0,false,false,1>"; HOST buffer. */
+ * prints it without the argument list, e.g. "k_wav_to_mel<10,0,false,false,1,true>" (last flag: min-max / log epilogue inside the kernel); HOST buffer. */
 int iris_plan_kernel_name(const iris_plan* plan, int with_bands, char* out_host, int capacity);
 /* Copy the plan's mel matrix [n_bins*n_mel] to HOST memory. */
 int iris_plan_get_mel(const iris_plan* plan, float* out_host);
@@ -257,6 +257,31 @@ int iris_bias_relu_maxpool_nchw(const float* x, const float* bias, float* y, int
                                 void* stream);
 int iris_bias_relu_maxpool(const float* x, const float* bias, float* y, int batch, int height, int width, int channels,
                            void* stream);
+
+/*
+ * Training-mode Conv2D bias + BatchNormalization + ReLU of ConvMPBlock (sj_train.py:191-201; Keras BatchNormalization
+ * momentum 0.99 / epsilon 1e-3 = torch momentum 0.01) on the channels-last convolution output z [rows = N H W, channels]
+ * in two passes each way instead of MIOpen's / ATen's seven forward and nine backward (bias add, mean / variance,
+ * normalise, ReLU; ReLU', dscale / dbias, dx, bias gradient).  The convolution stays MIOpen and is run WITHOUT bias:
+ * batch normalisation removes the batch mean, so the output does not depend on the bias - it only shifts the running
+ * mean (conv_bias, nullable, is added there) - and the bias gradient is identically zero.
+ *   forward : iris_bn_stats (sums_zeroed: DEVICE double [2 * channels], zero on entry: per-channel sum, sum of squares)
+ *             iris_bn_relu_apply: y = max(gamma (z - mean) rstd + beta, 0), biased variance; running_mean / running_var
+ *             updated in place ((1 - momentum) old + momentum new, unbiased variance); save_mean / save_rstd [channels] out
+ *   backward: iris_bn_relu_bwd_reduce (sums_zeroed [2 * channels]: sum g, sum g xhat with g = dy [y > 0]; the mask is
+ *             recomputed from z with the forward's own expression, y is not read)
+ *             iris_bn_relu_bwd_dx: dz = gamma rstd (g - sum_g / M - xhat sum_gx / M); dgamma = sum g xhat, dbeta = sum g
+ * channels: a multiple of 4, <= 4096; every pointer DEVICE, 16-byte aligned tensors.  Run on the current HIP device.
+ */
+int iris_bn_stats(const float* z, size_t rows, int channels, double* sums_zeroed, void* stream);
+int iris_bn_relu_apply(const float* z, float* y, size_t rows, int channels, const double* sums, const float* gamma,
+                       const float* beta, const float* conv_bias, float eps, float momentum, float* running_mean,
+                       float* running_var, float* save_mean, float* save_rstd, void* stream);
+int iris_bn_relu_bwd_reduce(const float* z, const float* dy, size_t rows, int channels, const float* save_mean,
+                            const float* save_rstd, const float* gamma, const float* beta, double* sums_zeroed, void* stream);
+int iris_bn_relu_bwd_dx(const float* z, const float* dy, float* dz, size_t rows, int channels, const float* save_mean,
+                        const float* save_rstd, const float* gamma, const float* beta, const double* sums, float* dgamma,
+                        float* dbeta, void* stream);
 
 /*
  * Sample synthesis in the complex-STFT domain, deterministic half of

@@ -812,6 +812,44 @@ def test_bias_relu_epilogues_match_torch(dev):
                               torch.zeros(6, device=dev))
 
 
+def test_fused_bn_relu_training_matches_torch(dev, monkeypatch):
+    """iris_bn_* behind _ConvBNReLU in training mode: outputs, every gradient (input, convolution weight, BatchNorm scale /
+    shift) and the running statistics equal the stock torch / MIOpen ops on the same parameters (fp32, different summation
+    orders only); the convolution bias gets an exact zero gradient (its true gradient is zero: BatchNorm removes the mean)."""
+    import copy
+    from challenge_amd import sj_train as S
+    S.configure_miopen()
+    torch.manual_seed(4)
+    for cin, cout, b, h, w in [(1, 32, 3, 16, 40), (32, 64, 2, 9, 7), (64, 512, 2, 4, 5)]:
+        blk = S._ConvBNReLU(cin, cout).to(dev).to(memory_format=torch.channels_last).train()
+        with torch.no_grad():
+            blk[1].weight.uniform_(0.5, 1.5)
+            blk[1].bias.uniform_(-0.3, 0.3)
+            blk[1].running_mean.uniform_(-0.2, 0.2)
+            blk[1].running_var.uniform_(0.5, 1.5)
+            blk[0].bias.uniform_(-0.5, 0.5)
+        ref = copy.deepcopy(blk)
+        x = torch.randn(b, cin, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        g = torch.randn(b, cout, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        monkeypatch.setattr(S, "FUSED_BN_RELU", True)
+        ya = blk(xa)
+        ya.backward(g)
+        monkeypatch.setattr(S, "FUSED_BN_RELU", False)
+        yb = ref(xb)
+        yb.backward(g)
+        tol = lambda t: 2e-5 * float(t.abs().max()) + 1e-6  # noqa: E731
+        assert float((ya - yb).abs().max()) <= tol(yb)
+        assert float((xa.grad - xb.grad).abs().max()) <= tol(xb.grad) * 5
+        assert float((blk[0].weight.grad - ref[0].weight.grad).abs().max()) <= tol(ref[0].weight.grad) * 5
+        assert float((blk[1].weight.grad - ref[1].weight.grad).abs().max()) <= tol(ref[1].weight.grad) * 5
+        assert float((blk[1].bias.grad - ref[1].bias.grad).abs().max()) <= tol(ref[1].bias.grad) * 5
+        assert float(blk[0].bias.grad.abs().max()) == 0.0 and float(ref[0].bias.grad.abs().max()) <= 1e-4 * float(g.abs().sum())
+        assert float((blk[1].running_mean - ref[1].running_mean).abs().max()) <= 1e-6
+        assert float((blk[1].running_var - ref[1].running_var).abs().max()) <= 1e-6
+        assert int(blk[1].num_batches_tracked) == int(ref[1].num_batches_tracked) == 1
+
+
 def test_inference_engine_matches_module(dev):
     """InferenceEngine (BatchNorm folded, conv + HIP bias/ReLU/pool epilogue, frontend + forward as one hipGraph) is the
     same function as the training module in eval mode: <= 1e-4 on the sigmoid outputs, eager and replayed."""
