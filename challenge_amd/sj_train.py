@@ -971,8 +971,10 @@ def wrap_ddp(model: CustomModel, device, world: int):
     if world <= 1:
         return None
     from torch.nn.parallel import DistributedDataParallel as DDP
+    # ONE collective per step - the bucketed gradient all-reduce: BatchNorm statistics stay per replica (the reference has
+    # no multi-GPU at all; rank 0's are the ones checkpointed), so the per-forward buffer broadcast is switched off
     return DDP(model, device_ids=[device.index] if device.type == 'cuda' else None,
-               bucket_cap_mb=25, gradient_as_bucket_view=True)
+               bucket_cap_mb=25, gradient_as_bucket_view=True, broadcast_buffers=False)
 
 
 def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=None, validation_steps=16,
