@@ -1,23 +1,23 @@
-// k_fused.h -- K1, the fused hot path: waveform -> mel magnitudes in one kernel.
+// k_fused.h -- K1, the fused hot path: waveform -> (log-)mel in one kernel.
 // Part of the single translation unit iris_frontend.hip.
 #pragma once
 // ---------------------------------------------------------------------------
-// K1: fused wav -> mel magnitudes (+ per-wave min/max partials)
+// K1: fused wav -> mel magnitudes -> (FUSE) per-sample min-max and log, or (!FUSE) per-wave min/max partials for K2
 //   work unit = chunk: consecutive frames of one clip, all C channels
 //   grid      = min(#chunks, #CUs) workgroups looping over chunks; one workgroup per CU with every
-//               wave the registers allow (16 at n_fft <= 512, 12 at 1024, 8 at 2048)
+//               wave the registers allow (16 at n_fft <= 1024, 12 with SpecAugment bands at 1024 and at 2048, 8
+//               for the other 2048 variants: fused_waves)
 //   per wave  = one frame at a time, claimed from the chunk's LDS queue, software-pipelined:
 //                 frame i is windowed, transformed (registers + private padded LDS exchanges),
 //                 untangled with the magnitude fused in, |X| goes to LDS; then - its sample
 //                 registers now dead - frame i+1 is loaded into them straight from global memory
 //                 and frame i+2 claimed, both in flight behind the banded mel reduction of frame i;
-//                 lane m stores band m of the frame straight to out[b, m, t, c] (the L2 merges the
-//                 4-byte stores).  n_fft 2048 has no registers to spare and lands frames by
-//                 LDS-DMA (global_load_lds) instead.
-//   LDS       = landing buffers [waves][N floats] (LDS-DMA targets; with direct loads only the
-//               staging area of the constant block) | exchange buffers [waves] (also |X|) | frame
-//               queue | mel table (mode 1) | time-band bitmap (BANDS); after the prologue the waves
-//               share nothing but the queue
+//                 lane m puts band m of the frame into the chunk's LDS tile (FUSE) or stores it straight to
+//                 out[b, m, t, c] (the L2 merges the 4-byte stores).
+//   LDS       = staging area of the constant block (re-read at the top of every chunk by the FUSE variants) |
+//               exchange buffers [waves] (also |X|) | frame queue | mel table (mode 1) | time-band bitmap (BANDS) |
+//               mel tile [M][pitch] + reduction scratch (FUSE); between prologue and epilogue the waves share
+//               nothing but the queue
 //   MELMODE 0 = band weights in registers (M <= 64, aligned band span <= 20, half spectrum): each lane
 //               reads a 16-byte-aligned window of 20 magnitudes with 5 ds_read_b128
 //           3 = band weights in registers, two bands per lane (64 < M <= 128, aligned band span <= 8
@@ -654,8 +654,8 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
         } else {
             // Fused epilogue: the chunk's mel values sit in the LDS tile.  Workgroup range -> (clips split over several
             // workgroups) one 8-byte {epoch, value} granule each for min and max, published with agent-scope stores and
-            // swept by wave 0 until every chunk of the clip carries this launch's epoch -> (x - min) / max(max - min,
-            // 1e-8), ln(x + 1e-8) -> coalesced rows of out[b, m, t0 .. t0 + nt, :].  Every workgroup publishes before
+            // swept by wave 0 until every chunk of the clip carries this launch's epoch -> minmax_log_value: (x - min) *
+            // (1 / max(max - min, 1e-8)), ln(x + 1e-8) -> coalesced rows of out[b, m, t0 .. t0 + nt, :].  Every workgroup publishes before
             // it waits and all workgroups of the grid are resident (grid <= CUs), so the waits always complete; the
             // sweep is bounded all the same (status word + NaN output instead of a hang).
             float* red = tile + (size_t)a.M * a.pitch;  // [2 * waves + 4]
