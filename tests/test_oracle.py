@@ -401,3 +401,19 @@ def test_philox_known_answers_and_stream_permutation():
     assert below.min() == 0 and below.max() == 22 and abs(below.mean() - 11.0) < 0.5
     unit = np.array([R.draw_unit(w) for w in words])
     assert 0.0 <= unit.min() and unit.max() < 1.0 and abs(unit.mean() - 0.5) < 0.02
+
+
+def test_mel_matrix_against_an_independent_implementation():
+    """The mel matrix stays unpinned by TensorFlow itself (not installable here).  What this image does hold is an
+    independent implementation of the same published recipe - HTK mel scale, triangles drawn in mel space - in the
+    `transformers` wheel (audio_utils.mel_filter_bank, float64): same support (231 / 461 / 676 non-zeros, the counts
+    SURVEY.md section 8 R3 records), values within the 2e-5 that the fp32-vs-fp64 evaluation of the recipe moves them.
+    A cross-check between two restatements, not a TensorFlow fixture (tests/golden/tf_mel_*.npz would be that)."""
+    tf_utils = pytest.importorskip("transformers.audio_utils")
+    for m, f, sr, nnz in [(80, 257, 16000, 231), (64, 513, 16000, 461), (128, 1025, 22050, 676)]:
+        w = R.linear_to_mel_weight_matrix(m, f, sr)
+        h = tf_utils.mel_filter_bank(num_frequency_bins=f, num_mel_filters=m, min_frequency=125.0, max_frequency=3800.0,
+                                     sampling_rate=sr, norm=None, mel_scale="htk", triangularize_in_mel_space=True)
+        assert h.shape == w.shape and int((w != 0).sum()) == nnz
+        assert np.array_equal(w != 0, h > 1e-12)
+        assert np.abs(w - h).max() <= 2e-5
