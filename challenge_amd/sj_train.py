@@ -917,12 +917,16 @@ def binary_crossentropy(y_true, y_pred):
 
 
 def make_optimizer(config, params):
+    params = list(params)
+    # foreach=True on a GPU: the update AND zero_grad run as a handful of multi-tensor kernels instead of one per
+    # parameter (86 fills of ~3.6 us each per step otherwise)
+    fe = bool(params) and params[0].is_cuda
     if config.optimizer == 'adam':
-        return torch.optim.Adam(params, lr=config.lr, eps=1e-7)  # Keras Adam epsilon
+        return torch.optim.Adam(params, lr=config.lr, eps=1e-7, foreach=fe)  # Keras Adam epsilon
     if config.optimizer == 'sgd':
-        return torch.optim.SGD(params, lr=config.lr, momentum=0.9)
+        return torch.optim.SGD(params, lr=config.lr, momentum=0.9, foreach=fe)
     if config.optimizer == 'rmsprop':
-        return torch.optim.RMSprop(params, lr=config.lr, momentum=0.9, alpha=0.9, eps=1e-7)
+        return torch.optim.RMSprop(params, lr=config.lr, momentum=0.9, alpha=0.9, eps=1e-7, foreach=fe)
     raise ValueError('adabelief is deprecated')
 
 
