@@ -458,6 +458,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (batch sweep, cache-resident replay, c3 forward, c4 training step)")
     ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--extras-limit", type=float, default=600.0,
+                    help="seconds the side measurements may take before the line is printed without them")
     ap.add_argument("--only-sweep", action="store_true", help="of the side measurements, run only the K1 batch sweep (A/B runs)")
     ap.add_argument("--resident", action="store_true",
                     help="replay ONE batch every step (Infinity-Cache resident, as round 1 measured) instead of rotating")
@@ -597,6 +599,65 @@ def main():
         result["ranks"] = ranks
         result["rccl_world"] = dist.get_world_size()
         result["backend"] = backend
+    import threading
+    done_lock, done = threading.Lock(), []
+    # what the final line needs from the device is fetched now: finish() may run while the GPU is stuck
+    kernel_name = plan.fused_kernel_name()
+    cpu_input = wavs[0].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+
+    def finish(extras):
+        """Rank 0: assemble and print the ONE JSON line (once: the watchdog below may get here first)."""
+        with done_lock:
+            if done or rank != 0:
+                return
+            done.append(True)
+            if extras:
+                result["extra"] = extras
+                if "c3_best_fp32_audio_s_per_s" in extras:
+                    result["stft_mel_fwd_audio_s_per_s"] = extras["c3_best_fp32_audio_s_per_s"]
+            algo_bytes = ALGO_BYTES_PER_AUDIO_S * audio_s_per_step  # per launch
+            traffic, step_traffic, traffic_note = committed_traffic()
+            step_gbs = algo_bytes / (elapsed / args.steps) / 1e9
+            roof = {
+                "bound": "hbm", "kernel": kernel_name, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": None, "traffic": traffic, "step_traffic": step_traffic, "traffic_source": traffic_note,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                # whole step (every kernel of the step + the boundaries between them) against the same bytes
+                "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                "how": f"kernel-timing pass after the timed region: {KERNEL_PASS} rotating steps with a HIP event pair around each "
+                       "kernel on the launch stream (hipExtLaunchKernel); `achieved` = algorithmic bytes / MEAN duration of the "
+                       "dominant kernel.  Such a pair reads marker-end -> kernel-end, i.e. the dispatch gap in front of the kernel "
+                       "is inside it: 1-2 us above rocprofv3's duration of the same kernel (profiles/r3/), so `frac` errs low",
+            }
+            if len(k1):
+                kernel_ms, k2_ms = float(k1.mean()), (float(k2.mean()) if len(k2) else 0.0)
+                roof.update({"kernel_ms": round(kernel_ms, 5), "kernel_ms_median": round(float(np.median(k1)), 5),
+                             "kernel_ms_min": round(float(k1.min()), 5), "launches_timed": int(len(k1)),
+                             "second_kernel": "k_minmax_log_apply" if len(k2) else None,
+                             "second_kernel_ms": round(k2_ms, 5) if len(k2) else None,
+                             "second_kernel_ms_median": round(float(np.median(k2)), 5) if len(k2) else None})
+                if kernel_ms + k2_ms <= ms_per_step * 1.05 + 0.004:  # the event reading carries up to ~2 us of dispatch gap per kernel
+                    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+                    roof["achieved"], roof["frac"] = round(achieved, 1), round(achieved / HBM_PEAK_GBS, 4)
+                else:
+                    roof["frac_withheld"] = (f"kernel_ms {kernel_ms:.5f} + second_kernel_ms {k2_ms:.5f} exceed ms_per_step "
+                                             f"{ms_per_step:.5f} x 1.05: inconsistent, no fraction reported")
+            roof["two_kernel_form"] = two
+            result["roofline"] = roof
+            if cpu_input is not None:
+                result["cpu_baseline"] = cpu_baseline(cpu_input)
+            print(json.dumps(result), flush=True)
+
+    # A side measurement that hangs (one rank failing inside a collective while the others wait) must not take the
+    # headline down with it: after --extras-limit seconds rank 0 prints the line without the extras and every rank leaves.
+    def abandon():
+        print(f"bench.py: rank {rank}: side measurements exceeded {args.extras_limit} s, abandoned", file=sys.stderr, flush=True)
+        finish({"error": f"side measurements exceeded {args.extras_limit} s and were abandoned"})
+        os._exit(0)
+    timer = threading.Timer(args.extras_limit, abandon)
+    timer.daemon = True
+    if not args.no_extras:
+        timer.start()
     extras = None
     if args.only_sweep and world == 1:
         extras = {"k1_batch_sweep": batch_sweep(dev, fence, max(args.extra_steps, 20))}
@@ -634,43 +695,8 @@ def main():
             plan.timing_enable(False)
             extras["c2_cache_resident_replay"] = {"k1_us": round(1e3 * float(kr.mean()), 2) if len(kr) else None,
                                                   "step_us": round(1e6 * dt, 2)}
-    if rank == 0:
-        if extras:
-            result["extra"] = extras
-            if "c3_best_fp32_audio_s_per_s" in extras:
-                result["stft_mel_fwd_audio_s_per_s"] = extras["c3_best_fp32_audio_s_per_s"]
-        algo_bytes = ALGO_BYTES_PER_AUDIO_S * audio_s_per_step  # per launch
-        traffic, step_traffic, traffic_note = committed_traffic()
-        step_gbs = algo_bytes / (elapsed / args.steps) / 1e9
-        roof = {
-            "bound": "hbm", "kernel": plan.fused_kernel_name(), "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": None, "traffic": traffic, "step_traffic": step_traffic, "traffic_source": traffic_note,
-            "algorithmic_bytes_per_launch": algo_bytes,
-            # whole step (every kernel of the step + the boundaries between them) against the same bytes
-            "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
-            "how": f"kernel-timing pass after the timed region: {KERNEL_PASS} rotating steps with a HIP event pair around each "
-                   "kernel on the launch stream (hipExtLaunchKernel); `achieved` = algorithmic bytes / MEAN duration of the "
-                   "dominant kernel.  Such a pair reads marker-end -> kernel-end, i.e. the dispatch gap in front of the kernel "
-                   "is inside it: 1-2 us above rocprofv3's duration of the same kernel (profiles/r3/), so `frac` errs low",
-        }
-        if len(k1):
-            kernel_ms, k2_ms = float(k1.mean()), (float(k2.mean()) if len(k2) else 0.0)
-            roof.update({"kernel_ms": round(kernel_ms, 5), "kernel_ms_median": round(float(np.median(k1)), 5),
-                         "kernel_ms_min": round(float(k1.min()), 5), "launches_timed": int(len(k1)),
-                         "second_kernel": "k_minmax_log_apply" if len(k2) else None,
-                         "second_kernel_ms": round(k2_ms, 5) if len(k2) else None,
-                         "second_kernel_ms_median": round(float(np.median(k2)), 5) if len(k2) else None})
-            if kernel_ms + k2_ms <= ms_per_step * 1.05 + 0.004:  # the event reading carries up to ~2 us of dispatch gap per kernel
-                achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-                roof["achieved"], roof["frac"] = round(achieved, 1), round(achieved / HBM_PEAK_GBS, 4)
-            else:
-                roof["frac_withheld"] = (f"kernel_ms {kernel_ms:.5f} + second_kernel_ms {k2_ms:.5f} exceed ms_per_step "
-                                         f"{ms_per_step:.5f} x 1.05: inconsistent, no fraction reported")
-        roof["two_kernel_form"] = two
-        result["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(wavs[0].cpu().numpy())
-        print(json.dumps(result), flush=True)
+    timer.cancel()
+    finish(extras)
     if world > 1:
         dist.destroy_process_group()
 

@@ -906,3 +906,21 @@ def test_bench_self_launch_two_ranks(dev):
     # the N > 1 line audits itself: who ran where, and how many ranks the collective backend saw
     assert res["rccl_world"] == 2 and [r["rank"] for r in res["ranks"]] == [0, 1]
     assert all(r["value"] > 0 and "device" in r for r in res["ranks"])
+
+
+def test_bench_line_survives_stuck_side_measurements(dev):
+    """The side measurements run under a watchdog: when they do not finish within --extras-limit the headline line is
+    still printed (with the reason in `extra.error`) and every rank leaves with exit code 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["IRIS_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--extras-limit", "0.2"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "abandoned" in res["extra"]["error"]
+    assert res["roofline"]["launches_timed"] >= 50 and res["rccl_world"] == 2
