@@ -78,6 +78,40 @@ def test_argument_validation_without_gpu():
     assert lib.iris_mix_wave_frame_active(p8, 1, 100, 1024, 0, p8, None) == -1
 
 
+def test_round3_entry_points_validate_before_any_launch():
+    """bias/ReLU epilogues, BatchNorm passes, device-side draws, epilogue mode and the timing sampler reject NULL,
+    misaligned and out-of-range arguments before any HIP call (error codes of include/iris_frontend.h)."""
+    lib = N.lib()
+    p16, p8 = C.c_void_p(16), C.c_void_p(8)
+    INVALID, UNSUPPORTED = -1, -2
+    assert lib.iris_bias_relu(None, p16, 4, 8, None) == INVALID
+    assert lib.iris_bias_relu(p16, p16, 4, 6, None) == UNSUPPORTED            # channels not a multiple of 4
+    assert lib.iris_bias_relu(p8, p16, 4, 8, None) == INVALID                 # 16-byte alignment
+    assert lib.iris_bias_relu(p16, p16, 0, 8, None) == 0                      # empty: nothing to do, no launch
+    assert lib.iris_bias_relu_maxpool(p16, p16, None, 1, 4, 4, 8, None) == INVALID
+    assert lib.iris_bias_relu_maxpool(p16, p16, p16, 1, 4, 4, 7, None) == UNSUPPORTED
+    assert lib.iris_bias_relu_maxpool(p16, p16, p16, 0, 4, 4, 8, None) == INVALID
+    assert lib.iris_bias_relu_nchw(p16, None, 4, 8, 64, None) == INVALID
+    assert lib.iris_bias_relu_nchw(p16, p16, 4, 8, 6, None) == UNSUPPORTED    # inner size not a multiple of 4
+    assert lib.iris_bias_relu_maxpool_nchw(p16, p16, None, 1, 4, 4, 8, None) == INVALID
+    assert lib.iris_bias_relu_maxpool_nchw(p16, p16, p16, 1, 0, 4, 8, None) == INVALID
+    assert lib.iris_bn_stats(None, 16, 8, p16, None) == INVALID
+    assert lib.iris_bn_stats(p16, 16, 6, p16, None) == UNSUPPORTED
+    assert lib.iris_bn_stats(p16, 16, 8192, p16, None) == UNSUPPORTED         # more than 4096 channels
+    assert lib.iris_bn_relu_apply(None, None, 16, 8, None, None, None, None, 1e-3, 0.01, None, None, None, None, None) == INVALID
+    assert lib.iris_bn_relu_bwd_reduce(None, p16, 16, 8, p16, p16, p16, p16, p16, None) == INVALID
+    assert lib.iris_bn_relu_bwd_dx(None, p16, p16, 16, 8, p16, p16, p16, p16, p16, p16, p16, None) == INVALID
+    assert lib.iris_mix_draw(None, None, None, 1, 64, 4, 4, 0.5, 1.0, 1.0, 7, None, None, None, None) == INVALID
+    assert lib.iris_augment_draw(0, 64, 64, 2, 2, 8, 8, 7, None, None, None, None) == INVALID
+    assert lib.iris_plan_set_epilogue(None, 0) == INVALID
+    assert lib.iris_plan_status(None, None) == INVALID
+    n = C.c_int(0)
+    assert lib.iris_timing_samples(None, 0, None, 0, C.byref(n)) == INVALID
+    assert lib.iris_timing_enable(None, 1) == INVALID
+    assert lib.iris_plan_kernel_name(None, 32, None, 0) == INVALID
+    assert b"" != lib.iris_last_error()
+
+
 def test_product_code_refuses_cpu_tensors():
     import torch
     from challenge_amd import frontend as FE
