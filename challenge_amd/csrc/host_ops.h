@@ -429,6 +429,7 @@ extern "C" int iris_bias_relu_maxpool(const float* x, const float* bias, float* 
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(y)) & 15)
         return fail(IRIS_E_INVALID, "iris_bias_relu_maxpool: x, bias and y must be 16-byte aligned");
     const size_t n4 = (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
+    if (n4 >= 2147483648ull) return fail(IRIS_E_UNSUPPORTED, "iris_bias_relu_maxpool: more than 2^31 pooled float4 elements");
     k_bias_relu_pool<<<grid_for(n4), 256, 0, (hipStream_t)stream>>>(x, bias, y, batch, height, width, channels / 4);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
@@ -467,9 +468,9 @@ static int bn_check(const void* a, const void* b, size_t rows, int channels, con
         return fail(IRIS_E_UNSUPPORTED, "%s: rows %zu, channels %d (a positive multiple of 4, <= 4096)", who, rows, channels);
     return IRIS_OK;
 }
-static unsigned bn_reduce_grid(size_t rows, int C4) {
+static unsigned bn_reduce_grid(size_t rows, int C4, int rows_per_pass = kBnRows) {
     const int cols = std::min(C4, 256), tys = 256 / cols;
-    return (unsigned)((rows + (size_t)kBnRows * tys - 1) / ((size_t)kBnRows * tys));
+    return (unsigned)((rows + (size_t)rows_per_pass * tys - 1) / ((size_t)rows_per_pass * tys));
 }
 static size_t bn_reduce_lds(int C4) {
     const int cols = std::min(C4, 256), tys = 256 / cols;
@@ -525,6 +526,59 @@ extern "C" int iris_bn_relu_bwd_dx(const float* z, const float* dy, float* dz, s
     const size_t n4 = rows * (size_t)(channels / 4);
     k_bn_relu_bwd_dx<<<grid_for(n4), 256, 4 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
         z, dy, dz, n4, channels / 4, (float)(1.0 / (double)rows), save_mean, save_rstd, gamma, beta, sums, dgamma, dbeta);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+// -- the same three passes with MaxPool 2x2 / stride 2 / 'same' folded in (z [B, H, W, C]; p, dp [B, ceil(H/2), ceil(W/2), C])
+static int bn_pool_check(const void* a, const void* b, int batch, int height, int width, int channels, const char* who) {
+    if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "%s: empty tensor", who);
+    if ((double)batch * ((height + 1) / 2) * ((width + 1) / 2) * (double)std::max(channels, 4) / 4 >= 2147483648.0)
+        return fail(IRIS_E_UNSUPPORTED, "%s: more than 2^31 pooled float4 elements", who);
+    return bn_check(a, b, (size_t)batch * height * width, channels, who);
+}
+
+extern "C" int iris_bn_relu_pool_apply(const float* z, float* p, int batch, int height, int width, int channels, const double* sums,
+                                       const float* gamma, const float* beta, const float* conv_bias, float eps, float momentum,
+                                       float* running_mean, float* running_var, float* save_mean, float* save_rstd, void* stream) {
+    int rc = bn_pool_check(z, p, batch, height, width, channels, "iris_bn_relu_pool_apply");
+    if (rc) return rc;
+    if (!sums || !gamma || !beta || !running_mean || !running_var || !save_mean || !save_rstd)
+        return fail(IRIS_E_INVALID, "iris_bn_relu_pool_apply: NULL argument");
+    const size_t n4 = (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
+    const double m = (double)batch * height * width;  // the statistics are those of the full-size activation
+    k_bn_relu_pool_apply<<<grid_for(n4), 256, 2 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
+        z, p, batch, height, width, channels / 4, 1.0 / m, m > 1.0 ? m / (m - 1.0) : 1.0, sums, gamma, beta, conv_bias, eps, momentum,
+        running_mean, running_var, save_mean, save_rstd);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_bn_relu_pool_bwd_reduce(const float* z, const float* dp, int batch, int height, int width, int channels,
+                                            const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                                            double* sums_zeroed, void* stream) {
+    int rc = bn_pool_check(z, sums_zeroed, batch, height, width, channels, "iris_bn_relu_pool_bwd_reduce");
+    if (rc) return rc;
+    if (!dp || !save_mean || !save_rstd || !gamma || !beta) return fail(IRIS_E_INVALID, "iris_bn_relu_pool_bwd_reduce: NULL argument");
+    const int C4 = channels / 4;
+    const size_t prow = (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2);
+    k_bn_pool_bwd_reduce<<<bn_reduce_grid(prow, C4, kBnPoolRows), 256, bn_reduce_lds(C4), (hipStream_t)stream>>>(
+        z, dp, batch, height, width, C4, save_mean, save_rstd, gamma, beta, sums_zeroed);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
+extern "C" int iris_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* dz, int batch, int height, int width, int channels,
+                                        const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                                        const double* sums, float* dgamma, float* dbeta, void* stream) {
+    int rc = bn_pool_check(z, dz, batch, height, width, channels, "iris_bn_relu_pool_bwd_dx");
+    if (rc) return rc;
+    if (!dp || !save_mean || !save_rstd || !gamma || !beta || !sums || !dgamma || !dbeta)
+        return fail(IRIS_E_INVALID, "iris_bn_relu_pool_bwd_dx: NULL argument");
+    const size_t n4 = (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
+    const double m = (double)batch * height * width;
+    k_bn_relu_pool_bwd_dx<<<grid_for(n4), 256, 4 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
+        z, dp, dz, batch, height, width, channels / 4, (float)(1.0 / m), save_mean, save_rstd, gamma, beta, sums, dgamma, dbeta);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }

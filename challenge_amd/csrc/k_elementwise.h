@@ -207,12 +207,40 @@ __global__ __launch_bounds__(256) void k_agc_clip(const iris_agc_row* rows, size
 // inference epilogue of a folded Conv2D + BatchNorm + ReLU (sj_train.py:191-201): y = max(x + bias[c], 0) in place on a
 // channels-last tensor [n_outer, C]; POOL: the 2x2 / stride-2 'same' max-pool of the block fused behind it
 // ---------------------------------------------------------------------------
+// Column of a grid-stride walk over [rows][C4] without a 64-bit modulo per element: c(i + stride) = c(i) + stride mod C4.
+struct ColumnWalk {
+    int c, step, C4;
+    __device__ __forceinline__ ColumnWalk(size_t first, size_t stride, int n) : c((int)(first % n)), step((int)(stride % n)), C4(n) {}
+    __device__ __forceinline__ void next() {
+        c += step;
+        if (c >= C4) c -= C4;
+    }
+};
+
+// One 2x2 / stride-2 'same' pooling window of a channels-last tensor [B, H, W, C4 float4].
+struct PoolWindow {
+    size_t base;     // float4 index of the window's (h0, w0) element
+    size_t down;     // float4 offset of the row below
+    bool w1, h1;     // the window has a second column / row
+};
+// pooled row r = (b Ho + ho) Wo + wo (32-bit: the host checks the sizes), float4 column c
+__device__ __forceinline__ PoolWindow pool_window(unsigned r, int c, int H, int W, int Ho, int Wo, int C4) {
+    const unsigned t = r / (unsigned)Wo, wo = r - t * (unsigned)Wo;
+    const unsigned b = t / (unsigned)Ho, ho = t - b * (unsigned)Ho;
+    PoolWindow w;
+    w.base = (((size_t)b * H + 2 * ho) * W + 2 * wo) * C4 + c;
+    w.down = (size_t)W * C4;
+    w.w1 = 2 * wo + 1 < (unsigned)W;
+    w.h1 = 2 * ho + 1 < (unsigned)H;
+    return w;
+}
 __global__ __launch_bounds__(256) void k_bias_relu(float* x, const float* bias, size_t n_vec4, int C4) {
     const float4* b4 = reinterpret_cast<const float4*>(bias);
     float4* x4 = reinterpret_cast<float4*>(x);
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x) {
+    ColumnWalk col(blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, C4);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x, col.next()) {
         float4 v = x4[i];
-        const float4 b = b4[i % C4];
+        const float4 b = b4[col.c];
         v.x = fmaxf(v.x + b.x, 0.f);
         v.y = fmaxf(v.y + b.y, 0.f);
         v.z = fmaxf(v.z + b.z, 0.f);
@@ -224,30 +252,25 @@ __global__ __launch_bounds__(256) void k_bias_relu(float* x, const float* bias, 
 // x [B, H, W, C] -> y [B, ceil(H/2), ceil(W/2), C]: y = maxpool2x2(relu(x + bias)) = relu(max over the window of x + bias)
 __global__ __launch_bounds__(256) void k_bias_relu_pool(const float* x, const float* bias, float* y, int B, int H, int W, int C4) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const size_t total = (size_t)B * Ho * Wo * C4;
+    const unsigned total = (unsigned)B * Ho * Wo * C4;  // < 2^31 (host check)
     const float4* b4 = reinterpret_cast<const float4*>(bias);
     const float4* x4 = reinterpret_cast<const float4*>(x);
     float4* y4 = reinterpret_cast<float4*>(y);
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
-        size_t r = i / C4;
-        const int wo = (int)(r % Wo);
-        r /= Wo;
-        const int ho = (int)(r % Ho), b = (int)(r / Ho);
-        const int h0 = 2 * ho, w0 = 2 * wo;
-        const bool h1 = h0 + 1 < H, w1 = w0 + 1 < W;
-        const size_t base = (((size_t)b * H + h0) * W + w0) * C4 + c;
-        float4 m = x4[base];
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / (unsigned)C4;
+        const int c = (int)(i - r * (unsigned)C4);
+        const PoolWindow w = pool_window(r, c, H, W, Ho, Wo, C4);
+        float4 m = x4[w.base];
         auto take = [&](size_t off) {
-            const float4 v = x4[base + off];
+            const float4 v = x4[w.base + off];
             m.x = fmaxf(m.x, v.x);
             m.y = fmaxf(m.y, v.y);
             m.z = fmaxf(m.z, v.z);
             m.w = fmaxf(m.w, v.w);
         };
-        if (w1) take(C4);
-        if (h1) take((size_t)W * C4);
-        if (h1 && w1) take((size_t)W * C4 + C4);
+        if (w.w1) take(C4);
+        if (w.h1) take(w.down);
+        if (w.h1 && w.w1) take(w.down + C4);
         const float4 bb = b4[c];
         m.x = fmaxf(m.x + bb.x, 0.f);
         m.y = fmaxf(m.y + bb.y, 0.f);
@@ -264,7 +287,8 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool(const float* x, const fl
 __global__ __launch_bounds__(256) void k_bias_relu_nchw(float* x, const float* bias, size_t n_vec4, size_t inner4, int C) {
     float4* x4 = reinterpret_cast<float4*>(x);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x) {
-        const float b = bias[(i / inner4) % C];
+        // (32-bit quotients when they fit: a 64-bit division costs more than the rest of the loop body)
+        const float b = n_vec4 <= 0xffffffffull ? bias[((unsigned)i / (unsigned)inner4) % (unsigned)C] : bias[(i / inner4) % C];
         float4 v = x4[i];
         v.x = fmaxf(v.x + b, 0.f);
         v.y = fmaxf(v.y + b, 0.f);
@@ -308,14 +332,21 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool_nchw(const float* x, con
 // channels-last convolution output z [rows = N H W, C] (the convolution itself stays MIOpen; its bias is NOT added by a
 // separate pass: batch normalisation subtracts the batch mean, so y does not depend on the bias - it only shifts the
 // running mean, which is accounted for here - and its gradient is identically zero):
-//   forward   k_bn_stats        per-channel sum, sum of squares of z (fp32 per thread over <= 64 rows, fp64 atomics per block)
+//   forward   k_bn_stats        per-channel sum, sum of squares of z (fp32 per thread over <= 32 rows, fp64 atomics per block)
 //             k_bn_relu_apply   y = max(gamma (z - mean) rstd + beta, 0); block 0 updates the running statistics
 //   backward  k_bn_reduce<true>      g = dy [y > 0]; sum g, sum g xhat per channel (same reduction scheme)
 //             k_bn_relu_bwd_dx       dz = gamma rstd (g - sum_g / M - xhat sum_gx / M); block 0 writes dgamma, dbeta
 // Instead of bias add, mean / variance, normalise, ReLU (7 passes over the activation) and ReLU', dscale / dbias, dx, bias
 // gradient (9 passes): 3 forward (read, read + write) and 5 backward (z and dy read twice, dz written; y is never read).  Thread layout: a block of 256 threads covers kBnRows rows x (C / 4) float4 columns.
 // ---------------------------------------------------------------------------
-constexpr int kBnRows = 64;  // rows per thread-row pass
+#ifndef IRIS_BN_ROWS
+#define IRIS_BN_ROWS 32
+#endif
+#ifndef IRIS_BN_POOL_ROWS
+#define IRIS_BN_POOL_ROWS 8
+#endif
+constexpr int kBnRows = IRIS_BN_ROWS;           // rows per thread-row pass
+constexpr int kBnPoolRows = IRIS_BN_POOL_ROWS;  // pooled rows (windows of four) per thread-row pass: 4x the blocks of the same tensor
 
 // (backward: the ReLU mask [y > 0] is recomputed from z with the forward's own scale / shift - bit-identical to testing
 // the stored y - so that y is not read at all)
@@ -342,6 +373,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float* z, const float* 
         }
         const size_t r_begin = (size_t)blockIdx.x * kBnRows * tys, r_end = min(r_begin + (size_t)kBnRows * tys, rows);
         if (c < C4 && ty < tys) {
+#pragma unroll 4
             for (size_t r = r_begin + ty; r < r_end; r += tys) {
                 const float4 v = z4[r * C4 + c];
                 if constexpr (!BWD) {
@@ -401,8 +433,9 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* z, float* y,
     float4* y4 = reinterpret_cast<float4*>(y);
     const float4* sc4 = reinterpret_cast<const float4*>(coef);
     const float4* sh4 = reinterpret_cast<const float4*>(coef + C);
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
+    ColumnWalk col(blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, C4);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x, col.next()) {
+        const int c = col.c;
         const float4 v = z4[i], sc = sc4[c], sh = sh4[c];
         float4 r;
         r.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
@@ -440,8 +473,9 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_dx(const float* z, const fl
     const float4* b4 = reinterpret_cast<const float4*>(coef + C);
     const float4* c4 = reinterpret_cast<const float4*>(coef + 2 * C);
     const float4* h4 = reinterpret_cast<const float4*>(coef + 3 * C);
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
+    ColumnWalk col(blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, C4);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec4; i += (size_t)gridDim.x * blockDim.x, col.next()) {
+        const int c = col.c;
         const float4 v = z4[i], d = d4[i], a = a4[c], b = b4[c], k = c4[c], h = h4[c];
         float4 r;
         r.x = fmaf(a.x, fmaf(v.x, a.x, h.x) > 0.f ? d.x : 0.f, fmaf(b.x, v.x, k.x));
@@ -449,5 +483,197 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_dx(const float* z, const fl
         r.z = fmaf(a.z, fmaf(v.z, a.z, h.z) > 0.f ? d.z : 0.f, fmaf(b.z, v.z, k.z));
         r.w = fmaf(a.w, fmaf(v.w, a.w, h.w) > 0.f ? d.w : 0.f, fmaf(b.w, v.w, k.w));
         o4[i] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The last convolution of a ConvMPBlock is followed by MaxPool 2x2 / stride 2 / 'same' (sj_train.py:191-201).  With the
+// pooling inside the BatchNorm + ReLU passes the full-size y is never written and the full-size dy never exists:
+//   forward   k_bn_relu_pool_apply      p = max over the window of max(z scale + shift, 0)         (reads z, writes p = 1/4)
+//   backward  k_bn_pool_bwd_reduce      g = dp at the window's first maximum if that is > 0; sum g, sum g xhat
+//             k_bn_relu_pool_bwd_dx     dz = a g + b z + d over every element of the window     (reads z + dp, writes dz)
+// The winner of a window is its first maximum in (h, w) scan order, which is what max_pool2d's index rule picks; windows
+// whose maximum is 0 pass no gradient (ReLU' there is 0 whichever element is chosen).
+// z [B, H, W, C] channels-last, p / dp [B, ceil(H/2), ceil(W/2), C]; a thread owns one float4 of one window.
+// ---------------------------------------------------------------------------
+// y of one element, and the running first maximum (value, its z, its slot)
+__device__ __forceinline__ void pool_take(float z, float sc, float sh, int slot, float& best, float& zbest, int& sel) {
+    const float y = fmaxf(fmaf(z, sc, sh), 0.f);
+    if (slot == 0 || y > best) {
+        best = y;
+        zbest = z;
+        sel = slot;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_relu_pool_apply(const float* z, float* p, int B, int H, int W, int C4, double inv_m,
+                                                            double unbias, const double* sums, const float* gamma, const float* beta,
+                                                            const float* conv_bias, float eps, float momentum, float* running_mean,
+                                                            float* running_var, float* save_mean, float* save_rstd) {
+    extern __shared__ float coef[];  // [2][C], formed exactly as k_bn_relu_apply forms them
+    const int C = 4 * C4;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double m = sums[c] * inv_m, var = fmax(sums[C + c] * inv_m - m * m, 0.0);
+        const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+        coef[c] = gamma[c] * rs;
+        coef[C + c] = beta[c] - mu * (gamma[c] * rs);
+        if (blockIdx.x == 0) {
+            save_mean[c] = mu;
+            save_rstd[c] = rs;
+            const float bias = conv_bias ? conv_bias[c] : 0.f;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (mu + bias);
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+        }
+    }
+    __syncthreads();
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const unsigned total = (unsigned)B * Ho * Wo * C4;  // < 2^31 (host check)
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* sc4 = reinterpret_cast<const float4*>(coef);
+    const float4* sh4 = reinterpret_cast<const float4*>(coef + C);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / (unsigned)C4;
+        const int c = (int)(i - r * (unsigned)C4);
+        const PoolWindow w = pool_window(r, c, H, W, Ho, Wo, C4);
+        const float4 sc = sc4[c], sh = sh4[c];
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // y >= 0
+        auto take = [&](size_t off) {
+            const float4 v = z4[w.base + off];
+            m.x = fmaxf(m.x, fmaf(v.x, sc.x, sh.x));
+            m.y = fmaxf(m.y, fmaf(v.y, sc.y, sh.y));
+            m.z = fmaxf(m.z, fmaf(v.z, sc.z, sh.z));
+            m.w = fmaxf(m.w, fmaf(v.w, sc.w, sh.w));
+        };
+        take(0);
+        if (w.w1) take(C4);
+        if (w.h1) take(w.down);
+        if (w.h1 && w.w1) take(w.down + C4);
+        p4[i] = m;
+    }
+}
+
+// the four elements of a window (missing ones repeat element 0 and can never win: `>` is strict)
+__device__ __forceinline__ void pool_load(const float4* z4, const PoolWindow& w, int C4, float4 (&v)[4]) {
+    v[0] = z4[w.base];
+    v[1] = w.w1 ? z4[w.base + C4] : v[0];
+    v[2] = w.h1 ? z4[w.base + w.down] : v[0];
+    v[3] = (w.h1 && w.w1) ? z4[w.base + w.down + C4] : v[0];
+}
+
+__global__ __launch_bounds__(256) void k_bn_pool_bwd_reduce(const float* z, const float* dp, int B, int H, int W, int C4,
+                                                            const float* mean, const float* rstd, const float* gamma,
+                                                            const float* beta, double* sums /*[2][4 C4]*/) {
+    // same thread layout and reduction as k_bn_reduce, over the POOLED rows
+    extern __shared__ float red[];
+    const int cols = min(C4, 256), tys = 256 / cols;
+    const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const size_t rows = (size_t)B * Ho * Wo;
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    const float4* d4 = reinterpret_cast<const float4*>(dp);
+    for (int c0 = 0; c0 < C4; c0 += cols) {
+        const int c = c0 + tx;
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < C4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mu[k] = mean[4 * c + k];
+                rs[k] = rstd[4 * c + k];
+                sc[k] = gamma[4 * c + k] * rs[k];
+                sh[k] = beta[4 * c + k] - mu[k] * sc[k];
+            }
+        }
+        const size_t r_begin = (size_t)blockIdx.x * kBnPoolRows * tys, r_end = min(r_begin + (size_t)kBnPoolRows * tys, rows);
+        if (c < C4 && ty < tys) {
+#pragma unroll 2
+            for (size_t r = r_begin + ty; r < r_end; r += tys) {
+                const PoolWindow w = pool_window((unsigned)r, c, H, W, Ho, Wo, C4);
+                float4 v[4];
+                pool_load(z4, w, C4, v);
+                const float4 d = d4[r * C4 + c];
+                const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float best = 0.f, zb = 0.f;
+                    int sel = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pool_take(reinterpret_cast<const float*>(&v[j])[k], sc[k], sh[k], j, best, zb, sel);
+                    const float g = best > 0.f ? dd[k] : 0.f;
+                    s0[k] += g;
+                    s1[k] = fmaf(g, (zb - mu[k]) * rs[k], s1[k]);
+                }
+            }
+        }
+        __syncthreads();
+        if (ty < tys) {
+            float* pp = red + ((size_t)ty * 2 * cols + tx) * 4;
+            float* q = pp + (size_t)cols * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pp[k] = s0[k];
+                q[k] = s1[k];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * 4 * cols; i += blockDim.x) {
+            const int which = i / (4 * cols), j = i - which * 4 * cols;
+            double acc = 0.0;
+            for (int t = 0; t < tys; ++t) acc += (double)red[((size_t)t * 2 * cols) * 4 + (size_t)which * cols * 4 + j];
+            const int cc = c0 * 4 + j;
+            if (cc < 4 * C4) atomicAdd(sums + (size_t)which * 4 * C4 + cc, acc);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* dz, int B, int H, int W, int C4,
+                                                             float inv_m, const float* mean, const float* rstd, const float* gamma,
+                                                             const float* beta, const double* sums, float* dgamma, float* dbeta) {
+    extern __shared__ float coef[];  // [4][C], as k_bn_relu_bwd_dx
+    const int C = 4 * C4;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float sg = (float)sums[c], sgx = (float)sums[C + c];
+        const float a = gamma[c] * rstd[c], b = -a * rstd[c] * sgx * inv_m;
+        coef[c] = a;
+        coef[C + c] = b;
+        coef[2 * C + c] = -a * sg * inv_m - b * mean[c];
+        coef[3 * C + c] = beta[c] - mean[c] * a;
+        if (blockIdx.x == 0) {
+            dbeta[c] = sg;
+            dgamma[c] = sgx;
+        }
+    }
+    __syncthreads();
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const unsigned total = (unsigned)B * Ho * Wo * C4;  // < 2^31 (host check)
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    const float4* d4 = reinterpret_cast<const float4*>(dp);
+    float4* o4 = reinterpret_cast<float4*>(dz);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / (unsigned)C4;
+        const int c = (int)(i - r * (unsigned)C4);
+        const PoolWindow w = pool_window(r, c, H, W, Ho, Wo, C4);
+        float4 v[4], o[4];
+        pool_load(z4, w, C4, v);
+        const float4 d = d4[i];
+        const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = coef[4 * c + k], b = coef[C + 4 * c + k], kk = coef[2 * C + 4 * c + k], h = coef[3 * C + 4 * c + k];
+            float best = 0.f, zb = 0.f;
+            int sel = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pool_take(reinterpret_cast<const float*>(&v[j])[k], a, h, j, best, zb, sel);
+            const float g = best > 0.f ? dd[k] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                reinterpret_cast<float*>(&o[j])[k] = fmaf(a, sel == j ? g : 0.f, fmaf(b, reinterpret_cast<const float*>(&v[j])[k], kk));
+        }
+        o4[w.base] = o[0];
+        if (w.w1) o4[w.base + C4] = o[1];
+        if (w.h1) o4[w.base + w.down] = o[2];
+        if (w.h1 && w.w1) o4[w.base + w.down + C4] = o[3];
     }
 }

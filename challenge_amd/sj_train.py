@@ -497,34 +497,50 @@ class FusedAGC:
 # Training-mode Conv2D bias + BatchNorm + ReLU through the HIP kernels iris_bn_* (two passes over the activation each way
 # instead of seven forward / nine backward); IRIS_FUSED_BN=0 keeps the stock torch / MIOpen ops.
 FUSED_BN_RELU = os.environ.get("IRIS_FUSED_BN", "1") != "0"
+FUSED_BN_POOL = os.environ.get("IRIS_FUSED_BN_POOL", "1") != "0"  # a block's MaxPool inside its last layer's passes
+
+
+def _is_pool_2x2_same(pool):
+    def pair(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    return (isinstance(pool, nn.MaxPool2d) and pair(pool.kernel_size) == (2, 2) and pair(pool.stride) == (2, 2)
+            and pair(pool.padding) == (0, 0) and pair(pool.dilation) == (1, 1) and pool.ceil_mode and not pool.return_indices)
 
 
 class _FusedBiasBNReLU(torch.autograd.Function):
-    """y = relu(batch_norm(z + conv_bias)) in training mode on a channels_last fp32 convolution output z (sj_train.py:191-201).
+    """y = relu(batch_norm(z + conv_bias)) in training mode on a channels_last fp32 convolution output z (sj_train.py:191-201),
+    with `pool` also the block's MaxPool2d(2, 2, ceil_mode=True) behind it (the full-size y and dy then never exist).
     The bias never touches the activation: batch normalisation subtracts the batch mean, so y does not depend on it (it
     only shifts the running mean, which iris_bn_relu_apply accounts for) and its gradient is identically zero."""
 
     @staticmethod
-    def forward(ctx, z, conv_bias, gamma, beta, running_mean, running_var, eps, momentum):
+    def forward(ctx, z, conv_bias, gamma, beta, running_mean, running_var, eps, momentum, pool=False):
         import ctypes as C
         from . import _native as N
-        c = int(z.shape[1])
-        rows = z.numel() // c
+        b, c, h, w = (int(v) for v in z.shape)
+        rows = b * h * w
         dev = z.device
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         sums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
-        y = torch.empty_like(z)  # preserves channels_last
+        if pool:
+            y = torch.empty((b, c, (h + 1) // 2, (w + 1) // 2), dtype=z.dtype, device=dev, memory_format=torch.channels_last)
+        else:
+            y = torch.empty_like(z)  # preserves channels_last
         save_mean = torch.empty(c, dtype=torch.float32, device=dev)
         save_rstd = torch.empty(c, dtype=torch.float32, device=dev)
         lib = N.lib()
+        tail = (sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), conv_bias.data_ptr() if conv_bias is not None else None,
+                float(eps), float(momentum), running_mean.data_ptr(), running_var.data_ptr(), save_mean.data_ptr(),
+                save_rstd.data_ptr(), stream)
         with torch.cuda.device(dev):
             N.check(lib.iris_bn_stats(z.data_ptr(), rows, c, sums.data_ptr(), stream), "iris_bn_stats")
-            N.check(lib.iris_bn_relu_apply(z.data_ptr(), y.data_ptr(), rows, c, sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                           conv_bias.data_ptr() if conv_bias is not None else None, float(eps), float(momentum),
-                                           running_mean.data_ptr(), running_var.data_ptr(), save_mean.data_ptr(),
-                                           save_rstd.data_ptr(), stream), "iris_bn_relu_apply")
+            if pool:
+                N.check(lib.iris_bn_relu_pool_apply(z.data_ptr(), y.data_ptr(), b, h, w, c, *tail), "iris_bn_relu_pool_apply")
+            else:
+                N.check(lib.iris_bn_relu_apply(z.data_ptr(), y.data_ptr(), rows, c, *tail), "iris_bn_relu_apply")
         ctx.save_for_backward(z, gamma, beta, save_mean, save_rstd)  # y is not needed: the mask is recomputed from z
         ctx.has_bias = conv_bias is not None
+        ctx.pool = bool(pool)
         ctx.mark_non_differentiable(running_mean, running_var)
         return y
 
@@ -533,8 +549,8 @@ class _FusedBiasBNReLU(torch.autograd.Function):
         import ctypes as C
         from . import _native as N
         z, gamma, beta, save_mean, save_rstd = ctx.saved_tensors
-        c = int(z.shape[1])
-        rows = z.numel() // c
+        b, c, h, w = (int(v) for v in z.shape)
+        rows = b * h * w
         dev = z.device
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         if not dy.is_contiguous(memory_format=torch.channels_last):
@@ -544,14 +560,19 @@ class _FusedBiasBNReLU(torch.autograd.Function):
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
         lib = N.lib()
+        stats = (save_mean.data_ptr(), save_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr())
         with torch.cuda.device(dev):
-            N.check(lib.iris_bn_relu_bwd_reduce(z.data_ptr(), dy.data_ptr(), rows, c, save_mean.data_ptr(), save_rstd.data_ptr(),
-                                                gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), stream), "iris_bn_relu_bwd_reduce")
-            N.check(lib.iris_bn_relu_bwd_dx(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, c, save_mean.data_ptr(),
-                                            save_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(),
-                                            dgamma.data_ptr(), dbeta.data_ptr(), stream), "iris_bn_relu_bwd_dx")
+            if ctx.pool:
+                N.check(lib.iris_bn_relu_pool_bwd_reduce(z.data_ptr(), dy.data_ptr(), b, h, w, c, *stats, stream),
+                        "iris_bn_relu_pool_bwd_reduce")
+                N.check(lib.iris_bn_relu_pool_bwd_dx(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), b, h, w, c, *stats,
+                                                     dgamma.data_ptr(), dbeta.data_ptr(), stream), "iris_bn_relu_pool_bwd_dx")
+            else:
+                N.check(lib.iris_bn_relu_bwd_reduce(z.data_ptr(), dy.data_ptr(), rows, c, *stats, stream), "iris_bn_relu_bwd_reduce")
+                N.check(lib.iris_bn_relu_bwd_dx(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, c, *stats,
+                                                dgamma.data_ptr(), dbeta.data_ptr(), stream), "iris_bn_relu_bwd_dx")
         dbias = torch.zeros(c, dtype=torch.float32, device=dev) if ctx.has_bias else None
-        return dz, dbias, dgamma, dbeta, None, None, None, None
+        return dz, dbias, dgamma, dbeta, None, None, None, None, None
 
 
 class _ConvBNReLU(nn.Sequential):
@@ -562,7 +583,9 @@ class _ConvBNReLU(nn.Sequential):
         layers.append(nn.ReLU(inplace=True))
         super().__init__(*layers)
 
-    def forward(self, x):
+    def forward(self, x, pool=None):
+        """`pool`: the MaxPool2d(2, 2, ceil_mode=True) that follows this layer in its ConvMPBlock (applied here, inside the
+        fused passes when they run, as the module otherwise)."""
         if (FUSED_BN_RELU and self.training and x.is_cuda and len(self) == 3 and isinstance(self[1], nn.BatchNorm2d)
                 and not torch.is_autocast_enabled()):
             conv, bn = self[0], self[1]
@@ -570,10 +593,14 @@ class _ConvBNReLU(nn.Sequential):
                 z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
                 if z.is_contiguous(memory_format=torch.channels_last):
                     bn.num_batches_tracked.add_(1)
-                    return _FusedBiasBNReLU.apply(z, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                                  bn.eps, bn.momentum)
-                return self[2](bn(z + conv.bias.view(1, -1, 1, 1) if conv.bias is not None else z))
-        return super().forward(x)
+                    fold = FUSED_BN_POOL and _is_pool_2x2_same(pool)
+                    y = _FusedBiasBNReLU.apply(z, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                               bn.eps, bn.momentum, fold)
+                    return y if (fold or pool is None) else pool(y)
+                y = self[2](bn(z + conv.bias.view(1, -1, 1, 1) if conv.bias is not None else z))
+                return y if pool is None else pool(y)
+        y = super().forward(x)
+        return y if pool is None else pool(y)
 
 
 class ConvMPBlock(nn.Module):
@@ -586,7 +613,12 @@ class ConvMPBlock(nn.Module):
         self.pool = nn.MaxPool2d(2, 2, ceil_mode=True) if MP else nn.Identity()
 
     def forward(self, x):
-        return self.pool(self.convs(x))
+        layers = list(self.convs)
+        for layer in layers[:-1]:
+            x = layer(x)
+        if isinstance(layers[-1], _ConvBNReLU) and isinstance(self.pool, nn.MaxPool2d):
+            return layers[-1](x, pool=self.pool)  # the pooling goes into the last layer's fused passes when those run
+        return self.pool(layers[-1](x))
 
 
 class FullyConnectedLayer(nn.Module):

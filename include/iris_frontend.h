@@ -284,6 +284,26 @@ int iris_bn_relu_bwd_dx(const float* z, const float* dy, float* dz, size_t rows,
                         float* dbeta, void* stream);
 
 /*
+ * The same passes for the LAST convolution of a ConvMPBlock, with its MaxPool2D(2, 2, 'same') folded in (sj_train.py:199-200:
+ * pooling follows the block's last Conv-BN-ReLU): z [batch, height, width, channels] channels-last; p and dp
+ * [batch, ceil(height / 2), ceil(width / 2), channels].  The full-size y is never written and the full-size dy never exists:
+ *   forward : iris_bn_stats as above (the statistics are those of the full-size z), then
+ *             iris_bn_relu_pool_apply: p = max over the window of max(gamma (z - mean) rstd + beta, 0)
+ *   backward: iris_bn_relu_pool_bwd_reduce / iris_bn_relu_pool_bwd_dx: g = dp at the window's first maximum in (h, w) scan
+ *             order (max_pool2d's index rule) where that maximum is > 0, 0 elsewhere; sums, dz, dgamma, dbeta as above.
+ * Same constraints as above.
+ */
+int iris_bn_relu_pool_apply(const float* z, float* p, int batch, int height, int width, int channels, const double* sums,
+                            const float* gamma, const float* beta, const float* conv_bias, float eps, float momentum,
+                            float* running_mean, float* running_var, float* save_mean, float* save_rstd, void* stream);
+int iris_bn_relu_pool_bwd_reduce(const float* z, const float* dp, int batch, int height, int width, int channels,
+                                 const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                                 double* sums_zeroed, void* stream);
+int iris_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* dz, int batch, int height, int width, int channels,
+                             const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                             const double* sums, float* dgamma, float* dbeta, void* stream);
+
+/*
  * Sample synthesis in the complex-STFT domain, deterministic half of
  * merge_complex_specs (pipeline.py:6-110) for a whole batch: every output sample
  * is   background crop (tiled along time, pipeline.py:29-35)

@@ -850,6 +850,56 @@ def test_fused_bn_relu_training_matches_torch(dev, monkeypatch):
         assert int(blk[1].num_batches_tracked) == int(ref[1].num_batches_tracked) == 1
 
 
+def test_fused_bn_relu_pool_block_matches_torch(dev, monkeypatch):
+    """A ConvMPBlock with its MaxPool folded into the last layer's BatchNorm + ReLU passes (iris_bn_relu_pool_*): outputs,
+    every gradient and the running statistics equal the stock torch / MIOpen ops, for even and odd heights / widths
+    (ceil_mode windows at the edges) and for blocks of one and two convolutions."""
+    import copy
+    from challenge_amd import sj_train as S
+    S.configure_miopen()
+    torch.manual_seed(5)
+    for cin, cout, nconv, b, h, w in [(1, 32, 2, 3, 16, 40), (32, 64, 2, 2, 9, 7), (64, 128, 1, 2, 5, 6), (16, 512, 1, 1, 1, 3)]:
+        blk = S.ConvMPBlock(cin, num_convs=nconv, fsize=cout, BN=True, MP=True).to(dev).to(memory_format=torch.channels_last).train()
+        with torch.no_grad():
+            for m in blk.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(-1.5, 1.5)   # negative scales too: the maximum must be taken after the affine map
+                    m.bias.uniform_(-0.3, 0.3)
+        ref = copy.deepcopy(blk)
+        x = torch.randn(b, cin, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        g = torch.randn(b, cout, (h + 1) // 2, (w + 1) // 2, device=dev).contiguous(memory_format=torch.channels_last)
+        monkeypatch.setattr(S, "FUSED_BN_RELU", True)
+        monkeypatch.setattr(S, "FUSED_BN_POOL", True)
+        ya = blk(xa)
+        assert ya.grad_fn.name().startswith("_FusedBiasBNReLU")   # the pooling ran inside the fused passes
+        ya.backward(g)
+        monkeypatch.setattr(S, "FUSED_BN_RELU", False)
+        yb = ref(xb)
+        yb.backward(g)
+        assert ya.shape == yb.shape and ya.is_contiguous(memory_format=torch.channels_last)
+        tol = lambda t: 2e-5 * float(t.abs().max()) + 1e-6  # noqa: E731
+        assert float((ya - yb).abs().max()) <= tol(yb)
+        assert float((xa.grad - xb.grad).abs().max()) <= tol(xb.grad) * 5
+        for (na, pa), (nb, pb) in zip(blk.named_parameters(), ref.named_parameters()):
+            if na.endswith("0.bias"):   # convolution bias: exact zero on the fused path, rounding noise on the stock one
+                assert float(pa.grad.abs().max()) == 0.0
+                continue
+            assert float((pa.grad - pb.grad).abs().max()) <= tol(pb.grad) * 5, (na, cin, cout, h, w)
+        for ma, mb in zip(blk.modules(), ref.modules()):
+            if isinstance(ma, torch.nn.BatchNorm2d):
+                assert float((ma.running_mean - mb.running_mean).abs().max()) <= 1e-6
+                assert float((ma.running_var - mb.running_var).abs().max()) <= 1e-6
+        # the unfolded form of the fused passes (pooling as the module) is the same function as well
+        monkeypatch.setattr(S, "FUSED_BN_RELU", True)
+        monkeypatch.setattr(S, "FUSED_BN_POOL", False)
+        blk.zero_grad()
+        xc = x.clone().requires_grad_(True)
+        yc = blk(xc)
+        yc.backward(g)
+        assert float((yc - ya).abs().max()) <= tol(ya) and float((xc.grad - xa.grad).abs().max()) <= tol(xa.grad) * 5
+
+
 def test_inference_engine_matches_module(dev):
     """InferenceEngine (BatchNorm folded, conv + HIP bias/ReLU/pool epilogue, frontend + forward as one hipGraph) is the
     same function as the training module in eval mode: <= 1e-4 on the sigmoid outputs, eager and replayed."""
