@@ -980,6 +980,46 @@ def configure_miopen() -> None:
     os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL")
     for d in ("FWD", "BWD", "WRW"):
         os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + d, "0")
+    _use_shipped_miopen_db()
+
+
+def _use_shipped_miopen_db() -> None:
+    """challenge_amd/miopen_db/ holds MIOpen's user perf-db / find-db after an exhaustive search (MIOPEN_FIND_ENFORCE=3,
+    scripts/gpu_miopen_tune.sh) over this model's convolution shapes at batch 64 on an MI355X: tuned kernel parameters for
+    the solvers MIOpen already has, 16.2 -> 15.1 ms per training step (profiles/r3/miopen_tune.log).  MIOpen also WRITES to
+    its user db, so a per-user, per-rank copy (miopen_db/_run/, named after the shipped content) is what MIOPEN_USER_DB_PATH points at.
+    Skipped when the user has set MIOPEN_USER_DB_PATH, or with IRIS_MIOPEN_DB=0; the files are keyed by MIOpen build and
+    GPU, so any other build / GPU simply does not find them."""
+    if "MIOPEN_USER_DB_PATH" in os.environ or os.environ.get("IRIS_MIOPEN_DB", "1") == "0":
+        return
+    import hashlib
+    import shutil
+    import tempfile
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+    try:
+        files = sorted(f for f in os.listdir(src) if f.endswith("db.txt"))
+        if not files:
+            return
+        digest = hashlib.sha256()
+        for f in files:
+            with open(os.path.join(src, f), "rb") as fh:
+                digest.update(f.encode() + b"\0" + fh.read())
+        uid = os.getuid() if hasattr(os, "getuid") else 0
+        name = f"u{uid}_r{os.environ.get('LOCAL_RANK', '0')}_{digest.hexdigest()[:12]}"
+        dst = os.path.join(src, "_run", name)  # beside the shipped files (git- and gpurun-ignored) ...
+        try:
+            os.makedirs(dst, exist_ok=True)
+        except OSError:  # ... or, for a read-only installation, in the temp dir
+            dst = os.path.join(tempfile.gettempdir(), "iris_miopen_db_" + name)
+            os.makedirs(dst, exist_ok=True)
+        for f in files:
+            if not os.path.exists(os.path.join(dst, f)):
+                tmp = os.path.join(dst, f + f".{os.getpid()}.tmp")
+                shutil.copyfile(os.path.join(src, f), tmp)
+                os.replace(tmp, os.path.join(dst, f))
+        os.environ["MIOPEN_USER_DB_PATH"] = dst
+    except OSError:
+        pass  # no shipped db / unwritable temp dir: MIOpen's own defaults
 
 
 def init_distributed():

@@ -17,11 +17,22 @@ gen = torch.Generator(device=dev).manual_seed(4321)
 wav = torch.randn(batch, 1, length, generator=gen, device=dev) * 0.1
 y = (torch.rand(batch, 16, 3, generator=gen, device=dev) < 0.1).float()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+bf16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"
+
+
+def step():
+    if bf16:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            model.train_step((fe(wav), y))
+    else:
+        model.train_step((fe(wav), y))
+
+
 for _ in range(3):
-    model.train_step((fe(wav), y))
+    step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(n):
-    model.train_step((fe(wav), y))
+    step()
 torch.cuda.synchronize()
-print(f"train step {1e3 * (time.perf_counter() - t0) / n:.3f} ms per batch of {batch}")
+print(f"train step{' (bf16 autocast)' if bf16 else ''} {1e3 * (time.perf_counter() - t0) / n:.3f} ms per batch of {batch}")

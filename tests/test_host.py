@@ -364,3 +364,29 @@ def test_batched_mask_draws_support_and_distribution():
         for _ in range(200):
             T.mask_draw_batch(8, 4, 16, 1, rng)
     assert T.mask_draw_batch(0, 10, 4, 2, rng).shape == (0, 2, 2)
+
+
+def test_configure_miopen_points_at_a_copy_of_the_shipped_db(monkeypatch):
+    """sj_train.configure_miopen: MIOPEN_USER_DB_PATH = a per-rank copy of challenge_amd/miopen_db (the tuned perf-db /
+    find-db), unless the user has set the variable or IRIS_MIOPEN_DB=0."""
+    from challenge_amd import sj_train as S
+    shipped = os.path.join(ROOT, "challenge_amd", "miopen_db")
+    files = sorted(f for f in os.listdir(shipped) if f.endswith("db.txt"))
+    assert any(f.endswith(".udb.txt") for f in files) and any(f.endswith(".ufdb.txt") for f in files)
+    for v in ("MIOPEN_USER_DB_PATH", "MIOPEN_FIND_MODE", "IRIS_MIOPEN_DB"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    S.configure_miopen()
+    dst = os.environ["MIOPEN_USER_DB_PATH"]
+    assert "_r3_" in os.path.basename(dst) and os.path.isdir(dst)
+    for f in files:
+        assert open(os.path.join(dst, f), "rb").read() == open(os.path.join(shipped, f), "rb").read()
+    assert os.environ["MIOPEN_FIND_MODE"] == "NORMAL"
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")   # the user's choice wins
+    S.configure_miopen()
+    assert os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("IRIS_MIOPEN_DB", "0")
+    S.configure_miopen()
+    assert "MIOPEN_USER_DB_PATH" not in os.environ
+    monkeypatch.delenv("MIOPEN_FIND_MODE", raising=False)
