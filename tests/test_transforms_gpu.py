@@ -974,3 +974,18 @@ def test_bench_line_survives_stuck_side_measurements(dev):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["value"] > 0 and "abandoned" in res["extra"]["error"]
     assert res["roofline"]["launches_timed"] >= 50 and res["rccl_world"] == 2
+
+
+def test_bench_strong_scaling_two_ranks(dev):
+    """`bench.py --gpus 2 --strong`: the fixed global batch (256 c2 clips) is split over the ranks and the line says so."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["IRIS_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--strong", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras", "--no-precondition"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["scaling"] == "strong" and res["n_gpus"] == 2 and res["config"]["global_batch"] == 256
+    assert "batch 128" in res["config"]["workload"] and res["value"] > 0 and res["rccl_world"] == 2
