@@ -264,7 +264,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         "c3_best_fp32_audio_s_per_s": round(world * audio_s / best_fwd, 1),
         "c4_train_step": {"audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3),
                           "batch_per_gpu": batch, "n_gpus": world, "params": sum(p.numel() for p in model.parameters()),
-                          "grad_allreduce": "DDP/RCCL" if world > 1 else "none", "device_ms_per_phase": breakdown,
+                          "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if world > 1 else "none", "device_ms_per_phase": breakdown,
                           "allreduce": comm},
         "bf16_autocast_opt_in": bf16,
     }
