@@ -190,7 +190,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         t_nosync = timed(train_nosync, steps)
         comm = {"step_ms_with_allreduce": round(1e3 * t_train, 3), "step_ms_no_sync": round(1e3 * t_nosync, 3),
                 "exposed_allreduce_ms_per_step": round(1e3 * (t_train - t_nosync), 3),
-                "grad_bytes": 4 * sum(p.numel() for p in model.parameters()), "bucket_cap_mb": 25}
+                "grad_bytes": 4 * sum(p.numel() for p in model.parameters()), "bucket_cap_mb": S.DDP_BUCKET_MB}
 
     # opt-in bf16 autocast variant of the forward and the training step, with its deviation from fp32 stated
     bf16 = None

@@ -1043,6 +1043,13 @@ def init_distributed():
     return rank, world, device
 
 
+# Gradient buckets of the v9 CRNN (39.5 MB, filled in reverse layer order): with 25 MB the last bucket is 22 MB (block 4's
+# first two convolutions and everything below) and its all-reduce starts only when backward has finished, fully exposed; with
+# 12 MB the buckets are 0.9 / 7.2 / 9.4 / 9.4 / 11.8 / 0.7 MB - the 11.8 MB one goes out while blocks 2 and 1 (40 % of backward)
+# still compute, and what is left after backward is 0.7 MB.
+DDP_BUCKET_MB = 12
+
+
 def wrap_ddp(model: CustomModel, device, world: int):
     if world <= 1:
         return None
@@ -1050,7 +1057,7 @@ def wrap_ddp(model: CustomModel, device, world: int):
     # ONE collective per step - the bucketed gradient all-reduce: BatchNorm statistics stay per replica (the reference has
     # no multi-GPU at all; rank 0's are the ones checkpointed), so the per-forward buffer broadcast is switched off
     return DDP(model, device_ids=[device.index] if device.type == 'cuda' else None,
-               bucket_cap_mb=25, gradient_as_bucket_view=True, broadcast_buffers=False)
+               bucket_cap_mb=DDP_BUCKET_MB, gradient_as_bucket_view=True, broadcast_buffers=False)
 
 
 def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=None, validation_steps=16,
