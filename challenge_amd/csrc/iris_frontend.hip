@@ -14,6 +14,7 @@
 //   k_elementwise.h  min-max / log, normalize, magnitude-phase, mask, adaptive gradient clipping
 //   k_mix.h          batched sample synthesis (merge_complex_specs)
 //   k_draw.h         the random half of a batch drawn on the device (source table, SpecAugment bands)
+//   k_lstm.h         the recurrent half of the CRNN's bidirectional LSTM (inference)
 //   host_plan.h      mel matrix, constant tables, plan create / destroy
 //   host_ops.h       the operators' C-ABI entry points
 #include "common.h"
@@ -27,4 +28,4 @@
 #include "host_ops.h"
 #include "k_mix.h"
 #include "k_draw.h"
-#include "k_draw.h"
+#include "k_lstm.h"

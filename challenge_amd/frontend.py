@@ -382,6 +382,22 @@ def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def bilstm128_forward(gx: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """Recurrent half of Bidirectional(LSTM(128, return_sequences=True)) in ONE launch (iris_bilstm128_forward).
+    gx [B, T, 2, 512]: input pre-activations x_t W_ih^T + b_ih + b_hh per direction, gate rows i, f, g, o;
+    w_hh [2, 512, 128]: recurrent matrices.  Returns [B, T, 256] = (h forward, h backward) per step, h_0 = c_0 = 0."""
+    if (gx.dim() != 4 or tuple(gx.shape[2:]) != (2, 512) or tuple(w_hh.shape) != (2, 512, 128) or not gx.is_cuda
+            or gx.dtype != torch.float32 or w_hh.dtype != torch.float32 or w_hh.device != gx.device):
+        raise ValueError("bilstm128_forward: gx must be a float32 device tensor [B, T, 2, 512], w_hh [2, 512, 128] beside it")
+    gx, w_hh = gx.contiguous(), w_hh.contiguous()
+    b, t = int(gx.shape[0]), int(gx.shape[1])
+    out = torch.empty((b, t, 256), dtype=torch.float32, device=gx.device)
+    with torch.cuda.device(gx.device):
+        rc = N.lib().iris_bilstm128_forward(gx.data_ptr(), w_hh.data_ptr(), out.data_ptr(), b, t, _stream_ptr(gx.device))
+    N.check(rc, "iris_bilstm128_forward")
+    return out
+
+
 class PipelinedFrontend:
     """Independent batches through the fused path on `n_streams` HIP streams, one `FrontendPlan` each (a plan's
     workspace belongs to one stream, include/iris_frontend.h), in the two-kernel form of the step: one stream's

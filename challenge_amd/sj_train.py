@@ -834,20 +834,51 @@ class _ConvBiasReLU(nn.Module):
         return _fe.bias_relu_maxpool(y, self.bias) if self.pool else _fe.bias_relu_(y, self.bias)
 
 
+class _HipBiLSTM(nn.Module):
+    """Inference form of the model's nn.LSTM(128, 128, bidirectional, batch_first): ONE GEMM for the input projections of
+    all steps and both directions, then the whole recurrence in ONE HIP launch (iris_bilstm128_forward; MIOpen runs a GEMM
+    and a pointwise kernel per step and direction).  Returns (output, None) like nn.LSTM."""
+
+    def __init__(self, lstm: nn.LSTM):
+        super().__init__()
+        if not self.supports(lstm):
+            raise ValueError("_HipBiLSTM: a one-layer bidirectional batch_first LSTM(128 -> 128) with biases is expected")
+        w_ih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], 0).detach()              # [1024, 128]
+        bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse], 0).detach()
+        w_hh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse], 0).detach()             # [2, 512, 128]
+        self.w_ih_t = nn.Parameter(w_ih.t().contiguous(), requires_grad=False)                      # [128, 1024]
+        self.bias = nn.Parameter(bias.clone(), requires_grad=False)
+        self.w_hh = nn.Parameter(w_hh.contiguous(), requires_grad=False)
+
+    @staticmethod
+    def supports(lstm) -> bool:
+        return (isinstance(lstm, nn.LSTM) and lstm.input_size == 128 and lstm.hidden_size == 128 and lstm.num_layers == 1
+                and lstm.bidirectional and lstm.batch_first and lstm.bias and lstm.proj_size == 0
+                and lstm.weight_ih_l0.dtype == torch.float32)
+
+    def forward(self, x):
+        b, t, _ = x.shape
+        gx = torch.addmm(self.bias, x.reshape(b * t, 128), self.w_ih_t).view(b, t, 2, 512)
+        return _fe.bilstm128_forward(gx, self.w_hh), None
+
+
 class InferenceEngine:
     """Inference-only execution of a CustomModel (the c3 path: HIP frontend + SpecAugment + CRNN forward):
       * eval-mode BatchNorm folded into the layer in front of it (`fold_batchnorm`);
       * every Conv2D + bias + ReLU (+ MaxPool) of the conv stack as MIOpen convolution + one HIP epilogue pass; block 1
         (1 or 2 -> 32 -> 32 channels at full resolution) runs in NCHW, where MIOpen's solvers are 40 % faster for the
         32 -> 32 layer, and hands over in NHWC through the pooling epilogue;
+      * the bidirectional LSTM as one GEMM + ONE HIP launch for the whole recurrence (`_HipBiLSTM`);
       * frontend + forward captured into ONE hipGraph (`replay`), when a frontend and an example batch are given.
     Same function as `model.eval()(x)` up to fp32 rounding (GPU test: <= 1e-4 on the sigmoid outputs).  The model
     stays on PyTorch-ROCm (MIOpen / hipBLASLt); only the elementwise epilogues are this repository's kernels."""
 
     def __init__(self, model: "CustomModel", frontend: Optional["WaveFrontend"] = None,
-                 example_wav: Optional[torch.Tensor] = None, fuse_epilogues: bool = True, block1_nchw: bool = True):
+                 example_wav: Optional[torch.Tensor] = None, fuse_epilogues: bool = True, block1_nchw: bool = True,
+                 fuse_lstm: bool = True):
         self.model = fold_batchnorm(model)
         self.fused_convs = 0
+        self.fused_lstm = False
         dev = next(self.model.parameters()).device
         if fuse_epilogues and dev.type == 'cuda':
             first = True
@@ -867,6 +898,9 @@ class InferenceEngine:
                 if has_pool:
                     blk.pool = nn.Identity()
                 self.fused_convs += len(convs)
+        if fuse_lstm and dev.type == 'cuda' and _HipBiLSTM.supports(getattr(self.model, 'lstm', None)):
+            self.model.lstm = _HipBiLSTM(self.model.lstm)
+            self.fused_lstm = True
         self.frontend, self.graph, self.graph_ok, self.graph_error = frontend, None, False, None
         if frontend is not None and example_wav is not None and dev.type == 'cuda':
             self.wav = example_wav

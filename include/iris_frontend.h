@@ -304,6 +304,15 @@ int iris_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* dz, int bat
                              const double* sums, float* dgamma, float* dbeta, void* stream);
 
 /*
+ * Recurrent half of the v9 CRNN's Bidirectional(LSTM(128, return_sequences=True)) for inference (sj_train.py:252), one launch
+ * for all time steps and both directions.  gx [batch, steps, 2, 512] = the input pre-activations x_t W_ih^T + b_ih + b_hh of
+ * direction 0 (forward) and 1 (backward), gate rows in the order i, f, g, o (one GEMM for all steps, done by the caller);
+ * w_hh [2, 512, 128] the recurrent matrices (16-byte aligned); out [batch, steps, 256] = (h forward, h backward) per step;
+ * h_0 = c_0 = 0.  fp32, device pointers, current HIP device.
+ */
+int iris_bilstm128_forward(const float* gx, const float* w_hh, float* out, int batch, int steps, void* stream);
+
+/*
  * Sample synthesis in the complex-STFT domain, deterministic half of
  * merge_complex_specs (pipeline.py:6-110) for a whole batch: every output sample
  * is   background crop (tiled along time, pipeline.py:29-35)

@@ -900,6 +900,33 @@ def test_fused_bn_relu_pool_block_matches_torch(dev, monkeypatch):
         assert float((yc - ya).abs().max()) <= tol(ya) and float((xc.grad - xa.grad).abs().max()) <= tol(xa.grad) * 5
 
 
+def test_hip_bilstm_matches_torch(dev):
+    """iris_bilstm128_forward behind sj_train._HipBiLSTM: the whole bidirectional recurrence in one launch equals
+    torch.nn.LSTM (MIOpen) on the same weights - odd batch sizes (a workgroup owns two rows), one step, long sequences,
+    large pre-activations (saturated gates)."""
+    from challenge_amd import frontend as FE
+    from challenge_amd import sj_train as S
+    torch.manual_seed(11)
+    lstm = torch.nn.LSTM(128, 128, batch_first=True, bidirectional=True).to(dev).eval()
+    with torch.no_grad():
+        for p in lstm.parameters():
+            p.uniform_(-0.25, 0.25)
+    hip = S._HipBiLSTM(lstm).to(dev)
+    # (inputs 30x larger: pre-activations ~ +-100, where the two implementations' fp32 summation orders differ by ~5e-5
+    # before the gates - rounding of the inputs' GEMM, not of the gate functions)
+    for b, t, scale, tol in [(64, 16, 1.0, 2e-6), (1, 1, 1.0, 2e-6), (3, 5, 1.0, 2e-6), (7, 40, 1.0, 2e-6), (5, 16, 30.0, 5e-5)]:
+        x = torch.randn(b, t, 128, device=dev) * scale
+        with torch.no_grad():
+            want, _ = lstm(x)
+            got, none = hip(x)
+        assert none is None and got.shape == want.shape == (b, t, 256)
+        assert float((got - want).abs().max()) <= tol, (b, t, scale, float((got - want).abs().max()))
+    assert not S._HipBiLSTM.supports(torch.nn.LSTM(128, 64, batch_first=True, bidirectional=True))
+    assert not S._HipBiLSTM.supports(torch.nn.LSTM(128, 128, batch_first=True))
+    with pytest.raises(ValueError):
+        FE.bilstm128_forward(torch.zeros(2, 3, 2, 256, device=dev), torch.zeros(2, 512, 128, device=dev))
+
+
 def test_inference_engine_matches_module(dev):
     """InferenceEngine (BatchNorm folded, conv + HIP bias/ReLU/pool epilogue, frontend + forward as one hipGraph) is the
     same function as the training module in eval mode: <= 1e-4 on the sigmoid outputs, eager and replayed."""
@@ -919,7 +946,7 @@ def test_inference_engine_matches_module(dev):
     fe = S.WaveFrontend(1024, 256, 64, 16000, 1, 4, length, dev, training=False)
     wav = torch.randn(4, 1, length, device=dev) * 0.1
     eng = S.InferenceEngine(model, fe, wav)
-    assert eng.fused_convs == 14
+    assert eng.fused_convs == 14 and eng.fused_lstm
     model.eval()
     with torch.no_grad():
         want = model(fe(wav))
