@@ -382,20 +382,43 @@ def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def bilstm128_forward(gx: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
-    """Recurrent half of Bidirectional(LSTM(128, return_sequences=True)) in ONE launch (iris_bilstm128_forward).
-    gx [B, T, 2, 512]: input pre-activations x_t W_ih^T + b_ih + b_hh per direction, gate rows i, f, g, o;
-    w_hh [2, 512, 128]: recurrent matrices.  Returns [B, T, 256] = (h forward, h backward) per step, h_0 = c_0 = 0."""
+def _check_bilstm(gx, w_hh, who):
     if (gx.dim() != 4 or tuple(gx.shape[2:]) != (2, 512) or tuple(w_hh.shape) != (2, 512, 128) or not gx.is_cuda
             or gx.dtype != torch.float32 or w_hh.dtype != torch.float32 or w_hh.device != gx.device):
-        raise ValueError("bilstm128_forward: gx must be a float32 device tensor [B, T, 2, 512], w_hh [2, 512, 128] beside it")
+        raise ValueError(f"{who}: gx must be a float32 device tensor [B, T, 2, 512], w_hh [2, 512, 128] beside it")
+
+
+def bilstm128_forward(gx: torch.Tensor, w_hh: torch.Tensor, save: bool = False):
+    """Recurrent half of Bidirectional(LSTM(128, return_sequences=True)) in ONE launch (iris_bilstm128_forward).
+    gx [B, T, 2, 512]: input pre-activations x_t W_ih^T + b_ih + b_hh per direction, gate rows i, f, g, o;
+    w_hh [2, 512, 128]: recurrent matrices.  Returns [B, T, 256] = (h forward, h backward) per step, h_0 = c_0 = 0;
+    with `save` also the activations [B, T, 2, 5, 128] = (i, f, g, o, c) that `bilstm128_backward` needs."""
+    _check_bilstm(gx, w_hh, "bilstm128_forward")
     gx, w_hh = gx.contiguous(), w_hh.contiguous()
     b, t = int(gx.shape[0]), int(gx.shape[1])
     out = torch.empty((b, t, 256), dtype=torch.float32, device=gx.device)
+    act = torch.empty((b, t, 2, 5, 128), dtype=torch.float32, device=gx.device) if save else None
     with torch.cuda.device(gx.device):
-        rc = N.lib().iris_bilstm128_forward(gx.data_ptr(), w_hh.data_ptr(), out.data_ptr(), b, t, _stream_ptr(gx.device))
+        rc = N.lib().iris_bilstm128_forward(gx.data_ptr(), w_hh.data_ptr(), out.data_ptr(),
+                                            act.data_ptr() if save else None, b, t, _stream_ptr(gx.device))
     N.check(rc, "iris_bilstm128_forward")
-    return out
+    return (out, act) if save else out
+
+
+def bilstm128_backward(dout: torch.Tensor, act: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """Back-propagation through time of `bilstm128_forward` in ONE launch: dout [B, T, 256] and the saved activations ->
+    the gradient of the input pre-activations, dgx [B, T, 2, 512]."""
+    b, t = int(dout.shape[0]), int(dout.shape[1])
+    if (tuple(dout.shape) != (b, t, 256) or tuple(act.shape) != (b, t, 2, 5, 128) or tuple(w_hh.shape) != (2, 512, 128)
+            or not dout.is_cuda or dout.dtype != torch.float32 or act.dtype != torch.float32):
+        raise ValueError("bilstm128_backward: dout [B, T, 256], act [B, T, 2, 5, 128], w_hh [2, 512, 128] (float32, device)")
+    dout, act, w_hh = dout.contiguous(), act.contiguous(), w_hh.contiguous()
+    dgx = torch.empty((b, t, 2, 512), dtype=torch.float32, device=dout.device)
+    with torch.cuda.device(dout.device):
+        rc = N.lib().iris_bilstm128_backward(dout.data_ptr(), act.data_ptr(), w_hh.data_ptr(), dgx.data_ptr(), b, t,
+                                             _stream_ptr(dout.device))
+    N.check(rc, "iris_bilstm128_backward")
+    return dgx
 
 
 class PipelinedFrontend:

@@ -716,7 +716,11 @@ class CustomModel(nn.Module):
         x = torch.relu(self.td(x))
         x = self.fc_pre(x)
         if self.lstm is not None:
-            x, _ = self.lstm(x)
+            if (FUSED_LSTM and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+                    and _lstm_is_bilstm128(self.lstm)):
+                x = bilstm128(self.lstm, x)  # the recurrence (and its backward through time) in one HIP launch each
+            else:
+                x, _ = self.lstm(x)
         return self.head(self.fc_post(x))
 
     # ---- Keras-like training surface ------------------------------------
@@ -834,6 +838,53 @@ class _ConvBiasReLU(nn.Module):
         return _fe.bias_relu_maxpool(y, self.bias) if self.pool else _fe.bias_relu_(y, self.bias)
 
 
+class _BiLSTM128(torch.autograd.Function):
+    """out = recurrence(gx, w_hh) of a bidirectional LSTM(128) with both passes through time inside ONE HIP launch each
+    (iris_bilstm128_forward / _backward).  backward returns dgx (autograd carries it on into W_ih, the biases and x through
+    the GEMM that formed gx) and dW_hh[d] = dgx[:, :, d, :]^T . h_prev, h_prev = the output shifted by one step of d."""
+
+    @staticmethod
+    def forward(ctx, gx, w_hh):
+        out, act = _fe.bilstm128_forward(gx, w_hh, save=True)
+        ctx.save_for_backward(act, w_hh, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        act, w_hh, out = ctx.saved_tensors
+        dgx = _fe.bilstm128_backward(dout, act, w_hh)
+        b, t = out.shape[0], out.shape[1]
+        hprev = torch.zeros((2, b, t, 128), dtype=out.dtype, device=out.device)
+        if t > 1:
+            hprev[0, :, 1:] = out[:, :-1, :128]   # forward direction came from t - 1
+            hprev[1, :, :-1] = out[:, 1:, 128:]   # backward direction came from t + 1
+        dg = dgx.permute(2, 3, 0, 1).reshape(2, 512, b * t)            # [d, gate row, (b, t)]
+        dw_hh = torch.bmm(dg, hprev.reshape(2, b * t, 128))
+        return dgx, dw_hh
+
+
+FUSED_LSTM = os.environ.get("IRIS_FUSED_LSTM", "1") != "0"
+
+
+def _lstm_is_bilstm128(lstm) -> bool:
+    return (isinstance(lstm, nn.LSTM) and lstm.input_size == 128 and lstm.hidden_size == 128 and lstm.num_layers == 1
+            and lstm.bidirectional and lstm.batch_first and lstm.bias and lstm.proj_size == 0
+            and lstm.weight_ih_l0.dtype == torch.float32)
+
+
+def bilstm128(lstm: nn.LSTM, x: torch.Tensor) -> torch.Tensor:
+    """`lstm(x)[0]` for the model's nn.LSTM(128, 128, bidirectional, batch_first) with the recurrence - and, under
+    autograd, its back-propagation through time - in one HIP launch each; the parameters stay the module's own."""
+    b, t, _ = x.shape
+    w_ih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], 0)                               # [1024, 128]
+    bias = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse], 0)
+    w_hh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse], 0)                              # [2, 512, 128]
+    gx = torch.nn.functional.linear(x.reshape(b * t, 128), w_ih, bias).view(b, t, 2, 512)
+    if torch.is_grad_enabled() and (gx.requires_grad or w_hh.requires_grad):
+        return _BiLSTM128.apply(gx, w_hh)
+    return _fe.bilstm128_forward(gx, w_hh)
+
+
 class _HipBiLSTM(nn.Module):
     """Inference form of the model's nn.LSTM(128, 128, bidirectional, batch_first): ONE GEMM for the input projections of
     all steps and both directions, then the whole recurrence in ONE HIP launch (iris_bilstm128_forward; MIOpen runs a GEMM
@@ -852,9 +903,7 @@ class _HipBiLSTM(nn.Module):
 
     @staticmethod
     def supports(lstm) -> bool:
-        return (isinstance(lstm, nn.LSTM) and lstm.input_size == 128 and lstm.hidden_size == 128 and lstm.num_layers == 1
-                and lstm.bidirectional and lstm.batch_first and lstm.bias and lstm.proj_size == 0
-                and lstm.weight_ih_l0.dtype == torch.float32)
+        return _lstm_is_bilstm128(lstm)
 
     def forward(self, x):
         b, t, _ = x.shape

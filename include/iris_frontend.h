@@ -304,13 +304,19 @@ int iris_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* dz, int bat
                              const double* sums, float* dgamma, float* dbeta, void* stream);
 
 /*
- * Recurrent half of the v9 CRNN's Bidirectional(LSTM(128, return_sequences=True)) for inference (sj_train.py:252), one launch
- * for all time steps and both directions.  gx [batch, steps, 2, 512] = the input pre-activations x_t W_ih^T + b_ih + b_hh of
+ * Recurrent half of the v9 CRNN's Bidirectional(LSTM(128, return_sequences=True)) (sj_train.py:252), one launch for all
+ * time steps and both directions.  gx [batch, steps, 2, 512] = the input pre-activations x_t W_ih^T + b_ih + b_hh of
  * direction 0 (forward) and 1 (backward), gate rows in the order i, f, g, o (one GEMM for all steps, done by the caller);
  * w_hh [2, 512, 128] the recurrent matrices (16-byte aligned); out [batch, steps, 256] = (h forward, h backward) per step;
- * h_0 = c_0 = 0.  fp32, device pointers, current HIP device.
+ * h_0 = c_0 = 0.  act: NULL for inference; for training [batch, steps, 2, 5, 128] receives (i, f, g, o, c) of every step.
+ * iris_bilstm128_backward: dout [batch, steps, 256] and the saved act -> dgx [batch, steps, 2, 512], the gradient of the
+ * pre-activations (back-propagation through time inside the launch); dW_ih, db, dx follow from dgx through the caller's GEMM,
+ * dW_hh[d] = dgx[:, :, d, :]^T . h_prev with h_prev = out shifted by one step of direction d.
+ * fp32, device pointers, current HIP device.
  */
-int iris_bilstm128_forward(const float* gx, const float* w_hh, float* out, int batch, int steps, void* stream);
+int iris_bilstm128_forward(const float* gx, const float* w_hh, float* out, float* act, int batch, int steps, void* stream);
+int iris_bilstm128_backward(const float* dout, const float* act, const float* w_hh, float* dgx, int batch, int steps,
+                            void* stream);
 
 /*
  * Sample synthesis in the complex-STFT domain, deterministic half of

@@ -109,9 +109,11 @@ def test_round3_entry_points_validate_before_any_launch():
     assert lib.iris_timing_samples(None, 0, None, 0, C.byref(n)) == INVALID
     assert lib.iris_timing_enable(None, 1) == INVALID
     assert lib.iris_plan_kernel_name(None, 32, None, 0) == INVALID
-    assert lib.iris_bilstm128_forward(None, p16, p16, 4, 16, None) == INVALID
-    assert lib.iris_bilstm128_forward(p16, p8, p16, 4, 16, None) == INVALID     # w_hh must be 16-byte aligned
-    assert lib.iris_bilstm128_forward(p16, p16, p16, 0, 16, None) == INVALID
+    assert lib.iris_bilstm128_forward(None, p16, p16, None, 4, 16, None) == INVALID
+    assert lib.iris_bilstm128_forward(p16, p8, p16, None, 4, 16, None) == INVALID     # w_hh must be 16-byte aligned
+    assert lib.iris_bilstm128_forward(p16, p16, p16, None, 0, 16, None) == INVALID
+    assert lib.iris_bilstm128_backward(p16, None, p16, p16, 4, 16, None) == INVALID
+    assert lib.iris_bilstm128_backward(p16, p16, p16, p16, 4, 0, None) == INVALID
     assert lib.iris_bn_relu_pool_apply(None, None, 1, 4, 4, 8, None, None, None, None, 1e-3, 0.01, None, None, None, None, None) == INVALID
     assert lib.iris_bn_relu_pool_apply(p16, p16, 0, 4, 4, 8, p16, p16, p16, None, 1e-3, 0.01, p16, p16, p16, p16, None) == INVALID
     assert lib.iris_bn_relu_pool_bwd_reduce(p16, None, 1, 4, 4, 8, p16, p16, p16, p16, p16, None) == INVALID

@@ -927,6 +927,38 @@ def test_hip_bilstm_matches_torch(dev):
         FE.bilstm128_forward(torch.zeros(2, 3, 2, 256, device=dev), torch.zeros(2, 512, 128, device=dev))
 
 
+def test_hip_bilstm_training_matches_torch(dev):
+    """sj_train.bilstm128 under autograd: output, input gradient and the gradients of all eight nn.LSTM parameters equal
+    torch's own (MIOpen) LSTM - back-propagation through time inside iris_bilstm128_backward, dW_hh from its dgx."""
+    import copy
+    from challenge_amd import sj_train as S
+    torch.manual_seed(12)
+    lstm = torch.nn.LSTM(128, 128, batch_first=True, bidirectional=True).to(dev)
+    with torch.no_grad():
+        for p in lstm.parameters():
+            p.uniform_(-0.3, 0.3)
+    ref = copy.deepcopy(lstm)
+    for b, t in [(64, 16), (3, 1), (5, 7), (2, 33)]:
+        lstm.zero_grad()
+        ref.zero_grad()
+        x = torch.randn(b, t, 128, device=dev)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        g = torch.randn(b, t, 256, device=dev)
+        ya = S.bilstm128(lstm, xa)
+        assert ya.grad_fn.name().startswith("_BiLSTM128")
+        ya.backward(g)
+        yb, _ = ref(xb)
+        yb.backward(g)
+        tol = lambda v: 2e-5 * float(v.abs().max()) + 1e-6  # noqa: E731
+        assert float((ya - yb).abs().max()) <= 2e-6
+        assert float((xa.grad - xb.grad).abs().max()) <= tol(xb.grad), (b, t)
+        for (n, pa), (_, pb) in zip(lstm.named_parameters(), ref.named_parameters()):
+            assert float((pa.grad - pb.grad).abs().max()) <= tol(pb.grad), (n, b, t)
+    # no autograd: the plain launch
+    with torch.no_grad():
+        assert float((S.bilstm128(lstm, x) - ref(x)[0]).abs().max()) <= 2e-6
+
+
 def test_inference_engine_matches_module(dev):
     """InferenceEngine (BatchNorm folded, conv + HIP bias/ReLU/pool epilogue, frontend + forward as one hipGraph) is the
     same function as the training module in eval mode: <= 1e-4 on the sigmoid outputs, eager and replayed."""
