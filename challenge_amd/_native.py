@@ -47,6 +47,7 @@ SIGNATURES = {
     "iris_mix_specs": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "iris_mix_wave_frame_active": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "iris_mix_waves": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "iris_bn_sums_len": (_sz, [_i]),
     "iris_bn_stats": (_i, [_vp, _sz, _i, _vp, _vp]),
     "iris_bn_relu_apply": (_i, [_vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_bwd_reduce": (_i, [_vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -468,6 +468,7 @@ static int bn_check(const void* a, const void* b, size_t rows, int channels, con
         return fail(IRIS_E_UNSUPPORTED, "%s: rows %zu, channels %d (a positive multiple of 4, <= 4096)", who, rows, channels);
     return IRIS_OK;
 }
+static int grid_bn(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 2048); }  // fat blocks: the per-block coefficient setup is amortised
 static unsigned bn_reduce_grid(size_t rows, int C4, int rows_per_pass = kBnRows) {
     const int cols = std::min(C4, 256), tys = 256 / cols;
     return (unsigned)((rows + (size_t)rows_per_pass * tys - 1) / ((size_t)rows_per_pass * tys));
@@ -476,6 +477,8 @@ static size_t bn_reduce_lds(int C4) {
     const int cols = std::min(C4, 256), tys = 256 / cols;
     return (size_t)tys * 2 * cols * 4 * sizeof(float);
 }
+
+extern "C" size_t iris_bn_sums_len(int channels) { return channels > 0 ? (size_t)bn_slots(channels) * 2 * channels : 0; }
 
 extern "C" int iris_bn_stats(const float* z, size_t rows, int channels, double* sums_zeroed, void* stream) {
     int rc = bn_check(z, sums_zeroed, rows, channels, "iris_bn_stats");
@@ -496,7 +499,7 @@ extern "C" int iris_bn_relu_apply(const float* z, float* y, size_t rows, int cha
         return fail(IRIS_E_INVALID, "iris_bn_relu_apply: NULL argument");
     const size_t n4 = rows * (size_t)(channels / 4);
     const double m = (double)rows;
-    k_bn_relu_apply<<<grid_for(n4), 256, 2 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(z, y, n4, channels / 4, 1.0 / m, rows > 1 ? m / (m - 1.0) : 1.0, sums,
+    k_bn_relu_apply<<<grid_bn(n4), 256, 2 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(z, y, n4, channels / 4, 1.0 / m, rows > 1 ? m / (m - 1.0) : 1.0, sums,
                                                                    gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
                                                                    save_mean, save_rstd);
     HIP_TRY(hipGetLastError());
@@ -524,7 +527,7 @@ extern "C" int iris_bn_relu_bwd_dx(const float* z, const float* dy, float* dz, s
     if (!dy || !save_mean || !save_rstd || !gamma || !beta || !sums || !dgamma || !dbeta)
         return fail(IRIS_E_INVALID, "iris_bn_relu_bwd_dx: NULL argument");
     const size_t n4 = rows * (size_t)(channels / 4);
-    k_bn_relu_bwd_dx<<<grid_for(n4), 256, 4 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
+    k_bn_relu_bwd_dx<<<grid_bn(n4), 256, 4 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
         z, dy, dz, n4, channels / 4, (float)(1.0 / (double)rows), save_mean, save_rstd, gamma, beta, sums, dgamma, dbeta);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
@@ -547,7 +550,7 @@ extern "C" int iris_bn_relu_pool_apply(const float* z, float* p, int batch, int 
         return fail(IRIS_E_INVALID, "iris_bn_relu_pool_apply: NULL argument");
     const size_t n4 = (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
     const double m = (double)batch * height * width;  // the statistics are those of the full-size activation
-    k_bn_relu_pool_apply<<<grid_for(n4), 256, 2 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
+    k_bn_relu_pool_apply<<<grid_bn(n4), 256, 2 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
         z, p, batch, height, width, channels / 4, 1.0 / m, m > 1.0 ? m / (m - 1.0) : 1.0, sums, gamma, beta, conv_bias, eps, momentum,
         running_mean, running_var, save_mean, save_rstd);
     HIP_TRY(hipGetLastError());
@@ -577,7 +580,7 @@ extern "C" int iris_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* 
         return fail(IRIS_E_INVALID, "iris_bn_relu_pool_bwd_dx: NULL argument");
     const size_t n4 = (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
     const double m = (double)batch * height * width;
-    k_bn_relu_pool_bwd_dx<<<grid_for(n4), 256, 4 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
+    k_bn_relu_pool_bwd_dx<<<grid_bn(n4), 256, 4 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
         z, dp, dz, batch, height, width, channels / 4, (float)(1.0 / m), save_mean, save_rstd, gamma, beta, sums, dgamma, dbeta);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;

@@ -345,6 +345,24 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool_nchw(const float* x, con
 #ifndef IRIS_BN_POOL_ROWS
 #define IRIS_BN_POOL_ROWS 8
 #endif
+#ifndef IRIS_BN_SLOTS
+#define IRIS_BN_SLOTS 8
+#endif
+// The per-channel sums are accumulated by fp64 atomics of every block.  A 32-channel layer has 64 addresses and 2048
+// blocks: the same-address atomics queue up behind one another.  Blocks therefore add into one of kBnSlots copies
+// (sums[slot][2][C], slot = block % bn_slots(C)) and the consumers add the copies up while they form their per-channel
+// coefficients (their blocks are fat - at most 2048 per launch - so that this setup is amortised).  A last-block fold behind an
+// arrival counter was measured too: the counter is one more hot address (reductions 0.88 -> 0.99 ms per step).
+constexpr int kBnSlots = IRIS_BN_SLOTS;  // at most; bn_slots(channels) of them are used (wide layers have few blocks per address)
+__host__ __device__ constexpr int bn_slots(int channels) {
+    return channels <= 64 ? kBnSlots : channels <= 128 ? kBnSlots / 2 : channels <= 256 ? kBnSlots / 4 : 1;
+}
+__device__ __forceinline__ double bn_sum(const double* sums, int C, int i) {
+    const int n = bn_slots(C);
+    double v = 0.0;
+    for (int s = 0; s < n; ++s) v += sums[(size_t)s * 2 * C + i];
+    return v;
+}
 constexpr int kBnRows = IRIS_BN_ROWS;           // rows per thread-row pass
 constexpr int kBnPoolRows = IRIS_BN_POOL_ROWS;  // pooled rows (windows of four) per thread-row pass: 4x the blocks of the same tensor
 
@@ -403,7 +421,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float* z, const float* 
             double acc = 0.0;
             for (int t = 0; t < tys; ++t) acc += (double)red[((size_t)t * 2 * cols) * 4 + (size_t)which * cols * 4 + j];
             const int cc = c0 * 4 + j;
-            if (cc < 4 * C4) atomicAdd(sums + (size_t)which * 4 * C4 + cc, acc);
+            if (cc < 4 * C4) atomicAdd(sums + (size_t)(blockIdx.x % bn_slots(4 * C4)) * 8 * C4 + (size_t)which * 4 * C4 + cc, acc);
         }
         __syncthreads();
     }
@@ -416,7 +434,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* z, float* y,
     extern __shared__ float coef[];  // [2][C]: scale = gamma rstd, shift = beta - mean scale  (y = max(z scale + shift, 0))
     const int C = 4 * C4;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double m = sums[c] * inv_m, var = fmax(sums[C + c] * inv_m - m * m, 0.0);
+        const double m = bn_sum(sums, C, c) * inv_m, var = fmax(bn_sum(sums, C, C + c) * inv_m - m * m, 0.0);
         const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
         coef[c] = gamma[c] * rs;
         coef[C + c] = beta[c] - mu * (gamma[c] * rs);
@@ -454,7 +472,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_dx(const float* z, const fl
     extern __shared__ float coef[];  // [4][C]
     const int C = 4 * C4;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float sg = (float)sums[c], sgx = (float)sums[C + c];
+        const float sg = (float)bn_sum(sums, C, c), sgx = (float)bn_sum(sums, C, C + c);
         const float a = gamma[c] * rstd[c], b = -a * rstd[c] * sgx * inv_m;
         coef[c] = a;
         coef[C + c] = b;
@@ -513,7 +531,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_pool_apply(const float* z, floa
     extern __shared__ float coef[];  // [2][C], formed exactly as k_bn_relu_apply forms them
     const int C = 4 * C4;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double m = sums[c] * inv_m, var = fmax(sums[C + c] * inv_m - m * m, 0.0);
+        const double m = bn_sum(sums, C, c) * inv_m, var = fmax(bn_sum(sums, C, C + c) * inv_m - m * m, 0.0);
         const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
         coef[c] = gamma[c] * rs;
         coef[C + c] = beta[c] - mu * (gamma[c] * rs);
@@ -622,7 +640,7 @@ __global__ __launch_bounds__(256) void k_bn_pool_bwd_reduce(const float* z, cons
             double acc = 0.0;
             for (int t = 0; t < tys; ++t) acc += (double)red[((size_t)t * 2 * cols) * 4 + (size_t)which * cols * 4 + j];
             const int cc = c0 * 4 + j;
-            if (cc < 4 * C4) atomicAdd(sums + (size_t)which * 4 * C4 + cc, acc);
+            if (cc < 4 * C4) atomicAdd(sums + (size_t)(blockIdx.x % bn_slots(4 * C4)) * 8 * C4 + (size_t)which * 4 * C4 + cc, acc);
         }
         __syncthreads();
     }
@@ -634,7 +652,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_pool_bwd_dx(const float* z, con
     extern __shared__ float coef[];  // [4][C], as k_bn_relu_bwd_dx
     const int C = 4 * C4;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float sg = (float)sums[c], sgx = (float)sums[C + c];
+        const float sg = (float)bn_sum(sums, C, c), sgx = (float)bn_sum(sums, C, C + c);
         const float a = gamma[c] * rstd[c], b = -a * rstd[c] * sgx * inv_m;
         coef[c] = a;
         coef[C + c] = b;

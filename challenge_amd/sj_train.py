@@ -521,7 +521,7 @@ class _FusedBiasBNReLU(torch.autograd.Function):
         rows = b * h * w
         dev = z.device
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        sums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+        sums = torch.zeros(int(N.lib().iris_bn_sums_len(c)), dtype=torch.float64, device=dev)
         if pool:
             y = torch.empty((b, c, (h + 1) // 2, (w + 1) // 2), dtype=z.dtype, device=dev, memory_format=torch.channels_last)
         else:
@@ -555,7 +555,7 @@ class _FusedBiasBNReLU(torch.autograd.Function):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
-        sums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+        sums = torch.zeros(int(N.lib().iris_bn_sums_len(c)), dtype=torch.float64, device=dev)
         dz = torch.empty_like(z)
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)

@@ -265,14 +265,17 @@ int iris_bias_relu_maxpool(const float* x, const float* bias, float* y, int batc
  * normalise, ReLU; ReLU', dscale / dbias, dx, bias gradient).  The convolution stays MIOpen and is run WITHOUT bias:
  * batch normalisation removes the batch mean, so the output does not depend on the bias - it only shifts the running
  * mean (conv_bias, nullable, is added there) - and the bias gradient is identically zero.
- *   forward : iris_bn_stats (sums_zeroed: DEVICE double [2 * channels], zero on entry: per-channel sum, sum of squares)
+ *   forward : iris_bn_stats (sums_zeroed: DEVICE double [iris_bn_sums_len(channels)], zero on entry: per-channel sum and sum
+ *             of squares, spread over several copies so that the blocks' atomics do not queue on one address; the
+ *             consumers below add the copies up)
  *             iris_bn_relu_apply: y = max(gamma (z - mean) rstd + beta, 0), biased variance; running_mean / running_var
  *             updated in place ((1 - momentum) old + momentum new, unbiased variance); save_mean / save_rstd [channels] out
- *   backward: iris_bn_relu_bwd_reduce (sums_zeroed [2 * channels]: sum g, sum g xhat with g = dy [y > 0]; the mask is
+ *   backward: iris_bn_relu_bwd_reduce (sums_zeroed, same length: sum g, sum g xhat with g = dy [y > 0]; the mask is
  *             recomputed from z with the forward's own expression, y is not read)
  *             iris_bn_relu_bwd_dx: dz = gamma rstd (g - sum_g / M - xhat sum_gx / M); dgamma = sum g xhat, dbeta = sum g
  * channels: a multiple of 4, <= 4096; every pointer DEVICE, 16-byte aligned tensors.  Run on the current HIP device.
  */
+size_t iris_bn_sums_len(int channels);
 int iris_bn_stats(const float* z, size_t rows, int channels, double* sums_zeroed, void* stream);
 int iris_bn_relu_apply(const float* z, float* y, size_t rows, int channels, const double* sums, const float* gamma,
                        const float* beta, const float* conv_bias, float eps, float momentum, float* running_mean,
