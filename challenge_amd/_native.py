@@ -55,6 +55,7 @@ SIGNATURES = {
     "iris_bn_relu_pool_apply": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_pool_bwd_reduce": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_pool_bwd_dx": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "iris_conv3x3_small_bias_relu_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "iris_bilstm128_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "iris_bilstm128_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "iris_mix_draw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, C.c_uint64, _vp, _vp, _vp, _vp]),

@@ -14,7 +14,8 @@
 //   k_elementwise.h  min-max / log, normalize, magnitude-phase, mask, adaptive gradient clipping
 //   k_mix.h          batched sample synthesis (merge_complex_specs)
 //   k_draw.h         the random half of a batch drawn on the device (source table, SpecAugment bands)
-//   k_lstm.h         the recurrent half of the CRNN's bidirectional LSTM (inference)
+//   k_lstm.h         the CRNN's bidirectional LSTM: forward and backward through time, one launch each
+//   k_conv_small.h   the CRNN's first convolution (1-2 input channels) with bias + ReLU, one pass
 //   host_plan.h      mel matrix, constant tables, plan create / destroy
 //   host_ops.h       the operators' C-ABI entry points
 #include "common.h"
@@ -29,3 +30,4 @@
 #include "k_mix.h"
 #include "k_draw.h"
 #include "k_lstm.h"
+#include "k_conv_small.h"

@@ -382,6 +382,23 @@ def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def conv3x3_small_bias_relu_nchw(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """relu(conv2d(x, weight, padding=1) + bias) for a contiguous [B, 1 or 2, H, W] input in ONE pass
+    (iris_conv3x3_small_bias_relu_nchw): the CRNN's first layer, which writes 16-32x what it reads."""
+    if (x.dim() != 4 or not x.is_contiguous() or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] not in (1, 2)
+            or tuple(weight.shape[1:]) != (x.shape[1], 3, 3) or not weight.is_contiguous() or x.shape[3] % 4):
+        raise ValueError("conv3x3_small_bias_relu_nchw: x must be a contiguous float32 device tensor [B, 1|2, H, W], W % 4 == 0, "
+                         "weight [Cout, Cin, 3, 3] contiguous")
+    b, cin, h, w = (int(v) for v in x.shape)
+    cout = int(weight.shape[0])
+    y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = N.lib().iris_conv3x3_small_bias_relu_nchw(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), b, cin, cout,
+                                                       h, w, _stream_ptr(x.device))
+    N.check(rc, "iris_conv3x3_small_bias_relu_nchw")
+    return y
+
+
 def _check_bilstm(gx, w_hh, who):
     if (gx.dim() != 4 or tuple(gx.shape[2:]) != (2, 512) or tuple(w_hh.shape) != (2, 512, 128) or not gx.is_cuda
             or gx.dtype != torch.float32 or w_hh.dtype != torch.float32 or w_hh.device != gx.device):

@@ -828,6 +828,10 @@ class _ConvBiasReLU(nn.Module):
                 x = x.as_strided((b, c, h, w), (h * w, h * w, w, 1)) if x.stride(3) == 1 and x.stride(2) == w else x.contiguous()
             else:
                 x = x.contiguous()
+            if (not self.pool and x.shape[1] <= 2 and tuple(self.weight.shape[2:]) == (3, 3) and tuple(self.padding) == (1, 1)
+                    and x.shape[3] % 4 == 0 and x.dtype == torch.float32):
+                # the model's first layer: a 9 / 18-tap stencil bound by its output stream - convolution, bias, ReLU in one pass
+                return _fe.conv3x3_small_bias_relu_nchw(x, self.weight, self.bias)
             y = torch.nn.functional.conv2d(x, self.weight, None, padding=self.padding)
             if not y.is_contiguous():
                 y = y.contiguous()

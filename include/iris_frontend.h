@@ -307,6 +307,15 @@ int iris_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* dz, int bat
                              const double* sums, float* dgamma, float* dbeta, void* stream);
 
 /*
+ * First convolution of the CRNN (ConvMPBlock's Conv2D(32, 3, padding='same') on the n_chan-channel log-mel input,
+ * sj_train.py:191-201, 244) with its (BatchNorm-folded) bias and ReLU in ONE pass, NCHW: x [batch, in_channels (1 or 2),
+ * height, width], weight [out_channels, in_channels, 3, 3], bias [out_channels] -> y [batch, out_channels, height, width].
+ * The layer writes 16-32x what it reads; every output byte is written once.  width a multiple of 4; x, y 16-byte aligned.
+ */
+int iris_conv3x3_small_bias_relu_nchw(const float* x, const float* weight, const float* bias, float* y, int batch,
+                                      int in_channels, int out_channels, int height, int width, void* stream);
+
+/*
  * Recurrent half of the v9 CRNN's Bidirectional(LSTM(128, return_sequences=True)) (sj_train.py:252), one launch for all
  * time steps and both directions.  gx [batch, steps, 2, 512] = the input pre-activations x_t W_ih^T + b_ih + b_hh of
  * direction 0 (forward) and 1 (backward), gate rows in the order i, f, g, o (one GEMM for all steps, done by the caller);

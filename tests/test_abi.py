@@ -109,6 +109,10 @@ def test_round3_entry_points_validate_before_any_launch():
     assert lib.iris_timing_samples(None, 0, None, 0, C.byref(n)) == INVALID
     assert lib.iris_timing_enable(None, 1) == INVALID
     assert lib.iris_plan_kernel_name(None, 32, None, 0) == INVALID
+    assert lib.iris_conv3x3_small_bias_relu_nchw(None, p16, p16, p16, 1, 1, 32, 8, 8, None) == INVALID
+    assert lib.iris_conv3x3_small_bias_relu_nchw(p16, p16, p16, p16, 1, 3, 32, 8, 8, None) == UNSUPPORTED   # 1 or 2 input channels
+    assert lib.iris_conv3x3_small_bias_relu_nchw(p16, p16, p16, p16, 1, 1, 32, 8, 6, None) == UNSUPPORTED   # width % 4
+    assert lib.iris_conv3x3_small_bias_relu_nchw(p8, p16, p16, p16, 1, 1, 32, 8, 8, None) == INVALID        # alignment
     assert lib.iris_bilstm128_forward(None, p16, p16, None, 4, 16, None) == INVALID
     assert lib.iris_bilstm128_forward(p16, p8, p16, None, 4, 16, None) == INVALID     # w_hh must be 16-byte aligned
     assert lib.iris_bilstm128_forward(p16, p16, p16, None, 0, 16, None) == INVALID

@@ -900,6 +900,25 @@ def test_fused_bn_relu_pool_block_matches_torch(dev, monkeypatch):
         assert float((yc - ya).abs().max()) <= tol(ya) and float((xc.grad - xa.grad).abs().max()) <= tol(xa.grad) * 5
 
 
+def test_first_conv_bias_relu_one_pass(dev):
+    """iris_conv3x3_small_bias_relu_nchw (the CRNN's first layer, 1 or 2 input channels): equals relu(conv2d + bias) on
+    odd heights, one-row and one-column-group images, and negative biases."""
+    from challenge_amd import frontend as FE
+    torch.manual_seed(13)
+    for b, cin, cout, h, w in [(3, 1, 32, 16, 40), (2, 2, 32, 9, 8), (1, 1, 7, 1, 4), (2, 2, 5, 3, 132), (64, 1, 32, 64, 512)]:
+        x = torch.randn(b, cin, h, w, device=dev)
+        wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.3
+        bias = torch.randn(cout, device=dev) * 0.5
+        want = torch.relu(torch.nn.functional.conv2d(x, wt, bias, padding=1))
+        got = FE.conv3x3_small_bias_relu_nchw(x, wt, bias)
+        assert got.shape == want.shape and got.is_contiguous()
+        assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (b, cin, cout, h, w)
+    with pytest.raises(ValueError):
+        FE.conv3x3_small_bias_relu_nchw(torch.zeros(1, 3, 4, 4, device=dev), torch.zeros(8, 3, 3, 3, device=dev), torch.zeros(8, device=dev))
+    with pytest.raises(ValueError):
+        FE.conv3x3_small_bias_relu_nchw(torch.zeros(1, 1, 4, 6, device=dev), torch.zeros(8, 1, 3, 3, device=dev), torch.zeros(8, device=dev))
+
+
 def test_hip_bilstm_matches_torch(dev):
     """iris_bilstm128_forward behind sj_train._HipBiLSTM: the whole bidirectional recurrence in one launch equals
     torch.nn.LSTM (MIOpen) on the same weights - odd batch sizes (a workgroup owns two rows), one step, long sequences,
