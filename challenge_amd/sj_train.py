@@ -1134,7 +1134,7 @@ def init_distributed():
 # first two convolutions and everything below) and its all-reduce starts only when backward has finished, fully exposed; with
 # 12 MB the buckets are 0.9 / 7.2 / 9.4 / 9.4 / 11.8 / 0.7 MB - the 11.8 MB one goes out while blocks 2 and 1 (40 % of backward)
 # still compute, and what is left after backward is 0.7 MB.
-DDP_BUCKET_MB = 12
+DDP_BUCKET_MB = int(os.environ.get("IRIS_DDP_BUCKET_MB", "12"))
 
 
 def wrap_ddp(model: CustomModel, device, world: int):
