@@ -1041,6 +1041,8 @@ def make_optimizer(config, params):
     # parameter (86 fills of ~3.6 us each per step otherwise)
     fe = bool(params) and params[0].is_cuda
     if config.optimizer == 'adam':
+        if fe and os.environ.get("IRIS_ADAM_FUSED", "1") != "0":  # the whole update in one multi-tensor launch
+            return torch.optim.Adam(params, lr=config.lr, eps=1e-7, fused=True)
         return torch.optim.Adam(params, lr=config.lr, eps=1e-7, foreach=fe)  # Keras Adam epsilon
     if config.optimizer == 'sgd':
         return torch.optim.SGD(params, lr=config.lr, momentum=0.9, foreach=fe)
