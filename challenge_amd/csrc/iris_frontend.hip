@@ -15,7 +15,8 @@
 //   k_mix.h          batched sample synthesis (merge_complex_specs)
 //   k_draw.h         the random half of a batch drawn on the device (source table, SpecAugment bands)
 //   k_lstm.h         the CRNN's bidirectional LSTM: forward and backward through time, one launch each
-//   k_conv_small.h   the CRNN's first convolution (1-2 input channels) with bias + ReLU, one pass
+//   k_conv_small.h   the CRNN's first convolution (1-2 input channels) with bias + ReLU, one pass (inference)
+//   k_conv0_bn.h     the same layer in training mode: convolution recomputed inside the BatchNorm + ReLU passes
 //   host_plan.h      mel matrix, constant tables, plan create / destroy
 //   host_ops.h       the operators' C-ABI entry points
 #include "common.h"
@@ -31,3 +32,4 @@
 #include "k_draw.h"
 #include "k_lstm.h"
 #include "k_conv_small.h"
+#include "k_conv0_bn.h"

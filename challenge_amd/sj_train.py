@@ -575,6 +575,79 @@ class _FusedBiasBNReLU(torch.autograd.Function):
         return dz, dbias, dgamma, dbeta, None, None, None, None, None
 
 
+class _FusedConv0BNReLU(torch.autograd.Function):
+    """relu(batch_norm(conv2d(x, w) + conv_bias)) for the model's FIRST layer (1 or 2 input channels, 3x3 'same') in training
+    mode, the convolution recomputed inside every pass (iris_conv0_*): its output - 32x the input - is never stored.
+    x gets no gradient (it is the feature tensor); the bias gradient is identically zero (BatchNorm removes the mean)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, conv_bias, gamma, beta, running_mean, running_var, eps, momentum):
+        import ctypes as C
+        from . import _native as N
+        b, cin, h, w = (int(v) for v in x.shape)
+        cout = int(weight.shape[0])
+        dev = x.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        xc = x.contiguous()                     # [B, CIN, H, W]; one channel: the channels_last tensor already is
+        wc = weight.detach().contiguous()       # [COUT, CIN, 3, 3]
+        lib = N.lib()
+        sums = torch.zeros(int(lib.iris_bn_sums_len(cout)), dtype=torch.float64, device=dev)
+        y = torch.empty((b, cout, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        save_mean = torch.empty(cout, dtype=torch.float32, device=dev)
+        save_rstd = torch.empty(cout, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(lib.iris_conv0_stats(xc.data_ptr(), wc.data_ptr(), b, cin, cout, h, w, sums.data_ptr(), stream), "iris_conv0_stats")
+            N.check(lib.iris_conv0_bn_relu(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), b, cin, cout, h, w, sums.data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(),
+                                           conv_bias.data_ptr() if conv_bias is not None else None, float(eps), float(momentum),
+                                           running_mean.data_ptr(), running_var.data_ptr(), save_mean.data_ptr(),
+                                           save_rstd.data_ptr(), stream), "iris_conv0_bn_relu")
+        ctx.save_for_backward(xc, wc, gamma, beta, save_mean, save_rstd)
+        ctx.has_bias = conv_bias is not None
+        ctx.weight_format = (torch.channels_last if weight.is_contiguous(memory_format=torch.channels_last)
+                             and not weight.is_contiguous() else torch.contiguous_format)
+        ctx.mark_non_differentiable(running_mean, running_var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        from . import _native as N
+        xc, wc, gamma, beta, save_mean, save_rstd = ctx.saved_tensors
+        b, cin, h, w = (int(v) for v in xc.shape)
+        cout = int(wc.shape[0])
+        dev = xc.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        lib = N.lib()
+        sums = torch.zeros(int(lib.iris_bn_sums_len(cout)), dtype=torch.float64, device=dev)
+        dw64 = torch.zeros(int(lib.iris_conv0_dweight_len(cin, cout)), dtype=torch.float64, device=dev)
+        dgamma = torch.empty(cout, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(lib.iris_conv0_bn_relu_backward(xc.data_ptr(), wc.data_ptr(), dy.data_ptr(), b, cin, cout, h, w,
+                                                    save_mean.data_ptr(), save_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                    sums.data_ptr(), dw64.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream),
+                    "iris_conv0_bn_relu_backward")
+        dw = dw64.view(-1, cout, cin, 3, 3).sum(0).to(torch.float32).contiguous(memory_format=ctx.weight_format)
+        dbias = torch.zeros(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        return None, dw, dbias, dgamma, dbeta, None, None, None, None
+
+
+FUSED_CONV0 = os.environ.get("IRIS_FUSED_CONV0", "1") != "0"
+
+
+def _is_first_layer_conv(conv, x) -> bool:
+    def pair(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    co = conv.out_channels
+    return (conv.in_channels in (1, 2) and pair(conv.kernel_size) == (3, 3) and pair(conv.padding) == (1, 1)
+            and pair(conv.stride) == (1, 1) and pair(conv.dilation) == (1, 1) and conv.groups == 1
+            and co % 4 == 0 and co <= 256 and 1024 % co == 0 and not x.requires_grad and x.dim() == 4
+            and x.shape[3] <= 2048)
+
+
 class _ConvBNReLU(nn.Sequential):
     def __init__(self, cin, cout, k=3, bn=True):
         layers = [nn.Conv2d(cin, cout, k, padding=k // 2)]
@@ -590,6 +663,10 @@ class _ConvBNReLU(nn.Sequential):
                 and not torch.is_autocast_enabled()):
             conv, bn = self[0], self[1]
             if x.dtype == torch.float32 and conv.out_channels % 4 == 0 and bn.track_running_stats and bn.momentum is not None:
+                if FUSED_CONV0 and pool is None and _is_first_layer_conv(conv, x):
+                    bn.num_batches_tracked.add_(1)  # the model's first layer: convolution recomputed inside the passes
+                    return _FusedConv0BNReLU.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                                   bn.running_var, bn.eps, bn.momentum)
                 z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
                 if z.is_contiguous(memory_format=torch.channels_last):
                     bn.num_batches_tracked.add_(1)

@@ -307,6 +307,29 @@ int iris_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* dz, int bat
                              const double* sums, float* dgamma, float* dbeta, void* stream);
 
 /*
+ * The CRNN's first layer in TRAINING mode - Conv2D(3x3 'same', 1 or 2 input channels) + BatchNormalization + ReLU
+ * (sj_train.py:191-201, 244) - with the convolution recomputed from x wherever its output is needed (9-18 FMAs per value
+ * against 4 bytes of traffic): z is never stored.  x [batch, in_channels, height, width] contiguous; weight
+ * [out_channels, in_channels, 3, 3] contiguous; y / dy [batch, height, width, out_channels] (channels-last); out_channels
+ * in {4, 8, ..., 256} dividing 1024.  The convolution runs WITHOUT bias (see iris_bn_stats); x gets no gradient.
+ *   forward : iris_conv0_stats (sums_zeroed as for iris_bn_stats), then iris_conv0_bn_relu (arguments as iris_bn_relu_apply)
+ *   backward: iris_conv0_bn_relu_backward: two launches (sum g / sum g xhat, then dz and the weight gradient);
+ *             sums_zeroed [iris_bn_sums_len(out_channels)] and dweight_zeroed [iris_conv0_dweight_len(...)] DEVICE doubles,
+ *             zero on entry; dweight = several partial copies [copies][out_channels][in_channels][3][3] that the caller
+ *             adds up (the blocks' atomics are spread over them); dgamma, dbeta [out_channels] floats.
+ */
+size_t iris_conv0_dweight_len(int in_channels, int out_channels);
+int iris_conv0_stats(const float* x, const float* weight, int batch, int in_channels, int out_channels, int height, int width,
+                     double* sums_zeroed, void* stream);
+int iris_conv0_bn_relu(const float* x, const float* weight, float* y, int batch, int in_channels, int out_channels, int height,
+                       int width, const double* sums, const float* gamma, const float* beta, const float* conv_bias, float eps,
+                       float momentum, float* running_mean, float* running_var, float* save_mean, float* save_rstd, void* stream);
+int iris_conv0_bn_relu_backward(const float* x, const float* weight, const float* dy, int batch, int in_channels,
+                                int out_channels, int height, int width, const float* save_mean, const float* save_rstd,
+                                const float* gamma, const float* beta, double* sums_zeroed, double* dweight_zeroed, float* dgamma,
+                                float* dbeta, void* stream);
+
+/*
  * First convolution of the CRNN (ConvMPBlock's Conv2D(32, 3, padding='same') on the n_chan-channel log-mel input,
  * sj_train.py:191-201, 244) with its (BatchNorm-folded) bias and ReLU in ONE pass, NCHW: x [batch, in_channels (1 or 2),
  * height, width], weight [out_channels, in_channels, 3, 3], bias [out_channels] -> y [batch, out_channels, height, width].

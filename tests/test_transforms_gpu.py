@@ -850,6 +850,51 @@ def test_fused_bn_relu_training_matches_torch(dev, monkeypatch):
         assert int(blk[1].num_batches_tracked) == int(ref[1].num_batches_tracked) == 1
 
 
+def test_first_layer_conv_recomputed_in_bn_passes(dev, monkeypatch):
+    """iris_conv0_* behind _ConvBNReLU for the model's first layer (1 or 2 input channels, no input gradient): output, weight /
+    BatchNorm gradients and running statistics equal the stock conv2d + BatchNorm + ReLU; the convolution output is never
+    stored (the Function saves x, not z)."""
+    import copy
+    from challenge_amd import sj_train as S
+    S.configure_miopen()
+    torch.manual_seed(6)
+    for cin, cout, b, h, w in [(1, 32, 3, 16, 40), (2, 32, 2, 9, 7), (1, 64, 2, 5, 33), (2, 8, 1, 1, 3), (1, 32, 8, 64, 128)]:
+        blk = S._ConvBNReLU(cin, cout).to(dev).to(memory_format=torch.channels_last).train()
+        with torch.no_grad():
+            blk[1].weight.uniform_(-1.5, 1.5)
+            blk[1].bias.uniform_(-0.3, 0.3)
+            blk[1].running_mean.uniform_(-0.2, 0.2)
+            blk[1].running_var.uniform_(0.5, 1.5)
+            blk[0].bias.uniform_(-0.5, 0.5)
+        ref = copy.deepcopy(blk)
+        x = torch.randn(b, cin, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        g = torch.randn(b, cout, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        monkeypatch.setattr(S, "FUSED_BN_RELU", True)
+        monkeypatch.setattr(S, "FUSED_CONV0", True)
+        ya = blk(x)
+        assert ya.grad_fn.name().startswith("_FusedConv0BNReLU") and ya.is_contiguous(memory_format=torch.channels_last)
+        assert all(t.shape != ya.shape for t in ya.grad_fn.saved_tensors)      # nothing of the output's size is kept
+        ya.backward(g)
+        monkeypatch.setattr(S, "FUSED_BN_RELU", False)
+        yb = ref(x)
+        yb.backward(g)
+        tol = lambda t: 2e-5 * float(t.abs().max()) + 1e-6  # noqa: E731
+        assert float((ya - yb).abs().max()) <= tol(yb), (cin, cout, h, w)
+        assert blk[0].weight.grad.shape == ref[0].weight.grad.shape
+        assert float((blk[0].weight.grad - ref[0].weight.grad).abs().max()) <= tol(ref[0].weight.grad) * 5, (cin, cout, h, w)
+        assert float((blk[1].weight.grad - ref[1].weight.grad).abs().max()) <= tol(ref[1].weight.grad) * 5
+        assert float((blk[1].bias.grad - ref[1].bias.grad).abs().max()) <= tol(ref[1].bias.grad) * 5
+        assert float(blk[0].bias.grad.abs().max()) == 0.0
+        assert float((blk[1].running_mean - ref[1].running_mean).abs().max()) <= 1e-6
+        assert float((blk[1].running_var - ref[1].running_var).abs().max()) <= 1e-6
+        # with FUSED_CONV0 off the generic fused passes run on MIOpen's convolution output: the same function
+        monkeypatch.setattr(S, "FUSED_BN_RELU", True)
+        monkeypatch.setattr(S, "FUSED_CONV0", False)
+        blk.zero_grad()
+        yc = blk(x)
+        assert yc.grad_fn.name().startswith("_FusedBiasBNReLU") and float((yc - ya).abs().max()) <= tol(ya)
+
+
 def test_fused_bn_relu_pool_block_matches_torch(dev, monkeypatch):
     """A ConvMPBlock with its MaxPool folded into the last layer's BatchNorm + ReLU passes (iris_bn_relu_pool_*): outputs,
     every gradient and the running statistics equal the stock torch / MIOpen ops, for even and odd heights / widths
