@@ -497,6 +497,7 @@ class FusedAGC:
 # Training-mode Conv2D bias + BatchNorm + ReLU through the HIP kernels iris_bn_* (two passes over the activation each way
 # instead of seven forward / nine backward); IRIS_FUSED_BN=0 keeps the stock torch / MIOpen ops.
 FUSED_BN_RELU = os.environ.get("IRIS_FUSED_BN", "1") != "0"
+FUSED_FC_BN = os.environ.get("IRIS_FUSED_FC_BN", "1") != "0"      # Dense + BatchNorm1d + ReLU through the same passes
 FUSED_BN_POOL = os.environ.get("IRIS_FUSED_BN_POOL", "1") != "0"  # a block's MaxPool inside its last layer's passes
 
 
@@ -708,9 +709,24 @@ class FullyConnectedLayer(nn.Module):
         self.act = {'relu': nn.ReLU(inplace=True), 'sigmoid': nn.Sigmoid()}[act]
 
     def forward(self, x):
-        x = self.fc(x)
-        if self.bn is not None:
-            x = self.bn(x.transpose(1, 2)).transpose(1, 2)
+        bn = self.bn
+        if (FUSED_BN_RELU and FUSED_FC_BN and self.training and bn is not None and isinstance(self.act, nn.ReLU) and x.is_cuda
+                and x.dim() == 3 and x.dtype == torch.float32 and self.fc.out_features % 4 == 0 and bn.track_running_stats
+                and bn.momentum is not None and not torch.is_autocast_enabled()):
+            # Dense + BatchNorm over the feature axis + ReLU = the convolution layers' passes on a [rows = B T, C] activation:
+            # the GEMM runs without bias (BatchNorm removes it), no transposes, no separate normalise / ReLU kernels
+            z = torch.nn.functional.linear(x, self.fc.weight)                # [B, T, C]
+            z4 = z.permute(0, 2, 1).unsqueeze(-1)                             # [B, C, T, 1]: a channels_last view of the same memory
+            if z4.is_contiguous(memory_format=torch.channels_last):
+                bn.num_batches_tracked.add_(1)
+                y4 = _FusedBiasBNReLU.apply(z4, self.fc.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                            bn.momentum, False)
+                return y4.squeeze(-1).permute(0, 2, 1)
+            x = z + self.fc.bias if self.fc.bias is not None else z
+        else:
+            x = self.fc(x)
+        if bn is not None:
+            x = bn(x.transpose(1, 2)).transpose(1, 2)
         return self.act(x)
 
 

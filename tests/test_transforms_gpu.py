@@ -895,6 +895,44 @@ def test_first_layer_conv_recomputed_in_bn_passes(dev, monkeypatch):
         assert yc.grad_fn.name().startswith("_FusedBiasBNReLU") and float((yc - ya).abs().max()) <= tol(ya)
 
 
+def test_fused_dense_bn_relu_matches_torch(dev, monkeypatch):
+    """FullyConnectedLayer (Dense + BatchNorm over the feature axis + ReLU, sj_train.py:204-211) through the iris_bn_* passes
+    on the [B T, C] activation: output, input gradient, weight / BatchNorm gradients, running statistics equal the stock
+    Linear + BatchNorm1d + ReLU."""
+    import copy
+    from challenge_amd import sj_train as S
+    torch.manual_seed(8)
+    for cin, cout, b, t in [(1024, 512, 64, 16), (256, 64, 3, 5), (128, 8, 1, 1), (64, 128, 2, 33)]:
+        if b * t == 1:
+            continue  # BatchNorm1d refuses a single value per channel in training mode
+        fc = S.FullyConnectedLayer(cin, cout, BN=True).to(dev).train()
+        with torch.no_grad():
+            fc.bn.weight.uniform_(-1.5, 1.5)
+            fc.bn.bias.uniform_(-0.3, 0.3)
+            fc.bn.running_mean.uniform_(-0.2, 0.2)
+            fc.bn.running_var.uniform_(0.5, 1.5)
+        ref = copy.deepcopy(fc)
+        x = torch.randn(b, t, cin, device=dev)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        g = torch.randn(b, t, cout, device=dev)
+        monkeypatch.setattr(S, "FUSED_FC_BN", True)
+        ya = fc(xa)
+        assert ya.shape == (b, t, cout)
+        ya.backward(g)
+        monkeypatch.setattr(S, "FUSED_FC_BN", False)
+        yb = ref(xb)
+        yb.backward(g)
+        tol = lambda v: 2e-5 * float(v.abs().max()) + 1e-6  # noqa: E731
+        assert float((ya - yb).abs().max()) <= tol(yb), (cin, cout, b, t)
+        assert float((xa.grad - xb.grad).abs().max()) <= tol(xb.grad) * 5
+        assert float((fc.fc.weight.grad - ref.fc.weight.grad).abs().max()) <= tol(ref.fc.weight.grad) * 5
+        assert float((fc.bn.weight.grad - ref.bn.weight.grad).abs().max()) <= tol(ref.bn.weight.grad) * 5
+        assert float((fc.bn.bias.grad - ref.bn.bias.grad).abs().max()) <= tol(ref.bn.bias.grad) * 5
+        assert float(fc.fc.bias.grad.abs().max()) == 0.0
+        assert float((fc.bn.running_mean - ref.bn.running_mean).abs().max()) <= 1e-6
+        assert float((fc.bn.running_var - ref.bn.running_var).abs().max()) <= 1e-6
+
+
 def test_fused_bn_relu_pool_block_matches_torch(dev, monkeypatch):
     """A ConvMPBlock with its MaxPool folded into the last layer's BatchNorm + ReLU passes (iris_bn_relu_pool_*): outputs,
     every gradient and the running statistics equal the stock torch / MIOpen ops, for even and odd heights / widths
