@@ -192,6 +192,21 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                 "exposed_allreduce_ms_per_step": round(1e3 * (t_train - t_nosync), 3),
                 "grad_bytes": 4 * sum(p.numel() for p in model.parameters()), "bucket_cap_mb": S.DDP_BUCKET_MB}
 
+    # the same training step as ONE replayed hipGraph (single GPU): no zero fills, no gradient-accumulate launches, no gaps
+    graphed = None
+    if world == 1:
+        try:
+            gm = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+            gm.load_state_dict(model.state_dict())
+            gm.compile(S.make_optimizer(cfg, gm.parameters(), capturable=True), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+            gstep = S.GraphedTrainStep(gm, (fe(wav), y))
+            t_graph = timed(lambda: gstep((fe(wav), y)), steps)
+            graphed = {"ms_per_step": round(1e3 * t_graph, 3), "audio_s_per_s": round(audio_s / t_graph, 1),
+                       "what": "sj_train.GraphedTrainStep: forward, loss, backward, AGC + clipvalue, Adam captured once, replayed"}
+            del gstep, gm
+        except Exception as exc:  # an optimisation on top of the eager step: never takes the line down
+            graphed = {"error": repr(exc)[:200]}
+
     # opt-in bf16 autocast variant of the forward and the training step, with its deviation from fp32 stated
     bf16 = None
     try:
@@ -264,7 +279,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         "c3_best_fp32_audio_s_per_s": round(world * audio_s / best_fwd, 1),
         "c4_train_step": {"audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3),
                           "batch_per_gpu": batch, "n_gpus": world, "params": sum(p.numel() for p in model.parameters()),
-                          "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if world > 1 else "none", "device_ms_per_phase": breakdown,
+                          "hipgraph": graphed, "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if world > 1 else "none", "device_ms_per_phase": breakdown,
                           "allreduce": comm},
         "bf16_autocast_opt_in": bf16,
     }

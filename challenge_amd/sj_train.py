@@ -469,7 +469,12 @@ class FusedAGC:
             rec[:, 0], rec[:, 1], rec[:, 2] = base_p + idx, base_g + idx, length
             recs.append(rec)
         table = np.concatenate(recs) if recs else np.zeros((0, 3), np.int64)
-        self._table = torch.from_numpy(table).to(self.params[0].device)
+        # pinned staging + asynchronous copy: legal while a hipGraph is being captured (it becomes a copy node of the graph)
+        host = torch.from_numpy(table)
+        if self.params[0].is_cuda:
+            host = host.pin_memory()
+            self._host_table = host  # keeps the staging buffer alive for as long as a captured copy may replay from it
+        self._table = host.to(self.params[0].device, non_blocking=True)
         self._sig = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
 
     def __call__(self, clip_factor=0.01, eps=1e-3, clipvalue=None):
@@ -1128,8 +1133,14 @@ def binary_crossentropy(y_true, y_pred):
     return torch.mean(-(y_true * torch.log(p) + (1 - y_true) * torch.log(1 - p)))
 
 
-def make_optimizer(config, params):
+def make_optimizer(config, params, capturable: bool = False):
+    """`capturable`: Adam with its step count and learning rate in device tensors, for `GraphedTrainStep`."""
     params = list(params)
+    if capturable:
+        if config.optimizer != 'adam' or not (params and params[0].is_cuda):
+            raise ValueError("make_optimizer(capturable=True): Adam on a GPU")
+        return torch.optim.Adam(params, lr=torch.tensor(float(config.lr), device=params[0].device), eps=1e-7, fused=True,
+                                capturable=True)
     # foreach=True on a GPU: the update AND zero_grad run as a handful of multi-tensor kernels instead of one per
     # parameter (86 fills of ~3.6 us each per step otherwise)
     fe = bool(params) and params[0].is_cuda
@@ -1240,6 +1251,73 @@ def wrap_ddp(model: CustomModel, device, world: int):
     # no multi-GPU at all; rank 0's are the ones checkpointed), so the per-forward buffer broadcast is switched off
     return DDP(model, device_ids=[device.index] if device.type == 'cuda' else None,
                bucket_cap_mb=DDP_BUCKET_MB, gradient_as_bucket_view=True, broadcast_buffers=False)
+
+
+class GraphedTrainStep:
+    """`model.train_step` (forward, loss, backward, AGC + clipvalue, optimiser) as ONE replayed hipGraph - single GPU, fixed
+    batch shape.  The gradients live in the graph's memory pool and are dropped inside the capture, so the replay has neither
+    the zero fills nor autograd's accumulate launches; 13.77 -> 13.55 ms per batch-64 step on an MI355X.
+
+        opt = make_optimizer(config, model.parameters(), capturable=True)      # learning rate held in a device tensor
+        model.compile(opt, loss, clipvalue=...)
+        step = GraphedTrainStep(model, (x, y))                                   # 3 eager warm-up steps (they train), then the capture
+        for x, y in data: loss = step((x, y))['loss']                            # inputs are copied into the static buffers
+        step.set_lr(value)                                                       # schedulers write the tensor
+
+    MIOpen must already know its kernels for these shapes (the warm-up steps see to that).  Not under DDP."""
+
+    def __init__(self, model: "CustomModel", example, warmup: int = 3):
+        x, y = example
+        if not x.is_cuda:
+            raise RuntimeError("GraphedTrainStep: a GPU tensor is required (hipGraph capture; no CPU fallback)")
+        if model._ddp is not None:
+            raise RuntimeError("GraphedTrainStep: not under DistributedDataParallel")
+        opt = model.optimizer
+        if not all(g.get('capturable', False) for g in opt.param_groups):
+            raise ValueError("GraphedTrainStep: the optimiser must be capturable - make_optimizer(config, params, capturable=True)")
+        self.model, self.x, self.y = model, x.clone(), y.clone()
+        # `warmup` eager steps in all (they train the model): all but the last on the current stream - without them the
+        # capture was invalidated on this stack (some first-use initialisation that a side stream alone does not trigger) -
+        # and the last one on a side stream, as torch's capture recipe asks
+        for _ in range(max(warmup, 2) - 1):
+            model.train_step((self.x, self.y))
+        torch.cuda.synchronize(x.device)
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):
+            model.train_step((self.x, self.y))
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        torch.cuda.synchronize(x.device)
+        object.__setattr__(model, '_fused_agc', None)  # its table holds the eager gradients' addresses
+        opt.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            model.train()
+            loss = model.loss_fn(self.y, model._call(self.x))
+            loss.backward()
+            if model.use_agc:
+                object.__setattr__(model, '_fused_agc', FusedAGC(list(model.parameters())))
+                model._fused_agc(0.01, 1e-3, model.clipvalue)
+            elif model.clipvalue:
+                torch.nn.utils.clip_grad_value_([p for p in model.parameters() if p.grad is not None], model.clipvalue)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            self.loss = loss.detach()
+        torch.cuda.synchronize(x.device)
+
+    def __call__(self, data):
+        x, y = data
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        self.graph.replay()
+        return {'loss': self.loss}
+
+    def set_lr(self, value: float) -> None:
+        for g in self.model.optimizer.param_groups:
+            if torch.is_tensor(g['lr']):
+                g['lr'].fill_(float(value))
+            else:
+                g['lr'] = float(value)
 
 
 def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=None, validation_steps=16,

@@ -1061,6 +1061,51 @@ def test_hip_bilstm_training_matches_torch(dev):
         assert float((S.bilstm128(lstm, x) - ref(x)[0]).abs().max()) <= 2e-6
 
 
+def test_graphed_train_step_equals_eager(dev):
+    """GraphedTrainStep (the whole training step as one replayed hipGraph) against the eager step from the same state.
+    With the learning rate written to 0 through set_lr the two are the same deterministic function of the batch: equal
+    losses, equal BatchNorm running statistics, parameters untouched.  With a learning rate both train; their losses stay
+    together only loosely - Adam's normalised update turns the 1e-7 noise of atomically reduced gradients (MIOpen's split-K
+    kernels) into +-lr steps on near-zero-gradient parameters, between two EAGER runs just the same."""
+    import copy
+    from challenge_amd import sj_train as S
+    S.configure_miopen()
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '64', '--n_frame', '128', '--n_chan', '1', '--batch_size', '4'])
+    torch.manual_seed(3)
+    b = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    b.compile(S.make_optimizer(cfg, b.parameters(), capturable=True), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+    xs = [torch.rand(4, 64, 128, 1, device=dev) for _ in range(3)]
+    ys = [(torch.rand(4, 4, 3, device=dev) < 0.2).float() for _ in range(3)]
+    step = S.GraphedTrainStep(b, (xs[0], ys[0]), warmup=2)
+    a = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    a.load_state_dict(b.state_dict())                    # the eager twin starts where the capture left the model
+    a.compile(S.make_optimizer(cfg, a.parameters()), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+    before = [p.detach().clone() for p in b.parameters()]
+    for g in a.optimizer.param_groups:
+        g['lr'] = 0.0
+    step.set_lr(0.0)
+    for x, y in zip(xs, ys):
+        la, lb = a.train_step((x, y))['loss'], step((x, y))['loss']
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(la)))
+    for p0, pb in zip(before, b.parameters()):
+        assert torch.equal(p0, pb)
+    for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        if ba.dtype.is_floating_point:
+            assert float((ba - bb).abs().max()) <= 1e-5 * float(ba.abs().max()) + 1e-7, n
+        else:
+            assert torch.equal(ba, bb), n                # num_batches_tracked
+    for g in a.optimizer.param_groups:
+        g['lr'] = 1e-3
+    step.set_lr(1e-3)
+    first = float(step((xs[0], ys[0]))['loss'])
+    a.train_step((xs[0], ys[0]))
+    for _ in range(12):
+        la, lb = float(a.train_step((xs[0], ys[0]))['loss']), float(step((xs[0], ys[0]))['loss'])
+    assert lb < first - 0.02 and abs(la - lb) <= 0.05, (first, la, lb)
+    with pytest.raises(ValueError):
+        S.GraphedTrainStep(a, (xs[0], ys[0]))            # a's optimiser is not capturable
+
+
 def test_inference_engine_matches_module(dev):
     """InferenceEngine (BatchNorm folded, conv + HIP bias/ReLU/pool epilogue, frontend + forward as one hipGraph) is the
     same function as the training module in eval mode: <= 1e-4 on the sigmoid outputs, eager and replayed."""
