@@ -571,12 +571,18 @@ __global__ __launch_bounds__(256) void k_bn_relu_pool_apply(const float* z, floa
     }
 }
 
-// the four elements of a window (missing ones repeat element 0 and can never win: `>` is strict)
-__device__ __forceinline__ void pool_load(const float4* z4, const PoolWindow& w, int C4, float4 (&v)[4]) {
-    v[0] = z4[w.base];
-    v[1] = w.w1 ? z4[w.base + C4] : v[0];
-    v[2] = w.h1 ? z4[w.base + w.down] : v[0];
-    v[3] = (w.h1 && w.w1) ? z4[w.base + w.down + C4] : v[0];
+// the four elements of a window as zz[slot][component] (missing ones repeat element 0 and can never win: `>` is strict);
+// plain float arrays with constant indices only: they stay in registers (indexing the float4s through a pointer put them in
+// scratch)
+__device__ __forceinline__ void pool_load(const float4* z4, const PoolWindow& w, int C4, float (&zz)[4][4]) {
+    const float4 v0 = z4[w.base];
+    const float4 v1 = w.w1 ? z4[w.base + C4] : v0;
+    const float4 v2 = w.h1 ? z4[w.base + w.down] : v0;
+    const float4 v3 = (w.h1 && w.w1) ? z4[w.base + w.down + C4] : v0;
+    zz[0][0] = v0.x; zz[0][1] = v0.y; zz[0][2] = v0.z; zz[0][3] = v0.w;
+    zz[1][0] = v1.x; zz[1][1] = v1.y; zz[1][2] = v1.z; zz[1][3] = v1.w;
+    zz[2][0] = v2.x; zz[2][1] = v2.y; zz[2][2] = v2.z; zz[2][3] = v2.w;
+    zz[3][0] = v3.x; zz[3][1] = v3.y; zz[3][2] = v3.z; zz[3][3] = v3.w;
 }
 
 __global__ __launch_bounds__(256) void k_bn_pool_bwd_reduce(const float* z, const float* dp, int B, int H, int W, int C4,
@@ -608,7 +614,7 @@ __global__ __launch_bounds__(256) void k_bn_pool_bwd_reduce(const float* z, cons
 #pragma unroll 2
             for (size_t r = r_begin + ty; r < r_end; r += tys) {
                 const PoolWindow w = pool_window((unsigned)r, c, H, W, Ho, Wo, C4);
-                float4 v[4];
+                float v[4][4];
                 pool_load(z4, w, C4, v);
                 const float4 d = d4[r * C4 + c];
                 const float dd[4] = {d.x, d.y, d.z, d.w};
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(256) void k_bn_pool_bwd_reduce(const float* z, cons
                     float best = 0.f, zb = 0.f;
                     int sel = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pool_take(reinterpret_cast<const float*>(&v[j])[k], sc[k], sh[k], j, best, zb, sel);
+                    for (int j = 0; j < 4; ++j) pool_take(v[j][k], sc[k], sh[k], j, best, zb, sel);
                     const float g = best > 0.f ? dd[k] : 0.f;
                     s0[k] += g;
                     s1[k] = fmaf(g, (zb - mu[k]) * rs[k], s1[k]);
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_pool_bwd_dx(const float* z, con
         const unsigned r = i / (unsigned)C4;
         const int c = (int)(i - r * (unsigned)C4);
         const PoolWindow w = pool_window(r, c, H, W, Ho, Wo, C4);
-        float4 v[4], o[4];
+        float v[4][4], o[4][4];
         pool_load(z4, w, C4, v);
         const float4 d = d4[i];
         const float dd[4] = {d.x, d.y, d.z, d.w};
@@ -683,15 +689,15 @@ __global__ __launch_bounds__(256) void k_bn_relu_pool_bwd_dx(const float* z, con
             float best = 0.f, zb = 0.f;
             int sel = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pool_take(reinterpret_cast<const float*>(&v[j])[k], a, h, j, best, zb, sel);
+            for (int j = 0; j < 4; ++j) pool_take(v[j][k], a, h, j, best, zb, sel);
             const float g = best > 0.f ? dd[k] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                reinterpret_cast<float*>(&o[j])[k] = fmaf(a, sel == j ? g : 0.f, fmaf(b, reinterpret_cast<const float*>(&v[j])[k], kk));
+                o[j][k] = fmaf(a, sel == j ? g : 0.f, fmaf(b, v[j][k], kk));
         }
-        o4[w.base] = o[0];
-        if (w.w1) o4[w.base + C4] = o[1];
-        if (w.h1) o4[w.base + w.down] = o[2];
-        if (w.h1 && w.w1) o4[w.base + w.down + C4] = o[3];
+        o4[w.base] = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+        if (w.w1) o4[w.base + C4] = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+        if (w.h1) o4[w.base + w.down] = make_float4(o[2][0], o[2][1], o[2][2], o[2][3]);
+        if (w.h1 && w.w1) o4[w.base + w.down + C4] = make_float4(o[3][0], o[3][1], o[3][2], o[3][3]);
     }
 }
