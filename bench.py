@@ -192,21 +192,6 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                 "exposed_allreduce_ms_per_step": round(1e3 * (t_train - t_nosync), 3),
                 "grad_bytes": 4 * sum(p.numel() for p in model.parameters()), "bucket_cap_mb": S.DDP_BUCKET_MB}
 
-    # the same training step as ONE replayed hipGraph (single GPU): no zero fills, no gradient-accumulate launches, no gaps
-    graphed = None
-    if world == 1:
-        try:
-            gm = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
-            gm.load_state_dict(model.state_dict())
-            gm.compile(S.make_optimizer(cfg, gm.parameters(), capturable=True), S.binary_crossentropy, clipvalue=cfg.clipvalue)
-            gstep = S.GraphedTrainStep(gm, (fe(wav), y))
-            t_graph = timed(lambda: gstep((fe(wav), y)), steps)
-            graphed = {"ms_per_step": round(1e3 * t_graph, 3), "audio_s_per_s": round(audio_s / t_graph, 1),
-                       "what": "sj_train.GraphedTrainStep: forward, loss, backward, AGC + clipvalue, Adam captured once, replayed"}
-            del gstep, gm
-        except Exception as exc:  # an optimisation on top of the eager step: never takes the line down
-            graphed = {"error": repr(exc)[:200]}
-
     # opt-in bf16 autocast variant of the forward and the training step, with its deviation from fp32 stated
     bf16 = None
     try:
@@ -235,6 +220,21 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                         "fp32, so fp32 stays the default and the reported metric"}
     except Exception as exc:  # an opt-in extra must never take the bench line down
         bf16 = {"error": repr(exc)[:200]}
+
+    # the same training step as ONE replayed hipGraph (single GPU): no zero fills, no gradient-accumulate launches, no gaps
+    graphed = None
+    if world == 1:
+        try:
+            gm = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+            gm.load_state_dict(model.state_dict())
+            gm.compile(S.make_optimizer(cfg, gm.parameters(), capturable=True), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+            gstep = S.GraphedTrainStep(gm, (fe(wav), y))
+            t_graph = timed(lambda: gstep((fe(wav), y)), steps)
+            graphed = {"ms_per_step": round(1e3 * t_graph, 3), "audio_s_per_s": round(audio_s / t_graph, 1),
+                       "what": "sj_train.GraphedTrainStep: forward, loss, backward, AGC + clipvalue, Adam captured once, replayed"}
+            del gstep, gm
+        except Exception as exc:  # an optimisation on top of the eager step: never takes the line down
+            graphed = {"error": repr(exc)[:200]}
 
     # input side of the reference's own training loop (spectra in, sj_train.py:74-130) at its default
     # shape: whole batches synthesised on the device (iris_mix_specs + mel kernel with bands)
