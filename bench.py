@@ -217,7 +217,9 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                 "train_ms_per_step": round(1e3 * t_tb, 3), "train_audio_s_per_s": round(world * audio_s / t_tb, 1),
                 "max_abs_dev_of_sigmoid_outputs_vs_fp32": round(dev_abs, 6),
                 "note": "opt-in (torch.autocast bf16 around the CRNN only; the frontend stays fp32); the reference trains in "
-                        "fp32, so fp32 stays the default and the reported metric"}
+                        "fp32, so fp32 stays the default and the reported metric.  Under autocast the model runs the stock "
+                        "torch / MIOpen ops: the HIP BatchNorm / ReLU / MaxPool / LSTM / first-layer passes are fp32 only, "
+                        "which is why the fp32 step has caught up with this one"}
     except Exception as exc:  # an opt-in extra must never take the bench line down
         bf16 = {"error": repr(exc)[:200]}
 
