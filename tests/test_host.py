@@ -390,3 +390,35 @@ def test_configure_miopen_points_at_a_copy_of_the_shipped_db(monkeypatch):
     S.configure_miopen()
     assert "MIOPEN_USER_DB_PATH" not in os.environ
     monkeypatch.delenv("MIOPEN_FIND_MODE", raising=False)
+
+
+def test_fused_pass_gates():
+    """The predicates that route a layer to the HIP passes (sj_train): exactly the layer shapes the kernels were written for;
+    anything else - and everything on the CPU - keeps the stock torch ops."""
+    import torch
+    from challenge_amd import sj_train as S
+    nn = torch.nn
+    assert S._is_pool_2x2_same(nn.MaxPool2d(2, 2, ceil_mode=True))
+    for other in (nn.MaxPool2d(2, 2), nn.MaxPool2d(3, 2, ceil_mode=True), nn.MaxPool2d((1, 2), (1, 2), ceil_mode=True),
+                  nn.MaxPool2d(2, 2, ceil_mode=True, return_indices=True), nn.AvgPool2d(2), nn.Identity(), None):
+        assert not S._is_pool_2x2_same(other)
+    assert S._lstm_is_bilstm128(nn.LSTM(128, 128, batch_first=True, bidirectional=True))
+    for other in (nn.LSTM(128, 128, batch_first=True), nn.LSTM(128, 64, batch_first=True, bidirectional=True),
+                  nn.LSTM(64, 128, batch_first=True, bidirectional=True), nn.LSTM(128, 128, bidirectional=True),
+                  nn.LSTM(128, 128, num_layers=2, batch_first=True, bidirectional=True),
+                  nn.LSTM(128, 128, batch_first=True, bidirectional=True, bias=False), nn.GRU(128, 128), None):
+        assert not S._lstm_is_bilstm128(other)
+    x = torch.zeros(2, 1, 8, 16)
+    assert S._is_first_layer_conv(nn.Conv2d(1, 32, 3, padding=1), x)
+    assert S._is_first_layer_conv(nn.Conv2d(2, 64, 3, padding=1), torch.zeros(2, 2, 8, 16))
+    assert not S._is_first_layer_conv(nn.Conv2d(1, 32, 3, padding=1), x.clone().requires_grad_(True))   # the input wants a gradient
+    assert not S._is_first_layer_conv(nn.Conv2d(1, 32, 3, padding=1), torch.zeros(2, 1, 8, 4096))        # rows too long for the LDS
+    for other in (nn.Conv2d(3, 32, 3, padding=1), nn.Conv2d(1, 32, 5, padding=2), nn.Conv2d(1, 32, 3), nn.Conv2d(1, 30, 3, padding=1),
+                  nn.Conv2d(1, 48, 3, padding=1), nn.Conv2d(1, 32, 3, padding=1, stride=2), nn.Conv2d(2, 32, 3, padding=1, groups=2)):
+        assert not S._is_first_layer_conv(other, torch.zeros(2, other.in_channels, 8, 16)), other
+    # on the CPU every layer runs the stock ops (no CPU fallback of the HIP passes exists or is needed)
+    blk = S.ConvMPBlock(1, num_convs=2, fsize=8, BN=True, MP=True).train()
+    y = blk(torch.randn(2, 1, 5, 6))
+    assert y.shape == (2, 8, 3, 3) and not y.grad_fn.name().startswith("_Fused")
+    fc = S.FullyConnectedLayer(16, 8, BN=True).train()
+    assert fc(torch.randn(2, 3, 16)).shape == (2, 3, 8)
