@@ -728,6 +728,11 @@ class FullyConnectedLayer(nn.Module):
                                             bn.momentum, False)
                 return y4.squeeze(-1).permute(0, 2, 1)
             x = z + self.fc.bias if self.fc.bias is not None else z
+        elif (bn is None and not self.training and isinstance(self.act, nn.ReLU) and x.is_cuda and x.dim() == 3
+              and not torch.is_grad_enabled() and self.fc.bias is not None and not torch.is_autocast_enabled()):
+            # inference with the BatchNorm folded away: Dense + bias + ReLU as ONE GEMM with a fused epilogue
+            b, t, c = x.shape
+            return torch._addmm_activation(self.fc.bias, x.reshape(b * t, c), self.fc.weight.t()).view(b, t, -1)
         else:
             x = self.fc(x)
         if bn is not None:
