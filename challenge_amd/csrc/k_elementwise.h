@@ -307,15 +307,26 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool_nchw(const float* x, con
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wo = wo0 + lane, h0 = 2 * ho, w0 = 2 * wo;
     const bool h1 = h0 + 1 < H, w1 = w0 + 1 < W, in = wo < Wo && lane < tile_w;
+    // even width and an 8-byte aligned tensor: a window row is ONE 8-byte load, a wave reads 512 contiguous bytes per row
+    const bool pairs = ((W & 1) == 0) && ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
     for (int c = wv; c < C; c += 4) {
         const float* p = x + (((size_t)b * C + c) * H + h0) * W + w0;
         float m = -INFINITY;
         if (in) {
-            m = p[0];
-            if (w1) m = fmaxf(m, p[1]);
-            if (h1) {
-                m = fmaxf(m, p[W]);
-                if (w1) m = fmaxf(m, p[W + 1]);
+            if (pairs) {
+                const float2 r0 = *reinterpret_cast<const float2*>(p);
+                m = fmaxf(r0.x, r0.y);
+                if (h1) {
+                    const float2 r1 = *reinterpret_cast<const float2*>(p + W);
+                    m = fmaxf(m, fmaxf(r1.x, r1.y));
+                }
+            } else {
+                m = p[0];
+                if (w1) m = fmaxf(m, p[1]);
+                if (h1) {
+                    m = fmaxf(m, p[W]);
+                    if (w1) m = fmaxf(m, p[W + 1]);
+                }
             }
             m = fmaxf(m + bias[c], 0.f);
         }
