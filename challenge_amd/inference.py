@@ -87,8 +87,9 @@ def features_for_eval(spec: torch.Tensor, config) -> torch.Tensor:
 def predict_frames(model, features: torch.Tensor, config, overlap_hop: int = 512, batch_size: int = 32,
                    smoothing: bool = True) -> torch.Tensor:
     """features [M, T, C'] -> thresholded frame predictions [T, K] (metrics.py:56-81).
-    (For repeated evaluation pass `sj_train.fold_batchnorm(model)`: the same function with the eval-mode
-    BatchNorms folded into the convolutions / dense layers in front of them.)"""
+    (For repeated evaluation pass `sj_train.InferenceEngine(model)` instead of the model: the same function with the
+    eval-mode BatchNorms folded away and the HIP epilogues / LSTM launch, 1.4x the module's rate; or
+    `sj_train.fold_batchnorm(model)` for the folding alone.)"""
     frame_len = features.shape[-2]
     windows = frame(features, config.n_frame, overlap_hop, pad_end=True, axis=-2)  # [M, W, n_frame, C']
     windows = windows.permute(1, 0, 2, 3)[..., :config.n_chan].contiguous()

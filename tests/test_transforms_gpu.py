@@ -293,6 +293,13 @@ def test_eval_path_on_gpu(dev):
     model = S.get_model(cfg).to(dev)
     out = I.evaluate_wav(model, wav, cfg, 16000, overlap_hop=32, device=dev)
     assert tuple(out.shape) == (157, 3) and set(np.unique(out.cpu().numpy())) <= {0.0, 1.0}
+    # the inference engine stands in for the model: same averaged predictions before the threshold (stereo input: the
+    # first layer runs the 2-channel stencil)
+    model = model.to(memory_format=torch.channels_last)
+    eng = S.InferenceEngine(model)
+    a = I.predict_frames(model, feats, cfg, overlap_hop=32, smoothing=False)
+    b = I.predict_frames(eng, feats, cfg, overlap_hop=32, smoothing=False)
+    assert eng.fused_lstm and eng.fused_convs == 14 and float((a - b).abs().mean()) <= 0.01   # thresholded frames: a few may flip
 
 
 def test_device_mixer_matches_oracle(dev):
