@@ -28,8 +28,8 @@ for case in range(n_cases):
     if kind == "block":
         cin = int(rng.choice([1, 2, 8, 32]))
         cout = int(rng.choice([8, 16, 32, 64, 128]))
-        # (B >= 2, H >= 2: the STOCK side of the comparison - torch's Conv2d + BatchNorm2d on MIOpen, channels-last, training mode -
-        # dumps core on [1, 2, 1, 33] -> 64 and [1, 8, 9, 17] -> 128 channels in this image, with or without the shipped perf-db)
+        # (B >= 2: the STOCK side of the comparison - torch's BatchNorm2d on MIOpen, channels-last, training mode - dumps core on
+        # batch-1 inputs in this image)
         nconv, b, h, w = int(rng.integers(1, 4)), int(rng.integers(2, 6)), int(rng.integers(2, 20)), int(rng.integers(2, 70))
         mod = S.ConvMPBlock(cin, num_convs=nconv, fsize=cout, BN=True, MP=bool(rng.random() < 0.8)).to(dev).to(memory_format=torch.channels_last).train()
         x = torch.randn(b, cin, h, w, device=dev).contiguous(memory_format=torch.channels_last)
