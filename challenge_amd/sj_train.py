@@ -89,6 +89,10 @@ class ARGS:
         a('--per_sample_pipeline', action='store_true',
           help='build samples one at a time with the tf.data-shaped graph (make_dataset) instead of the '
                'batched on-device synthesis (make_device_dataset), which is the default on a GPU')
+        a('--host_draws', action='store_true',
+          help='draw the random half of every batch (source choice, offsets, gains, SpecAugment bands) on the host and upload '
+               'it, instead of on the device (iris_mix_draw / iris_augment_draw, the default on a GPU: no upload, so the '
+               'host is never held behind the previous step)')
         a('--no_clipvalue_after_agc', action='store_true',
           help="skip Adam's element-wise clipvalue (TF < 2.4 behaviour of the custom train_step)")
         a('--validation_steps', type=int, default=16)
@@ -1416,12 +1420,14 @@ def main(argv=None):
     if device.type == 'cuda' and config.online_stft:
         # corpora resident in HBM as WAVEFORMS, mixed before the STFT, fused frontend on line (synthetic sources:
         # the reference's pickles hold spectra, not waveforms)
-        train_set = make_wave_dataset(config, training=True, device=device, seed=1000 + rank)
-        test_set = make_wave_dataset(config, training=False, device=device, seed=2000 + rank)
+        dd = not config.host_draws
+        train_set = make_wave_dataset(config, training=True, device=device, seed=1000 + rank, device_draw=dd)
+        test_set = make_wave_dataset(config, training=False, device=device, seed=2000 + rank, device_draw=dd)
     elif device.type == 'cuda' and not config.per_sample_pipeline:
         # corpora resident in HBM, whole batches synthesised on the device (each rank draws its own stream)
-        train_set = make_device_dataset(config, training=True, device=device, seed=1000 + rank)
-        test_set = make_device_dataset(config, training=False, device=device, seed=2000 + rank)
+        dd = not config.host_draws
+        train_set = make_device_dataset(config, training=True, device=device, seed=1000 + rank, device_draw=dd)
+        test_set = make_device_dataset(config, training=False, device=device, seed=2000 + rank, device_draw=dd)
     else:
         train_set = make_dataset(config, training=True)
         test_set = make_dataset(config, training=False)
