@@ -55,10 +55,12 @@ SIGNATURES = {
     "iris_bn_relu_pool_apply": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_pool_bwd_reduce": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_pool_bwd_dx": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "iris_conv3x3_c32_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "iris_conv0_dweight_len": (_sz, [_i, _i]),
     "iris_conv0_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "iris_conv0_bn_relu": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "iris_conv0_bn_relu_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "iris_conv3x3_small_bias_relu_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "iris_conv3x3_small_bias_relu_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "iris_bilstm128_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "iris_bilstm128_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

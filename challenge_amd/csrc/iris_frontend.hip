@@ -17,6 +17,7 @@
 //   k_lstm.h         the CRNN's bidirectional LSTM: forward and backward through time, one launch each
 //   k_conv_small.h   the CRNN's first convolution (1-2 input channels) with bias + ReLU, one pass (inference)
 //   k_conv0_bn.h     the same layer in training mode: convolution recomputed inside the BatchNorm + ReLU passes
+//   k_conv_c32.h     the 32 -> 32 convolution of block 1 on the fp32 matrix cores, bias + ReLU (+ MaxPool) fused (inference)
 //   host_plan.h      mel matrix, constant tables, plan create / destroy
 //   host_ops.h       the operators' C-ABI entry points
 #include "common.h"
@@ -33,3 +34,4 @@
 #include "k_lstm.h"
 #include "k_conv_small.h"
 #include "k_conv0_bn.h"
+#include "k_conv_c32.h"

@@ -168,6 +168,31 @@ __global__ __launch_bounds__(256) void k_conv0_bn_relu(const float* __restrict__
     }
 }
 
+// Inference form of the same layer (BatchNorm folded into weight and bias): y = max(z + bias, 0), channels-last.
+template <int CIN>
+__global__ __launch_bounds__(256) void k_conv0_bias_relu(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                         int W, int C4) {
+    extern __shared__ float c0mem[];
+    const int tys = 256 / C4, tx = threadIdx.x % C4, ty = threadIdx.x / C4;
+    float wreg[4][CIN][9];
+    conv0_load_weights<CIN>(w, tx, wreg);
+    const float4 bv = reinterpret_cast<const float4*>(bias)[tx];
+    float4* y4 = reinterpret_cast<float4*>(y);
+    for (unsigned row = blockIdx.x; row < (unsigned)B * H; row += gridDim.x) {
+        __syncthreads();
+        conv0_stage_rows<CIN>(x, c0mem, row, H, W);
+        __syncthreads();
+        for (int wq = ty; wq < W; wq += tys) {
+            const Conv0Taps<CIN> t = conv0_taps<CIN>(c0mem, wq, W);
+            float z[4];
+            conv0_z<CIN>(t, wreg, z);
+            y4[((size_t)row * W + wq) * C4 + tx] =
+                make_float4(fmaxf(z[0] + bv.x, 0.f), fmaxf(z[1] + bv.y, 0.f), fmaxf(z[2] + bv.z, 0.f), fmaxf(z[3] + bv.w, 0.f));
+        }
+    }
+}
+
 // DW = false: sums[0][c] += g, sums[1][c] += g xhat.   DW = true: dw[co][ci][tap] += dz * tap (fp64 staging buffer).
 template <int CIN, bool DW>
 __global__ __launch_bounds__(256) void k_conv0_bwd(const float* __restrict__ x, const float* __restrict__ w,
@@ -253,6 +278,23 @@ static int conv0_check(const void* a, const void* b, int batch, int cin, int cou
     return IRIS_OK;
 }
 static size_t conv0_tile_bytes(int cin, int width) { return (size_t)cin * 3 * (width + 2) * sizeof(float); }
+
+extern "C" int iris_conv3x3_small_bias_relu_nhwc(const float* x, const float* weight, const float* bias, float* y, int batch,
+                                                 int in_channels, int out_channels, int height, int width, void* stream) {
+    int rc = conv0_check(x, weight, batch, in_channels, out_channels, height, width, "iris_conv3x3_small_bias_relu_nhwc");
+    if (rc) return rc;
+    if (!bias || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_small_bias_relu_nhwc: NULL argument");
+    if ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(y)) & 15)
+        return fail(IRIS_E_INVALID, "iris_conv3x3_small_bias_relu_nhwc: bias and y must be 16-byte aligned");
+    const unsigned grid = (unsigned)std::min<size_t>((size_t)batch * height, 4096);
+    const size_t lds = conv0_tile_bytes(in_channels, width);
+    if (in_channels == 1)
+        k_conv0_bias_relu<1><<<grid, 256, lds, (hipStream_t)stream>>>(x, weight, bias, y, batch, height, width, out_channels / 4);
+    else
+        k_conv0_bias_relu<2><<<grid, 256, lds, (hipStream_t)stream>>>(x, weight, bias, y, batch, height, width, out_channels / 4);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
 
 extern "C" size_t iris_conv0_dweight_len(int in_channels, int out_channels) {
     return (in_channels > 0 && out_channels > 0) ? (size_t)kConv0DwSlots * out_channels * in_channels * 9 : 0;

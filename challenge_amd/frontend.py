@@ -382,20 +382,51 @@ def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def conv3x3_small_bias_relu_nchw(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    """relu(conv2d(x, weight, padding=1) + bias) for a contiguous [B, 1 or 2, H, W] input in ONE pass
-    (iris_conv3x3_small_bias_relu_nchw): the CRNN's first layer, which writes 16-32x what it reads."""
+def conv3x3_small_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, channels_last: bool = False) -> torch.Tensor:
+    """relu(conv2d(x, weight, padding=1) + bias) for a contiguous [B, 1 or 2, H, W] input in ONE pass: the CRNN's first layer,
+    which writes 16-32x what it reads.  Output contiguous (iris_conv3x3_small_bias_relu_nchw; W a multiple of 4) or
+    channels_last (iris_conv3x3_small_bias_relu_nhwc; W <= 2048, output channels 4 .. 256 dividing 1024)."""
     if (x.dim() != 4 or not x.is_contiguous() or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] not in (1, 2)
-            or tuple(weight.shape[1:]) != (x.shape[1], 3, 3) or not weight.is_contiguous() or x.shape[3] % 4):
-        raise ValueError("conv3x3_small_bias_relu_nchw: x must be a contiguous float32 device tensor [B, 1|2, H, W], W % 4 == 0, "
+            or tuple(weight.shape[1:]) != (x.shape[1], 3, 3) or not weight.is_contiguous()):
+        raise ValueError("conv3x3_small_bias_relu: x must be a contiguous float32 device tensor [B, 1|2, H, W], "
                          "weight [Cout, Cin, 3, 3] contiguous")
     b, cin, h, w = (int(v) for v in x.shape)
     cout = int(weight.shape[0])
-    y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device)
+    if channels_last:
+        if cout % 4 or cout > 256 or 1024 % cout or w > 2048:
+            raise ValueError("conv3x3_small_bias_relu(channels_last): output channels 4 .. 256 dividing 1024, W <= 2048")
+        y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        fn, name = N.lib().iris_conv3x3_small_bias_relu_nhwc, "iris_conv3x3_small_bias_relu_nhwc"
+    else:
+        if w % 4:
+            raise ValueError("conv3x3_small_bias_relu: W must be a multiple of 4 for the contiguous output")
+        y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device)
+        fn, name = N.lib().iris_conv3x3_small_bias_relu_nchw, "iris_conv3x3_small_bias_relu_nchw"
     with torch.cuda.device(x.device):
-        rc = N.lib().iris_conv3x3_small_bias_relu_nchw(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), b, cin, cout,
-                                                       h, w, _stream_ptr(x.device))
-    N.check(rc, "iris_conv3x3_small_bias_relu_nchw")
+        rc = fn(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), b, cin, cout, h, w, _stream_ptr(x.device))
+    N.check(rc, name)
+    return y
+
+
+def conv3x3_small_bias_relu_nchw(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    return conv3x3_small_bias_relu(x, weight, bias, channels_last=False)
+
+
+def conv3x3_c32_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, pool: bool = False) -> torch.Tensor:
+    """relu(conv2d(x, weight, padding=1) + bias), with `pool` max-pooled 2x2 'same' behind it, for a channels_last
+    [B, 32, H, W] input and a [32, 32, 3, 3] weight, on the fp32 matrix cores (iris_conv3x3_c32_bias_relu).  Returns a
+    channels_last tensor."""
+    if (x.dim() != 4 or x.shape[1] != 32 or not x.is_contiguous(memory_format=torch.channels_last) or not x.is_cuda
+            or x.dtype != torch.float32 or tuple(weight.shape) != (32, 32, 3, 3) or not weight.is_contiguous()):
+        raise ValueError("conv3x3_c32_bias_relu: x must be a float32 channels_last device tensor [B, 32, H, W], weight a contiguous "
+                         "[32, 32, 3, 3]")
+    b, _, h, w = (int(v) for v in x.shape)
+    oh, ow = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
+    y = torch.empty((b, 32, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = N.lib().iris_conv3x3_c32_bias_relu(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w,
+                                                1 if pool else 0, _stream_ptr(x.device))
+    N.check(rc, "iris_conv3x3_c32_bias_relu")
     return y
 
 

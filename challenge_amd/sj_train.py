@@ -921,14 +921,42 @@ class _ConvBiasReLU(nn.Module):
     bias + ReLU (iris_bias_relu) - or, for the last convolution of a block, bias + ReLU + the block's 2x2 max-pool
     (iris_bias_relu_maxpool) - instead of separate add / clamp / pooling kernels over the activation."""
 
-    def __init__(self, conv: nn.Conv2d, pool: bool, nchw: bool = False):
+    def __init__(self, conv: nn.Conv2d, pool: bool, nchw: bool = False, hip: Optional[str] = None):
+        """`hip`: None (MIOpen convolution + epilogue pass), 'stencil' (first layer, 1-2 input channels: one-pass HIP stencil,
+        channels-last output) or 'mfma32' (32 -> 32 channels: the convolution itself on the fp32 matrix cores with bias, ReLU
+        and the block's pooling fused, channels-last in and out)."""
         super().__init__()
-        fmt = torch.contiguous_format if nchw else torch.channels_last
+        fmt = torch.contiguous_format if (nchw or hip) else torch.channels_last
         self.weight = nn.Parameter(conv.weight.detach().clone(memory_format=fmt), requires_grad=False)
         self.bias = nn.Parameter(conv.bias.detach().clone(), requires_grad=False)
-        self.padding, self.pool, self.nchw = conv.padding, pool, nchw
+        self.padding, self.pool, self.nchw, self.hip = conv.padding, pool, nchw, hip
+
+    @staticmethod
+    def hip_form(conv: nn.Conv2d) -> Optional[str]:
+        """Which HIP convolution, if any, this (folded) layer's shape has."""
+        def pair(v):
+            return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+        plain = (pair(conv.kernel_size) == (3, 3) and pair(conv.padding) == (1, 1) and pair(conv.stride) == (1, 1)
+                 and pair(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is not None
+                 and conv.weight.dtype == torch.float32)
+        if plain and conv.in_channels in (1, 2) and conv.out_channels % 4 == 0 and conv.out_channels <= 256 and 1024 % conv.out_channels == 0:
+            return 'stencil'
+        if plain and conv.in_channels == 32 and conv.out_channels == 32:
+            return 'mfma32'
+        return None
 
     def forward(self, x):
+        if self.hip == 'stencil' and x.shape[3] <= 2048 and not self.pool:
+            b, c, h, w = x.shape  # one channel: channels_last and contiguous coincide in memory
+            xc = x.as_strided((b, c, h, w), (h * w, h * w, w, 1)) if (c == 1 and x.stride(3) == 1 and x.stride(2) == w) else x.contiguous()
+            return _fe.conv3x3_small_bias_relu(xc, self.weight, self.bias, channels_last=True)
+        if self.hip == 'mfma32':
+            if not x.is_contiguous(memory_format=torch.channels_last):
+                x = x.contiguous(memory_format=torch.channels_last)
+            return _fe.conv3x3_c32_bias_relu(x, self.weight, self.bias, pool=self.pool)
+        if self.hip:  # shape outside the HIP kernel's range: MIOpen on the contiguous weight
+            y = torch.nn.functional.conv2d(x, self.weight, self.bias, padding=self.padding).relu_()
+            return torch.nn.functional.max_pool2d(y, 2, 2, ceil_mode=True) if self.pool else y
         if self.nchw:  # contiguous in, contiguous out - or, with the block's pooling, channels_last out
             if x.shape[1] == 1:  # one channel: NHWC and NCHW coincide in memory; give the view plain NCHW strides, or the
                 b, c, h, w = x.shape  # convolution is dispatched as channels_last and its output has to be copied back
@@ -1025,9 +1053,10 @@ class _HipBiLSTM(nn.Module):
 class InferenceEngine:
     """Inference-only execution of a CustomModel (the c3 path: HIP frontend + SpecAugment + CRNN forward):
       * eval-mode BatchNorm folded into the layer in front of it (`fold_batchnorm`);
-      * every Conv2D + bias + ReLU (+ MaxPool) of the conv stack as MIOpen convolution + one HIP epilogue pass; block 1
-        (1 or 2 -> 32 -> 32 channels at full resolution) runs in NCHW, where MIOpen's solvers are 40 % faster for the
-        32 -> 32 layer, and hands over in NHWC through the pooling epilogue;
+      * every Conv2D + bias + ReLU (+ MaxPool) of the conv stack as MIOpen convolution + one HIP epilogue pass - except
+        block 1 (1 or 2 -> 32 -> 32 channels at full resolution), whose two convolutions are HIP kernels themselves: a
+        one-pass stencil and an implicit GEMM on the fp32 matrix cores with bias, ReLU and the pooling fused
+        (`hip_convs=False`: MIOpen, block 1 in NCHW where its solvers are 40 % faster for the 32 -> 32 layer);
       * the bidirectional LSTM as one GEMM + ONE HIP launch for the whole recurrence (`_HipBiLSTM`);
       * frontend + forward captured into ONE hipGraph (`replay`), when a frontend and an example batch are given.
     Same function as `model.eval()(x)` up to fp32 rounding (GPU test: <= 1e-4 on the sigmoid outputs).  The model
@@ -1035,9 +1064,10 @@ class InferenceEngine:
 
     def __init__(self, model: "CustomModel", frontend: Optional["WaveFrontend"] = None,
                  example_wav: Optional[torch.Tensor] = None, fuse_epilogues: bool = True, block1_nchw: bool = True,
-                 fuse_lstm: bool = True):
+                 fuse_lstm: bool = True, hip_convs: bool = True):
         self.model = fold_batchnorm(model)
         self.fused_convs = 0
+        self.hip_convs = 0
         self.fused_lstm = False
         dev = next(self.model.parameters()).device
         if fuse_epilogues and dev.type == 'cuda':
@@ -1053,8 +1083,12 @@ class InferenceEngine:
                 if not ok:
                     continue
                 nchw = nchw and has_pool  # the hand-over to NHWC happens in the pooling epilogue
-                blk.convs = nn.Sequential(*[_ConvBiasReLU(m[0], has_pool and i == len(convs) - 1, nchw)
+                forms = [_ConvBiasReLU.hip_form(m[0]) if hip_convs else None for m in convs]
+                if any(forms):  # layers with a HIP convolution stay channels-last throughout
+                    nchw = False
+                blk.convs = nn.Sequential(*[_ConvBiasReLU(m[0], has_pool and i == len(convs) - 1, nchw and not forms[i], forms[i])
                                             for i, m in enumerate(convs)])
+                self.hip_convs += sum(1 for f in forms if f)
                 if has_pool:
                     blk.pool = nn.Identity()
                 self.fused_convs += len(convs)

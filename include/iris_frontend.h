@@ -307,6 +307,15 @@ int iris_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* dz, int bat
                              const double* sums, float* dgamma, float* dbeta, void* stream);
 
 /*
+ * Second layer of the CRNN's first block for inference: Conv2D(32 -> 32, 3x3 'same') + (BatchNorm-folded) bias + ReLU, and
+ * with pool != 0 the block's MaxPool2D(2, 2, 'same') behind it (sj_train.py:191-201, 244), as an implicit GEMM on the fp32
+ * matrix cores (exact fp32).  x [batch, height, width, 32] channels-last, weight [32, 32, 3, 3] contiguous, bias [32];
+ * y [batch, height, width, 32] or, pooled, [batch, ceil(height / 2), ceil(width / 2), 32].  x 16-byte aligned.
+ */
+int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, const float* bias, float* y, int batch, int height, int width,
+                               int pool, void* stream);
+
+/*
  * The CRNN's first layer in TRAINING mode - Conv2D(3x3 'same', 1 or 2 input channels) + BatchNormalization + ReLU
  * (sj_train.py:191-201, 244) - with the convolution recomputed from x wherever its output is needed (9-18 FMAs per value
  * against 4 bytes of traffic): z is never stored.  x [batch, in_channels, height, width] contiguous; weight
@@ -336,6 +345,10 @@ int iris_conv0_bn_relu_backward(const float* x, const float* weight, const float
  * The layer writes 16-32x what it reads; every output byte is written once.  width a multiple of 4; x, y 16-byte aligned.
  */
 int iris_conv3x3_small_bias_relu_nchw(const float* x, const float* weight, const float* bias, float* y, int batch,
+                                      int in_channels, int out_channels, int height, int width, void* stream);
+/* the same with a channels-last output y [batch, height, width, out_channels] (out_channels in {4, 8, ..., 256} dividing
+ * 1024; width <= 2048; bias, y 16-byte aligned), which is what iris_conv3x3_c32_bias_relu reads */
+int iris_conv3x3_small_bias_relu_nhwc(const float* x, const float* weight, const float* bias, float* y, int batch,
                                       int in_channels, int out_channels, int height, int width, void* stream);
 
 /*

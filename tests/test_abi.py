@@ -113,6 +113,12 @@ def test_round3_entry_points_validate_before_any_launch():
     assert lib.iris_conv3x3_small_bias_relu_nchw(p16, p16, p16, p16, 1, 3, 32, 8, 8, None) == UNSUPPORTED   # 1 or 2 input channels
     assert lib.iris_conv3x3_small_bias_relu_nchw(p16, p16, p16, p16, 1, 1, 32, 8, 6, None) == UNSUPPORTED   # width % 4
     assert lib.iris_conv3x3_small_bias_relu_nchw(p8, p16, p16, p16, 1, 1, 32, 8, 8, None) == INVALID        # alignment
+    assert lib.iris_conv3x3_small_bias_relu_nhwc(p16, p16, None, p16, 1, 1, 32, 8, 8, None) == INVALID
+    assert lib.iris_conv3x3_small_bias_relu_nhwc(p16, p16, p16, p16, 1, 1, 48, 8, 8, None) == UNSUPPORTED   # 48 does not divide 1024
+    assert lib.iris_conv3x3_small_bias_relu_nhwc(p16, p16, p16, p16, 1, 1, 32, 8, 4096, None) == UNSUPPORTED  # rows beyond the LDS
+    assert lib.iris_conv3x3_c32_bias_relu(None, p16, p16, p16, 1, 8, 8, 0, None) == INVALID
+    assert lib.iris_conv3x3_c32_bias_relu(p8, p16, p16, p16, 1, 8, 8, 1, None) == INVALID                  # alignment
+    assert lib.iris_conv3x3_c32_bias_relu(p16, p16, p16, p16, 0, 8, 8, 1, None) == INVALID
     assert lib.iris_bilstm128_forward(None, p16, p16, None, 4, 16, None) == INVALID
     assert lib.iris_bilstm128_forward(p16, p8, p16, None, 4, 16, None) == INVALID     # w_hh must be 16-byte aligned
     assert lib.iris_bilstm128_forward(p16, p16, p16, None, 0, 16, None) == INVALID

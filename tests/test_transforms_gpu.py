@@ -1003,10 +1003,36 @@ def test_first_conv_bias_relu_one_pass(dev):
         got = FE.conv3x3_small_bias_relu_nchw(x, wt, bias)
         assert got.shape == want.shape and got.is_contiguous()
         assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (b, cin, cout, h, w)
+        if cout % 4 == 0 and 1024 % cout == 0:   # the channels-last form (what the matrix-core convolution behind it reads)
+            got = FE.conv3x3_small_bias_relu(x, wt, bias, channels_last=True)
+            assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+            assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (b, cin, cout, h, w)
     with pytest.raises(ValueError):
         FE.conv3x3_small_bias_relu_nchw(torch.zeros(1, 3, 4, 4, device=dev), torch.zeros(8, 3, 3, 3, device=dev), torch.zeros(8, device=dev))
     with pytest.raises(ValueError):
         FE.conv3x3_small_bias_relu_nchw(torch.zeros(1, 1, 4, 6, device=dev), torch.zeros(8, 1, 3, 3, device=dev), torch.zeros(8, device=dev))
+
+
+def test_conv32_matrix_core_kernel(dev):
+    """iris_conv3x3_c32_bias_relu (32 -> 32 channels, implicit GEMM on the fp32 MFMA, bias + ReLU (+ MaxPool) fused): equals
+    relu(conv2d + bias) and its 2x2 'same' max-pool on sizes that are and are not multiples of the 4 x 64 tile, incl. odd ones."""
+    from challenge_amd import frontend as FE
+    torch.manual_seed(14)
+    for b, h, w in [(2, 8, 64), (1, 5, 70), (3, 4, 7), (2, 1, 1), (1, 9, 129), (4, 64, 512)]:
+        x = torch.randn(b, 32, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        wt = torch.randn(32, 32, 3, 3, device=dev) * 0.1
+        bias = torch.randn(32, device=dev) * 0.5
+        want = torch.relu(torch.nn.functional.conv2d(x, wt, bias, padding=1))
+        got = FE.conv3x3_c32_bias_relu(x, wt, bias)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        tol = 2e-5 * max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) <= tol, (b, h, w, float((got - want).abs().max()))
+        wantp = torch.nn.functional.max_pool2d(want, 2, 2, ceil_mode=True)
+        gotp = FE.conv3x3_c32_bias_relu(x, wt, bias, pool=True)
+        assert gotp.shape == wantp.shape and float((gotp - wantp).abs().max()) <= tol, (b, h, w)
+    with pytest.raises(ValueError):
+        FE.conv3x3_c32_bias_relu(torch.zeros(1, 16, 4, 4, device=dev).contiguous(memory_format=torch.channels_last),
+                                 torch.zeros(32, 32, 3, 3, device=dev), torch.zeros(32, device=dev))
 
 
 def test_hip_bilstm_matches_torch(dev):
@@ -1132,7 +1158,7 @@ def test_inference_engine_matches_module(dev):
     fe = S.WaveFrontend(1024, 256, 64, 16000, 1, 4, length, dev, training=False)
     wav = torch.randn(4, 1, length, device=dev) * 0.1
     eng = S.InferenceEngine(model, fe, wav)
-    assert eng.fused_convs == 14 and eng.fused_lstm
+    assert eng.fused_convs == 14 and eng.fused_lstm and eng.hip_convs == 2
     model.eval()
     with torch.no_grad():
         want = model(fe(wav))
