@@ -93,8 +93,11 @@ def predict_frames(model, features: torch.Tensor, config, overlap_hop: int = 512
     frame_len = features.shape[-2]
     windows = frame(features, config.n_frame, overlap_hop, pad_end=True, axis=-2)  # [M, W, n_frame, C']
     windows = windows.permute(1, 0, 2, 3)[..., :config.n_chan].contiguous()
-    model.eval()
-    preds = torch.cat([model(windows[i:i + batch_size]) for i in range(0, windows.shape[0], batch_size)])
+    if hasattr(model, 'predict'):  # CustomModel: Keras-style predict (on a GPU: through its cached InferenceEngine)
+        preds = model.predict(windows, batch_size=batch_size)
+    else:
+        model.eval()
+        preds = torch.cat([model(windows[i:i + batch_size]) for i in range(0, windows.shape[0], batch_size)])
     if config.v in label_downsample_model:
         preds = preds.repeat_interleave(config.n_frame // preds.shape[-2], dim=-2)  # UpSampling1D
     preds = preds.permute(2, 0, 1)  # [K, W, n_frame]

@@ -877,6 +877,35 @@ class CustomModel(nn.Module):
         self.eval()
         return {'loss': self.loss_fn(y, self(x))}
 
+    def _state_version(self):
+        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+
+    @torch.no_grad()
+    def predict(self, x: torch.Tensor, batch_size: int = 32) -> torch.Tensor:
+        """Keras `Model.predict` (what metrics.evaluate calls, metrics.py:62): inference in batches of `batch_size`, no
+        gradients, training state untouched.  On a GPU it runs through an `InferenceEngine` (BatchNorm folded, HIP epilogues /
+        block-1 convolutions / LSTM launch; outputs equal to 1e-4) that is rebuilt whenever a parameter or buffer has changed
+        since it was made."""
+        if x.is_cuda and x.dtype == torch.float32:
+            ver = self._state_version()
+            eng = self.__dict__.get('_predict_engine')
+            if eng is None or eng[0] != ver:
+                was_training = self.training
+                eng = (ver, InferenceEngine(self))
+                self.train(was_training)
+                object.__setattr__(self, '_predict_engine', eng)
+            fn = eng[1]
+        else:
+            was_training = self.training
+            self.eval()
+            fn = self.__call__
+        try:
+            outs = [fn(x[i:i + batch_size]) for i in range(0, x.shape[0], batch_size)]
+        finally:
+            if not (x.is_cuda and x.dtype == torch.float32):
+                self.train(was_training)
+        return torch.cat(outs) if len(outs) != 1 else outs[0]
+
 
 @torch.no_grad()
 def fold_batchnorm(model: nn.Module) -> nn.Module:
@@ -886,7 +915,7 @@ def fold_batchnorm(model: nn.Module) -> nn.Module:
     fp32 rounding (CPU test: <= 1e-5 on the sigmoid outputs); 18 + 5 normalisation launches fewer per forward of
     the v9 CRNN.  The copy is put in eval mode; training keeps the original (BN needs batch statistics there)."""
     import copy
-    keep = {k: model.__dict__.get(k) for k in ('optimizer', '_ddp', '_fused_agc')}  # training state stays with the original
+    keep = {k: model.__dict__.get(k) for k in ('optimizer', '_ddp', '_fused_agc', '_predict_engine')}  # stays with the original
     try:
         for k in keep:
             if k in model.__dict__:

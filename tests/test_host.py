@@ -422,3 +422,20 @@ def test_fused_pass_gates():
     assert y.shape == (2, 8, 3, 3) and not y.grad_fn.name().startswith("_Fused")
     fc = S.FullyConnectedLayer(16, 8, BN=True).train()
     assert fc(torch.randn(2, 3, 16)).shape == (2, 3, 8)
+
+
+def test_model_predict_is_keras_like():
+    """CustomModel.predict (metrics.py:62 calls Keras' model.predict): batches, no gradients, training flag untouched, same
+    values as the module in eval mode."""
+    import torch
+    from challenge_amd import sj_train as S
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '32', '--n_frame', '64', '--n_chan', '1'])
+    torch.manual_seed(0)
+    model = S.get_model(cfg).train()
+    x = torch.randn(5, 32, 64, 1)
+    out = model.predict(x, batch_size=2)
+    assert model.training and not out.requires_grad and tuple(out.shape) == (5, 2, 3)
+    model.eval()
+    with torch.no_grad():
+        want = model(x)
+    assert float((out - want).abs().max()) <= 1e-6

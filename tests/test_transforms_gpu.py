@@ -1035,6 +1035,34 @@ def test_conv32_matrix_core_kernel(dev):
                                  torch.zeros(32, 32, 3, 3, device=dev), torch.zeros(32, device=dev))
 
 
+def test_model_predict_uses_a_cached_engine(dev):
+    """CustomModel.predict on the GPU: through an InferenceEngine that is reused while the weights stand and rebuilt after a
+    training step; values equal the module in eval mode to 1e-4."""
+    from challenge_amd import sj_train as S
+    S.configure_miopen()
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '64', '--n_frame', '128', '--n_chan', '1', '--batch_size', '4'])
+    torch.manual_seed(2)
+    model = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    model.compile(S.make_optimizer(cfg, model.parameters()), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+    x = torch.rand(6, 64, 128, 1, device=dev)
+    y = (torch.rand(6, 4, 3, device=dev) < 0.2).float()
+
+    def reference():
+        model.eval()
+        with torch.no_grad():
+            return model(x)
+
+    p1 = model.predict(x, batch_size=4)
+    eng1 = model._predict_engine[1]
+    assert eng1.hip_convs == 2 and eng1.fused_lstm and float((p1 - reference()).abs().max()) <= 1e-4
+    model.predict(x)
+    assert model._predict_engine[1] is eng1                       # unchanged weights: the same engine
+    model.train_step((x[:4], y[:4]))
+    p2 = model.predict(x)
+    assert model._predict_engine[1] is not eng1 and model.training   # rebuilt; the training flag is left alone
+    assert float((p2 - reference()).abs().max()) <= 1e-4 and float((p2 - p1).abs().max()) > 0
+
+
 def test_hip_bilstm_matches_torch(dev):
     """iris_bilstm128_forward behind sj_train._HipBiLSTM: the whole bidirectional recurrence in one launch equals
     torch.nn.LSTM (MIOpen) on the same weights - odd batch sizes (a workgroup owns two rows), one step, long sequences,
