@@ -257,6 +257,20 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
     wds = iter(S.make_wave_dataset(dcfg, True, sources=wsrc, device=dev, seed=rank))
     t_wdata_host = timed(lambda: next(wds), steps)
     del wds, wsrc
+    # what bounds c3 / c4 once the frontend is 1 % of them: the CRNN's convolutions on the fp32 matrix cores (157.3 TFLOP/s)
+    conv_flops, hw = 0.0, (N_MEL, 512)
+    for blk in model.features:
+        for m in blk.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                conv_flops += 2.0 * batch * hw[0] * hw[1] * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
+        if isinstance(getattr(blk, "pool", None), torch.nn.MaxPool2d):
+            hw = (-(-hw[0] // 2), -(-hw[1] // 2))
+    best_fwd_ms = 1e3 * min(t for t in (t_fwd, t_fwd_folded, t_fwd_graph) if t is not None)
+    mfma = {"conv_gflop_per_forward": round(conv_flops / 1e9, 1), "fp32_mfma_peak_tflops": 157.3,
+            "c3_bound_ms": round(1e3 * conv_flops / 157.3e12, 3), "c3_frac_of_bound": round(1e3 * conv_flops / 157.3e12 / best_fwd_ms, 3),
+            "c4_bound_ms": round(3e3 * conv_flops / 157.3e12, 3), "c4_frac_of_bound": round(3e3 * conv_flops / 157.3e12 / (1e3 * t_train), 3),
+            "note": "forward = one pass over the convolutions, training = three (forward, backward-data, backward-weight); "
+                    "fp32 in / fp32 accumulate MFMA, the precision the reference trains in"}
     c3 = {"audio_s_per_s": round(world * audio_s / t_fwd, 1), "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch,
           "what": "training-mode model object in eval(): BatchNorm kernels, separate bias / ReLU kernels (the literal module)",
           "inference_engine": {
@@ -279,6 +293,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                          "shape": "waveforms [2, L_i] resident in HBM -> mixed [64, 2, 130816] -> log-mel [64, 80, 512, 2] + labels"},
         "c3_frontend_specaug_crnn_fwd": c3,
         "c3_best_fp32_audio_s_per_s": round(world * audio_s / best_fwd, 1),
+        "crnn_matrix_core_bound": mfma,
         "c4_train_step": {"audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3),
                           "batch_per_gpu": batch, "n_gpus": world, "params": sum(p.numel() for p in model.parameters()),
                           "hipgraph": graphed, "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if world > 1 else "none", "device_ms_per_phase": breakdown,
