@@ -416,8 +416,8 @@ def self_launch(args, argv):
         sys.exit(2)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
            f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + argv
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL needs it on this driver)
+    from challenge_amd.sj_train import distributed_env  # imports torch, touches no GPU
+    env = distributed_env(dict(os.environ))  # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: RCCL needs it on this driver), MASTER_ADDR
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     if lines:
@@ -508,6 +508,9 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:  # ranks started by the driver's own `python -m torch.distributed.run ... bench.py`: same environment as
+        from challenge_amd.sj_train import distributed_env  # self_launch gives its children, before the first GPU call
+        distributed_env()
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
     # test hook: IRIS_BENCH_SHARE_GPU=1 lets several ranks share cuda:0 over gloo, to exercise the N > 1
     # control flow (self-launch, barriers, max over ranks, DDP) on a one-GPU box; never set in a real run
@@ -525,6 +528,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL
         backend = dist.get_backend()
+        if not share and backend != "nccl":  # the N > 1 line is about RCCL over xGMI; anything else is a mis-launch
+            print(f"bench.py: world {world} runs on backend '{backend}', expected 'nccl' (RCCL)", file=sys.stderr)
+            sys.exit(2)
     if args.strong and STRONG_GLOBAL_BATCH % world:
         print(f"bench.py: --strong needs a world size that divides {STRONG_GLOBAL_BATCH}", file=sys.stderr)
         sys.exit(2)
@@ -631,6 +637,14 @@ def main():
         result["ranks"] = ranks
         result["rccl_world"] = dist.get_world_size()
         result["backend"] = backend
+        result["backend_is_rccl"] = backend == "nccl"  # false only under the share-one-GPU test hook (gloo)
+        # `value` scales trivially (no collective in the frontend): the quantity north_star's ">= 6x at 8 GPUs" is about is
+        # the TRAINING STEP, lifted to the top level below once it has been measured (side_measurements)
+        result["metric"] = ("audio-seconds/sec @16 kHz, STFT+mel frontend only, whole job (embarrassingly parallel: no "
+                            "collective).  SCALING TARGET = the training step: see train_step_ms / train_step_audio_s_per_s / "
+                            "allreduce_exposed_ms at the top level of this line (c4: frontend + CRNN forward / backward + "
+                            "RCCL gradient all-reduce + AGC + Adam, batch 64 per GPU)")
+        result.update({"train_step_ms": None, "train_step_audio_s_per_s": None, "allreduce_exposed_ms": None, "grad_bytes": None})
     import threading
     done_lock, done = threading.Lock(), []
     # what the final line needs from the device is fetched now: finish() may run while the GPU is stuck
@@ -647,6 +661,12 @@ def main():
                 result["extra"] = extras
                 if "c3_best_fp32_audio_s_per_s" in extras:
                     result["stft_mel_fwd_audio_s_per_s"] = extras["c3_best_fp32_audio_s_per_s"]
+                c4 = extras.get("c4_train_step")
+                if world > 1 and c4:  # the scaling curve of the END-TO-END TRAINING STEP, at the top level of the line
+                    comm = c4.get("allreduce") or {}
+                    result.update({"train_step_ms": c4.get("ms_per_step"), "train_step_audio_s_per_s": c4.get("audio_s_per_s"),
+                                   "allreduce_exposed_ms": comm.get("exposed_allreduce_ms_per_step"),
+                                   "grad_bytes": comm.get("grad_bytes")})
             algo_bytes = ALGO_BYTES_PER_AUDIO_S * audio_s_per_step  # per launch
             traffic, step_traffic, traffic_note = committed_traffic()
             step_gbs = algo_bytes / (elapsed / args.steps) / 1e9

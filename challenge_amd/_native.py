@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("IRIS_LIB") or os.path.join(_HERE, "csrc", "libiris_fr
 IRIS_F_MINMAX, IRIS_F_LOG, IRIS_F_NORMALIZE = 1, 2, 4
 IRIS_MEL_F32, IRIS_MEL_F16_MFMA = 0, 1
 IRIS_EPILOGUE_FUSED, IRIS_EPILOGUE_TWO_KERNELS = 0, 1
+IRIS_E_EPILOGUE_TIMEOUT = -5
 
 # every symbol include/iris_frontend.h declares, with (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -29,6 +30,7 @@ SIGNATURES = {
     "iris_plan_set_mel_precision": (_i, [_vp, _i]),
     "iris_plan_set_epilogue": (_i, [_vp, _i]),
     "iris_plan_status": (_i, [_vp, C.POINTER(_i)]),
+    "iris_plan_set_epilogue_timeout": (_i, [_vp, C.c_ulonglong]),
     "iris_plan_get_mel": (_i, [_vp, _fp]),
     "iris_plan_num_frames": (_i, [_vp, _i]),
     "iris_normalize_workspace": (_sz, [_i, _sz]),
@@ -84,6 +86,12 @@ class IrisError(RuntimeError):
     """A C-ABI call returned a non-zero status."""
 
 
+class EpilogueTimeout(IrisError):
+    """A fused-epilogue launch of a plan gave up a bounded wait (IRIS_E_EPILOGUE_TIMEOUT): its workgroups were not
+    co-resident - concurrent kernels, a CU mask or another process on the device.  Features produced by that plan since
+    its last clean status are suspect (the affected clips are NaN); the plan has switched to the two-kernel form."""
+
+
 def lib() -> C.CDLL:
     """Load libiris_frontend.so (once).  Raises ImportError if it is not built."""
     global _lib
@@ -114,4 +122,6 @@ def check(status: int, what: str) -> None:
     msg = lib().iris_last_error().decode("utf-8", "replace")
     if status in (-1, -2, -3):  # bad argument / unsupported / capacity
         raise ValueError(f"{what}: {msg} (status {status})")
+    if status == IRIS_E_EPILOGUE_TIMEOUT:
+        raise EpilogueTimeout(f"{what}: {msg} (status {status})")
     raise IrisError(f"{what}: {msg} (status {status})")

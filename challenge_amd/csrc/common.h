@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -86,8 +87,10 @@ struct iris_plan {
     void* d_wfrag;
     int* d_tile_ks;
     float* d_ws;  // workspace
-    unsigned long long* d_slots;  // fused epilogue: [n_slots][2] {epoch, value} granules, then the status word
-    unsigned* d_status;
+    unsigned long long* d_slots;  // fused epilogue: [n_slots][2] {epoch, value} granules
+    unsigned* h_status;           // status word in pinned, coherent HOST memory: the kernel raises it with a system-scope
+    unsigned* d_status;           // store (through d_status, its device address), the host reads it without synchronising
+    unsigned long long timeout_ticks;  // bound of the epilogue's waits, in s_memrealtime ticks (100 MHz)
     size_t n_slots;
     unsigned epoch;  // launches of the fused-epilogue kernel so far (granule tag; never 0)
     int epilogue;    // IRIS_EPILOGUE_*

@@ -252,6 +252,11 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     if ((rc = check_bands(t_bands, n_tb, "iris_wav_to_logmel")) ||
         (rc = check_bands(f_bands, n_fb, "iris_wav_to_logmel")))
         return rc;
+    if (take_status(p))  // raised by an earlier launch (host-visible word: no synchronisation here)
+        return fail(IRIS_E_EPILOGUE_TIMEOUT,
+                    "iris_wav_to_logmel: an earlier fused-epilogue launch of this plan gave up waiting for its clip's other "
+                    "workgroups (they were not co-resident: concurrent kernels, a CU mask or another process on the device) and "
+                    "wrote NaN; nothing was enqueued by this call, the plan now uses the two-kernel form");
     DeviceGuard guard(p->device);
     hipStream_t s = (hipStream_t)stream;
     FusedArgs a;
@@ -313,6 +318,7 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     }
     a.slots = p->d_slots;
     a.status = p->d_status;
+    a.timeout_ticks = p->timeout_ticks;
     a.epoch = 0;
     a.tile_off = a.pitch = 0;
     a.do_minmax = do_minmax;

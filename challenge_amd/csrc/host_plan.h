@@ -316,6 +316,8 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->magmel_generic = getenv("IRIS_MAGMEL_GENERIC") != nullptr;  // test hook: read once, never per launch
     p->d_slots = nullptr;
     p->d_status = nullptr;
+    p->h_status = nullptr;
+    p->timeout_ticks = kEpilogueTimeoutTicks;
     p->epoch = 0;
     p->epilogue = IRIS_EPILOGUE_FUSED;
     if (const char* e = getenv("IRIS_EPILOGUE")) p->epilogue = atoi(e) == IRIS_EPILOGUE_TWO_KERNELS ? IRIS_EPILOGUE_TWO_KERNELS : IRIS_EPILOGUE_FUSED;
@@ -556,7 +558,17 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
         iris_plan_destroy(p);
         return fail((int)e, "hipMalloc(epilogue slots) failed: %s", hipGetErrorString(e));
     }
-    p->d_status = reinterpret_cast<unsigned*>(p->d_slots + 2 * p->n_slots);
+    // the status word: pinned coherent host memory mapped into the device, so that a failed wait is visible to the
+    // host on its next call without any synchronisation
+    e = hipHostMalloc((void**)&p->h_status, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) {
+        *p->h_status = 0;
+        e = hipHostGetDevicePointer((void**)&p->d_status, p->h_status, 0);
+    }
+    if (e != hipSuccess) {
+        iris_plan_destroy(p);
+        return fail((int)e, "hipHostMalloc(status word) failed: %s", hipGetErrorString(e));
+    }
     *out = p;
     return IRIS_OK;
 }
@@ -642,6 +654,7 @@ extern "C" int iris_plan_destroy(iris_plan* p) {
     (void)hipFree(p->d_tile_ks);
     (void)hipFree(p->d_ws);
     (void)hipFree(p->d_slots);
+    if (p->h_status) (void)hipHostFree(p->h_status);
     delete p;
     return IRIS_OK;
 }
@@ -668,13 +681,27 @@ extern "C" int iris_plan_set_epilogue(iris_plan* p, int mode) {
     return IRIS_OK;
 }
 
+// Reads and clears the host-visible status word.  A raised word means a fused-epilogue launch gave up a wait: the
+// co-residency its clip-level exchange relies on does not hold in this process' environment, so the plan leaves the
+// fused form for good.
+static bool take_status(iris_plan* p) {
+    if (!p->h_status) return false;
+    const unsigned v = __atomic_exchange_n(p->h_status, 0u, __ATOMIC_ACQ_REL);
+    if (v) p->epilogue = IRIS_EPILOGUE_TWO_KERNELS;
+    return v != 0;
+}
+
 extern "C" int iris_plan_status(iris_plan* p, int* status) {
     if (!p || !status) return fail(IRIS_E_INVALID, "iris_plan_status: NULL argument");
     DeviceGuard guard(p->device);
-    unsigned v = 0;
-    HIP_TRY(hipMemcpy(&v, p->d_status, sizeof(v), hipMemcpyDeviceToHost));  // synchronises with the device
-    if (v) HIP_TRY(hipMemset(p->d_status, 0, sizeof(v)));
-    *status = (int)v;
+    HIP_TRY(hipDeviceSynchronize());  // every launch of the plan so far has finished (and its system-scope store landed)
+    *status = take_status(p) ? 1 : 0;
+    return IRIS_OK;
+}
+
+extern "C" int iris_plan_set_epilogue_timeout(iris_plan* p, unsigned long long microseconds) {
+    if (!p) return fail(IRIS_E_INVALID, "iris_plan_set_epilogue_timeout: NULL plan");
+    p->timeout_ticks = microseconds * 100ull;  // s_memrealtime: 100 MHz
     return IRIS_OK;
 }
 

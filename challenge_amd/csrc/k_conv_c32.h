@@ -158,19 +158,21 @@ extern "C" int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, c
     if (!x || !weight || !bias || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_c32_bias_relu: NULL argument");
     if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_c32_bias_relu: empty tensor");
     if ((reinterpret_cast<uintptr_t>(x) & 15)) return fail(IRIS_E_INVALID, "iris_conv3x3_c32_bias_relu: x must be 16-byte aligned");
-    static bool attr_set = false;
-    if (!attr_set) {
+    // per DEVICE (the attribute belongs to the function object of the current device) and safe from several threads: one
+    // atomic flag per device ordinal; setting the attribute twice is harmless, skipping it on a second GPU is not
+    int dev = 0, n_cu = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    static std::atomic<unsigned> attr_set[64];
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c32<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kC32LdsBytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c32<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kC32LdsBytes));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(1u, std::memory_order_release);
     }
     const long long n_tiles = (long long)((width + kC32TileW - 1) / kC32TileW) * ((height + kC32TileH - 1) / kC32TileH) * batch;
     if (n_tiles >= 2147483647LL) return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_c32_bias_relu: too many tiles");
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        n_cu = 256;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const unsigned grid = (unsigned)std::min<long long>(n_tiles, 2LL * n_cu);  // persistent: two workgroups per CU walk the tiles
     if (pool) k_conv3x3_c32<true><<<grid, 256, kC32LdsBytes, (hipStream_t)stream>>>(x, weight, bias, y, batch, height, width);
     else k_conv3x3_c32<false><<<grid, 256, kC32LdsBytes, (hipStream_t)stream>>>(x, weight, bias, y, batch, height, width);

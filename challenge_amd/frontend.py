@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 from typing import Optional, Tuple
 
 import numpy as np
@@ -62,6 +63,21 @@ def mel_weight_matrix(num_mel_bins: int = 20, num_spectrogram_bins: int = 129,
     return out
 
 
+_LIVE_PLANS: "weakref.WeakSet[FrontendPlan]" = weakref.WeakSet()
+
+
+def check_plans(device=None) -> None:
+    """Raise EpilogueTimeout if any live plan (on `device`, or anywhere) reports a failed fused-epilogue wait.
+    Synchronises; meant for the places that synchronise anyway (`sj_train.fit` calls it once per epoch)."""
+    dev = None if device is None else torch.device(device)
+    for plan in list(_LIVE_PLANS):
+        if plan._handle is None or plan.n_fft == 0:
+            continue
+        if dev is not None and dev.type == "cuda" and dev.index is not None and plan.device != dev:
+            continue
+        plan.raise_on_failure()
+
+
 class FrontendPlan:
     """State of `Spectrogram(n_fft, power=None)` (data_utils.py:17) plus the
     `magphase_to_mel(...)` closure (transforms.py:51-56) on one device."""
@@ -101,6 +117,7 @@ class FrontendPlan:
         self._lock = threading.Lock()
         self.mel_precision = "fp32"
         self.epilogue = "two_kernels" if os.environ.get("IRIS_EPILOGUE") == "1" else "fused"
+        _LIVE_PLANS.add(self)
 
     @classmethod
     def mel_only(cls, n_mel: int, n_bins: int, channels: int, max_batch: int, device,
@@ -143,10 +160,29 @@ class FrontendPlan:
         self.epilogue = mode
 
     def status(self) -> int:
-        """0 = every bounded in-kernel wait of the fused epilogue completed so far (synchronises; resets the word)."""
+        """0 = every bounded in-kernel wait of the fused epilogue completed so far; 1 = one gave up (clips written as
+        NaN).  Synchronises with the device and resets the word; after a 1 the plan stays on the two-kernel form."""
         st = C.c_int(0)
         N.check(N.lib().iris_plan_status(self._handle, C.byref(st)), "iris_plan_status")
+        if st.value:
+            self.epilogue = "two_kernels"
         return st.value
+
+    def raise_on_failure(self) -> None:
+        """`status()` as an exception: EpilogueTimeout naming the plan.  Call where a synchronisation happens anyway
+        (end of an epoch, after reading a loss); the hot path itself reports a failed EARLIER launch without any
+        synchronisation - the next `wav_to_logmel` on the plan raises the same exception."""
+        if self._handle is not None and self.status():
+            raise N.EpilogueTimeout(
+                f"FrontendPlan(n_fft={self.n_fft}, hop={self.hop}, n_mel={self.n_mel}, channels={self.channels}, "
+                f"max_batch={self.max_batch}, device={self.device}): a fused min-max / log epilogue gave up waiting for "
+                "its clip's other workgroups (not co-resident: concurrent kernels, a CU mask or another process on the "
+                "device) and wrote NaN features; the plan now uses the two-kernel form")
+
+    def set_epilogue_timeout(self, microseconds: int) -> None:
+        """Bound of the fused epilogue's in-kernel waits (default 2 s).  0 gives up after the first sweep: the test hook
+        that makes the failure path reachable on a healthy device."""
+        N.check(N.lib().iris_plan_set_epilogue_timeout(self._handle, int(microseconds)), "iris_plan_set_epilogue_timeout")
 
     def close(self) -> None:
         if self._handle is not None:
@@ -226,6 +262,8 @@ class FrontendPlan:
         with self._lock, torch.cuda.device(self.device):
             rc = N.lib().iris_wav_to_logmel(self._handle, wav.data_ptr(), out.data_ptr(), b, length, flags,
                                             tbp, ntb, fbp, nfb, _stream_ptr(self.device))
+        if rc == N.IRIS_E_EPILOGUE_TIMEOUT:
+            self.epilogue = "two_kernels"  # the library has switched the plan for good
         N.check(rc, "iris_wav_to_logmel")
         return out
 

@@ -481,8 +481,16 @@ class FusedAGC:
         self._table = host.to(self.params[0].device, non_blocking=True)
         self._sig = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
 
+    def freeze(self) -> None:
+        """After a hipGraph capture: the table and its pinned staging buffer are referenced by the graph and must never be
+        rebuilt; any later call of this object raises instead."""
+        self._frozen = True
+
     def __call__(self, clip_factor=0.01, eps=1e-3, clipvalue=None):
         import ctypes as C
+        if getattr(self, '_frozen', False):
+            raise RuntimeError("FusedAGC: this instance belongs to a captured hipGraph (GraphedTrainStep) and cannot be "
+                               "called eagerly; eager steps use the model's own instance")
         sig = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
         if sig != self._sig:
             self._build()
@@ -814,6 +822,10 @@ class CustomModel(nn.Module):
         self.use_agc = True
         object.__setattr__(self, '_ddp', None)  # not a submodule: DDP wraps this very module
         object.__setattr__(self, '_fused_agc', None)
+        # bumped by everything that changes parameters or buffers WITHOUT going through ATen's version counters: the raw-
+        # pointer BatchNorm / AGC kernels, hipGraph replays (GraphedTrainStep), load_state_dict; `predict` keys its cached
+        # InferenceEngine on it
+        object.__setattr__(self, '_generation', 0)
 
     def forward(self, x):
         """x: [B, n_mels, n_frame, n_chan] (the reference's channels-last input)."""
@@ -845,6 +857,7 @@ class CustomModel(nn.Module):
         mark = _mark or (lambda name: None)
         x, y = data
         self.train()
+        self.bump_generation()
         fused = self.use_agc and x.is_cuda  # one HIP launch for AGC + clipvalue over the whole model
         # fused: keep the gradient buffers in place (measured: dropping them saves the zero + accumulate
         # kernels, 1.3 ms, but the buffers then move and FusedAGC re-uploads its table every step: +0.8 ms net)
@@ -877,8 +890,17 @@ class CustomModel(nn.Module):
         self.eval()
         return {'loss': self.loss_fn(y, self(x))}
 
+    def bump_generation(self) -> None:
+        """Tell `predict` that parameters / buffers have changed (see `_generation`)."""
+        object.__setattr__(self, '_generation', self._generation + 1)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.bump_generation()
+        return out
+
     def _state_version(self):
-        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+        return (self._generation, sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers()))
 
     @torch.no_grad()
     def predict(self, x: torch.Tensor, batch_size: int = 32) -> torch.Tensor:
@@ -1201,6 +1223,140 @@ def get_model(config):
                               "(EfficientNet / speech-enhancement branches, sj_train.py:299-401)")
 
 
+# ---------------------------------------------------------------------------
+# checkpoints of the reference: Keras weights -> this module's state_dict      sj_train.py:467-469, eval.py:42-65
+# ---------------------------------------------------------------------------
+def _keras_weight_list(weights) -> list:
+    """An ORDERED list of arrays from: a list / tuple (model.get_weights()), an .npz path or an open NpzFile / dict whose
+    keys are 'arr_0', 'arr_1', ... (np.savez(path, *model.get_weights())) or '<index>|<keras weight name>'
+    (scripts/dump_keras_weights.py).  Order = Keras' model.weights order = layer order of define_keras_model."""
+    if isinstance(weights, (str, os.PathLike)):
+        with np.load(weights) as z:
+            return _keras_weight_list({k: z[k] for k in z.files})
+    if isinstance(weights, (list, tuple)):
+        return [np.asarray(w) for w in weights]
+    keys = list(weights.keys())
+
+    def order(k):
+        head = k.split('|', 1)[0]
+        if head.isdigit():
+            return int(head)
+        if k.startswith('arr_') and k[4:].isdigit():
+            return int(k[4:])
+        raise ValueError(f"load_keras_weights: cannot order the key {k!r}; expected 'arr_<i>' or '<i>|<name>' keys "
+                         "(np.savez(path, *model.get_weights()) or scripts/dump_keras_weights.py)")
+    return [np.asarray(weights[k]) for k in sorted(keys, key=order)]
+
+
+@torch.no_grad()
+def load_keras_weights(model: "CustomModel", weights) -> "CustomModel":
+    """Load a checkpoint of the REFERENCE model (`model.load_weights(NAME)`, sj_train.py:467-469; eval.py:42-65) into the
+    torch CustomModel: `weights` = the reference model's `get_weights()` in layer order (see `_keras_weight_list`; Keras
+    .h5 files are converted where TensorFlow exists by scripts/dump_keras_weights.py - h5py is not needed here).
+    Layer walk of define_keras_model (sj_train.py:214-255) with Keras' layouts mapped onto torch's:
+      Conv2D kernel [kh, kw, cin, cout] (HWIO) -> weight [cout, cin, kh, kw]; bias as is
+      BatchNormalization gamma, beta, moving_mean, moving_variance -> weight, bias, running_mean, running_var (eps 1e-3 both)
+      Dense / TimeDistributed(Dense) kernel [in, out] -> weight [out, in]; the TimeDistributed input is the Permute + Reshape
+        of [B, M', T', C] to [B, T', M' C] (m' major, :243-244) - the order `CustomModel.forward` flattens in
+      Bidirectional(LSTM(128)) forward then backward layer: kernel [in, 4u], recurrent_kernel [u, 4u], bias [4u], gate order
+        i, f, c, o = torch's i, f, g, o -> weight_ih [4u, in], weight_hh [4u, u], bias_ih = bias, bias_hh = 0
+    Shapes are checked entry by entry; a count or shape mismatch raises ValueError naming the layer.  v 6 / 7 / 8 / 9."""
+    ws = _keras_weight_list(weights)
+    pos = [0]
+
+    def take(shape, what):
+        if pos[0] >= len(ws):
+            raise ValueError(f"load_keras_weights: ran out of arrays at {what} (got {len(ws)})")
+        w = ws[pos[0]]
+        if tuple(w.shape) != tuple(shape):
+            raise ValueError(f"load_keras_weights: array {pos[0]} is {tuple(w.shape)}, expected {tuple(shape)} for {what}")
+        pos[0] += 1
+        return torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
+
+    def put(dst, src):
+        dst.copy_(src.to(dst.device, dst.dtype))  # same shape by construction; copy_ honours dst's memory format
+
+    def conv(c: nn.Conv2d, what):
+        kh, kw = c.kernel_size
+        k = take((kh, kw, c.in_channels, c.out_channels), what + ' kernel')
+        put(c.weight, k.permute(3, 2, 0, 1).contiguous())
+        put(c.bias, take((c.out_channels,), what + ' bias'))
+
+    def bnorm(b, what):
+        n = b.num_features
+        put(b.weight, take((n,), what + ' gamma'))
+        put(b.bias, take((n,), what + ' beta'))
+        put(b.running_mean, take((n,), what + ' moving_mean'))
+        put(b.running_var, take((n,), what + ' moving_variance'))
+
+    def dense(fc: nn.Linear, what):
+        put(fc.weight, take((fc.in_features, fc.out_features), what + ' kernel').t().contiguous())
+        put(fc.bias, take((fc.out_features,), what + ' bias'))
+
+    def conv_bn(layer: _ConvBNReLU, what):
+        conv(layer[0], what)
+        if isinstance(layer[1], nn.BatchNorm2d):
+            bnorm(layer[1], what + ' BatchNormalization')
+
+    for bi, blk in enumerate(model.features):
+        if isinstance(blk, ConvMPBlock):
+            for li, layer in enumerate(blk.convs):
+                conv_bn(layer, f'features[{bi}].convs[{li}] Conv2D')
+        elif isinstance(blk, _Bottleneck):
+            for li, layer in enumerate(blk.body):
+                conv_bn(layer, f'features[{bi}].body[{li}] Conv2D')
+        # _SmoothPool has no weights
+    dense(model.td, 'TimeDistributed(Dense 1024)')
+    for fi, fc in enumerate(list(model.fc_pre)):
+        dense(fc.fc, f'fc_pre[{fi}] Dense')
+        bnorm(fc.bn, f'fc_pre[{fi}] BatchNormalization')
+    if model.lstm is not None:
+        u, nin = model.lstm.hidden_size, model.lstm.input_size
+        for suffix, what in (('', 'Bidirectional forward LSTM'), ('_reverse', 'Bidirectional backward LSTM')):
+            put(getattr(model.lstm, 'weight_ih_l0' + suffix), take((nin, 4 * u), what + ' kernel').t().contiguous())
+            put(getattr(model.lstm, 'weight_hh_l0' + suffix), take((u, 4 * u), what + ' recurrent_kernel').t().contiguous())
+            put(getattr(model.lstm, 'bias_ih_l0' + suffix), take((4 * u,), what + ' bias'))
+            getattr(model.lstm, 'bias_hh_l0' + suffix).zero_()
+    dense(model.fc_post.fc, 'fc_post Dense')
+    bnorm(model.fc_post.bn, 'fc_post BatchNormalization')
+    dense(model.head.fc, 'head Dense')
+    if pos[0] != len(ws):
+        raise ValueError(f"load_keras_weights: {len(ws) - pos[0]} arrays left over after the last layer ({len(ws)} given, "
+                         f"{pos[0]} used): not a checkpoint of this architecture (v {model.config_v})")
+    if hasattr(model, 'bump_generation'):
+        model.bump_generation()
+    return model
+
+
+def keras_weight_shapes(model: "CustomModel") -> list:
+    """Shapes of the reference model's get_weights() for this architecture, in order (what `load_keras_weights` expects)."""
+    probe = []
+
+    def conv_bn(layer):
+        c = layer[0]
+        probe.append((*c.kernel_size, c.in_channels, c.out_channels))
+        probe.append((c.out_channels,))
+        if isinstance(layer[1], nn.BatchNorm2d):
+            probe.extend([(c.out_channels,)] * 4)
+    for blk in model.features:
+        if isinstance(blk, ConvMPBlock):
+            for layer in blk.convs:
+                conv_bn(layer)
+        elif isinstance(blk, _Bottleneck):
+            for layer in blk.body:
+                conv_bn(layer)
+    probe.extend([(model.td.in_features, model.td.out_features), (model.td.out_features,)])
+    for fc in list(model.fc_pre):
+        probe.extend([(fc.fc.in_features, fc.fc.out_features), (fc.fc.out_features,)] + [(fc.fc.out_features,)] * 4)
+    if model.lstm is not None:
+        u, nin = model.lstm.hidden_size, model.lstm.input_size
+        probe.extend([(nin, 4 * u), (u, 4 * u), (4 * u,)] * 2)
+    fc = model.fc_post
+    probe.extend([(fc.fc.in_features, fc.fc.out_features), (fc.fc.out_features,)] + [(fc.fc.out_features,)] * 4)
+    probe.extend([(model.head.fc.in_features, model.head.fc.out_features), (model.head.fc.out_features,)])
+    return probe
+
+
 def binary_crossentropy(y_true, y_pred):
     """tf.keras.losses.BinaryCrossentropy(): mean over all elements, probabilities
     clipped to [1e-7, 1 - 1e-7]."""
@@ -1290,9 +1446,21 @@ def _use_shipped_miopen_db() -> None:
         pass  # no shipped db / unwritable temp dir: MIOpen's own defaults
 
 
+def distributed_env(env=None):
+    """Environment a multi-process GPU job needs on this stack, set BEFORE the first GPU call of the process (or in the
+    environment handed to the ranks): the host driver only supports dmabuf IPC, and without HSA_ENABLE_IPC_MODE_LEGACY=0
+    RCCL's intra-node transports fail with `hipIpcGetMemHandle: invalid argument`.  `bench.self_launch`, `init_distributed`
+    and INTEGRATION.md's launch line all go through here, so the three cannot drift apart.  Values the user has set win."""
+    env = os.environ if env is None else env
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('MASTER_ADDR', '127.0.0.1')  # single node; the container's hostname may not resolve
+    return env
+
+
 def init_distributed():
     """One process per GPU (torchrun): returns (rank, world, device).  Backend 'nccl' is
     RCCL on ROCm; 'gloo' on CPU-only hosts (tests)."""
+    distributed_env()  # before torch.cuda.is_available(): that call already initialises the HIP runtime
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -1322,10 +1490,35 @@ def wrap_ddp(model: CustomModel, device, world: int):
     if world <= 1:
         return None
     from torch.nn.parallel import DistributedDataParallel as DDP
-    # ONE collective per step - the bucketed gradient all-reduce: BatchNorm statistics stay per replica (the reference has
-    # no multi-GPU at all; rank 0's are the ones checkpointed), so the per-forward buffer broadcast is switched off
+    # ONE collective per step - the bucketed gradient all-reduce: BatchNorm statistics stay per replica during the epoch
+    # (the reference has no multi-GPU at all), so the per-forward buffer broadcast is switched off; `fit` averages them
+    # over the ranks once per epoch, before validation and checkpointing (average_bn_statistics)
     return DDP(model, device_ids=[device.index] if device.type == 'cuda' else None,
                bucket_cap_mb=DDP_BUCKET_MB, gradient_as_bucket_view=True, broadcast_buffers=False)
+
+
+@torch.no_grad()
+def average_bn_statistics(model: nn.Module, world: int) -> None:
+    """BatchNorm running statistics are per replica under DDP (`broadcast_buffers=False`: no per-forward broadcast), each
+    rank seeing 1 / world of the data.  Before validation and checkpointing they are averaged over the ranks - ONE small
+    all-reduce per epoch over the 46 running_mean / running_var vectors flattened together - so that every rank validates,
+    and rank 0 saves, the same model.  (The mean of per-rank variances ignores the spread of the per-rank means: the
+    running averages of identically distributed shards, where that spread is O(1 / sqrt(steps)).)"""
+    if world <= 1:
+        return
+    bufs = [b for name, b in model.named_buffers() if name.endswith(('running_mean', 'running_var'))]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
+    torch.distributed.all_reduce(flat)
+    flat /= world
+    off = 0
+    for b in bufs:
+        n = b.numel()
+        b.copy_(flat[off:off + n].view_as(b))
+        off += n
+    if hasattr(model, 'bump_generation'):
+        model.bump_generation()
 
 
 class GraphedTrainStep:
@@ -1365,14 +1558,19 @@ class GraphedTrainStep:
         torch.cuda.synchronize(x.device)
         object.__setattr__(model, '_fused_agc', None)  # its table holds the eager gradients' addresses
         opt.zero_grad(set_to_none=True)
+        # The captured AGC launch reads a table whose pinned staging buffer is the source of a captured copy node: this
+        # object owns both for as long as the graph lives, and the model's own `_fused_agc` stays None - an eager
+        # `model.train_step` later (e.g. a ragged last batch) builds a SEPARATE FusedAGC instead of rebuilding - and
+        # freeing - the buffers the graph replays from.
+        self._agc = FusedAGC(list(model.parameters())) if model.use_agc else None
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             model.train()
             loss = model.loss_fn(self.y, model._call(self.x))
             loss.backward()
             if model.use_agc:
-                object.__setattr__(model, '_fused_agc', FusedAGC(list(model.parameters())))
-                model._fused_agc(0.01, 1e-3, model.clipvalue)
+                self._agc(0.01, 1e-3, model.clipvalue)
+                self._agc.freeze()
             elif model.clipvalue:
                 torch.nn.utils.clip_grad_value_([p for p in model.parameters() if p.grad is not None], model.clipvalue)
             opt.step()
@@ -1385,6 +1583,7 @@ class GraphedTrainStep:
         self.x.copy_(x, non_blocking=True)
         self.y.copy_(y, non_blocking=True)
         self.graph.replay()
+        self.model.bump_generation()  # a replay moves parameters and BatchNorm statistics behind ATen's back
         return {'loss': self.loss}
 
     def set_lr(self, value: float) -> None:
@@ -1416,6 +1615,13 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
             loss = loss / world
         row = {'epoch': epoch, 'loss': float(loss), 'lr': model.optimizer.param_groups[0]['lr'],
                'time': time.time() - t0}
+        if loss.is_cuda:
+            # float(loss) has just synchronised: the one place per epoch where the frontend plans' status words are read
+            # for certain (the hot path also reports a failed earlier launch at the plan's next call, without a sync).
+            # Raises EpilogueTimeout naming the plan instead of training on NaN features.
+            _fe.check_plans(loss.device)
+        if world > 1:
+            average_bn_statistics(model, world)
         if not math.isfinite(row['loss']):
             if verbose and rank == 0:
                 print('NaN loss, terminating')
@@ -1478,8 +1684,17 @@ def main(argv=None):
                   ddp=wrap_ddp(model, device, world))
     if rank == 0:
         print(NAME, sum(p.numel() for p in model.parameters()), 'parameters')
-    if config.pretrain and os.path.exists(NAME.replace('.h5', '.pt')):
-        model.load_state_dict(torch.load(NAME.replace('.h5', '.pt'), map_location=device))
+    if config.pretrain:
+        # `model.load_weights(NAME)` (sj_train.py:467-469): this module's own .pt checkpoint, or - a model trained with the
+        # reference - its Keras weights as an .npz next to it (scripts/dump_keras_weights.py writes one from the .h5)
+        if os.path.exists(NAME.replace('.h5', '.pt')):
+            model.load_state_dict(torch.load(NAME.replace('.h5', '.pt'), map_location=device))
+            if rank == 0:
+                print('loaded pretrained model', NAME.replace('.h5', '.pt'))
+        elif os.path.exists(NAME.replace('.h5', '.npz')):
+            load_keras_weights(model, NAME.replace('.h5', '.npz'))
+            if rank == 0:
+                print('loaded pretrained Keras weights', NAME.replace('.h5', '.npz'))
     if device.type == 'cuda' and config.online_stft:
         # corpora resident in HBM as WAVEFORMS, mixed before the STFT, fused frontend on line (synthetic sources:
         # the reference's pickles hold spectra, not waveforms)

@@ -49,7 +49,8 @@ enum {
     IRIS_E_INVALID = -1,     /* null pointer, non-positive size, inconsistent arguments */
     IRIS_E_UNSUPPORTED = -2, /* shape outside what the kernels are built for */
     IRIS_E_CAPACITY = -3,    /* batch / length larger than the plan was created for */
-    IRIS_E_NOMEM = -4
+    IRIS_E_NOMEM = -4,
+    IRIS_E_EPILOGUE_TIMEOUT = -5 /* an EARLIER fused-epilogue launch of this plan gave up a bounded wait (see iris_plan_set_epilogue) */
 };
 
 /* flags for iris_wav_to_logmel */
@@ -120,17 +121,27 @@ int iris_plan_set_mel_precision(iris_plan* plan, int precision);
  *                              fp16-MFMA variant and shapes whose chunk does not fit the LDS tile take the two-kernel
  *                              path by themselves.  Do not run several fused launches CONCURRENTLY on one device
  *                              (plans on different streams): each could hold CUs while waiting for workgroups the
- *                              other keeps from starting; the wait is bounded (~2 s: the affected clips come out as
- *                              NaN and iris_plan_status reports 1), never a hang.  Use TWO_KERNELS for such pipelines.
+ *                              other keeps from starting (so could a CU mask, or another process on the device).
+ *                              The wait is bounded (~2 s), never a hang, and its failure is LOUD: the affected clips come
+ *                              out as NaN, the kernel raises the plan's status word - which lives in host-visible memory -
+ *                              and the next iris_wav_to_logmel on the plan (it reads the word on entry: no
+ *                              synchronisation, no device access) enqueues nothing, switches the plan to TWO_KERNELS for
+ *                              good and returns IRIS_E_EPILOGUE_TIMEOUT: outputs of this plan since the last successful
+ *                              iris_plan_status / since that call's predecessor are suspect.  Use TWO_KERNELS from the
+ *                              start for pipelines that overlap plans.
  *   IRIS_EPILOGUE_TWO_KERNELS  fused kernel (raw mel + per-wave partials), then the min-max / log kernel.
  * IRIS_EPILOGUE=1 in the environment at plan creation selects TWO_KERNELS (test / A-B hook; so do IRIS_CHUNK_FRAMES=n,
  * frames per chunk of the fused kernel, and IRIS_MAGMEL_GENERIC - test hooks read once per plan, never per launch).
- * iris_plan_status: 0 = every bounded wait so far completed; synchronises with the device; resets the word.
+ * iris_plan_status: synchronises with the device, then 0 = every bounded wait so far completed, 1 = one gave up (the
+ * word is reset and the plan stays on TWO_KERNELS from then on).
+ * iris_plan_set_epilogue_timeout: the bound of those waits in microseconds (default 2,000,000; 0 = give up after the
+ * first sweep - the test hook that makes the failure path reachable on a healthy device).
  */
 #define IRIS_EPILOGUE_FUSED 0
 #define IRIS_EPILOGUE_TWO_KERNELS 1
 int iris_plan_set_epilogue(iris_plan* plan, int mode);
 int iris_plan_status(iris_plan* plan, int* status_out);
+int iris_plan_set_epilogue_timeout(iris_plan* plan, unsigned long long microseconds);
 
 /* Name of the fused kernel iris_wav_to_logmel launches for this plan (with / without SpecAugment bands), as rocprofv3
  * prints it without the argument list, e.g. "k_wav_to_mel<10,0,false,false,1,true>" (last flag: min-max / log epilogue inside the kernel); HOST buffer. */

@@ -90,8 +90,11 @@ def frame_signal(wav: np.ndarray, n_fft: int, hop: int) -> np.ndarray:
     if n_fft // 2 >= length:
         raise ValueError("reflect padding needs n_fft//2 < signal length")
     t = n_frames(length, hop)
-    idx = (np.arange(t)[:, None] * hop - n_fft // 2) + np.arange(n_fft)[None, :]
-    return wav[..., reflect_index(idx, length)]
+    # reflect-pad once (1-D index map), then strided windows: the same samples as wav[..., reflect_index(t*hop -
+    # n_fft/2 + n)], without a [T, n_fft] fancy index (whose result NumPy lays out index-major, i.e. strided)
+    padded = wav[..., reflect_index(np.arange(-(n_fft // 2), length + n_fft // 2), length)]
+    win = np.lib.stride_tricks.sliding_window_view(padded, n_fft, axis=-1)[..., ::hop, :]
+    return win[..., :t, :]
 
 
 def stft(wav: np.ndarray, n_fft: int = 512, hop: Optional[int] = None,
@@ -606,6 +609,61 @@ def wav_to_mel(wav: np.ndarray, n_fft: int, hop: int, n_mel: int,
     w = linear_to_mel_weight_matrix(n_mel, f, sample_rate, dtype=np.float32, **mel_kw).astype(dtype)
     mel = np.einsum('bcft,fm->bmtc', mag, w, optimize=True)
     return mel.astype(dtype)
+
+
+# --------------------------------------------------------------------------
+# the stated fp32 tolerance of the mel stage, as ONE rule for every shape and input
+# --------------------------------------------------------------------------
+MEL_REL_TOL = 1e-5        # north_star: mel magnitudes within 1e-5 relative error
+MEL_NOISE_ULPS = 4.0      # x eps(fp32) x (rms of the frame's spectrum) x (sum of the band's weights)
+
+
+def mel_tolerance(wav, n_fft, hop, n_mel, sample_rate=16000, t_bands=None, f_bands=None,
+                  rel=MEL_REL_TOL, ulps=MEL_NOISE_ULPS, **mel_kw):
+    """(ref, tol): the fp64 mel [B, M, T, C] of wav[B, C, L] and the element-wise bound an fp32 implementation is
+    held to,
+
+        |mel - ref| <= rel * |ref|  +  ulps * eps_fp32 * xrms[b, t, c] * sum_k W[k, m]
+
+    First term: north_star's 1e-5 relative error.  Second term: the absolute noise floor of ANY fp32 transform - the
+    rounding noise of an n_fft-point fp32 FFT is ~1.2 u x (rms of that frame's spectrum) on every bin, however small
+    the bin's own value (scripts/fft_error_model.py: scipy's fp32 pocketfft 1.2-1.7 u, torch.stft 1.1-1.2 u, the HIP
+    kernel's operation order 1.1-1.2 u on bins below 2 % of the rms; u = eps / 2), and a mel band passes it on
+    weighted by its filter: sum_k W[k, m].  For ordinary values the second term is a few per cent of the first; it
+    only matters where a narrow band (the reference's 80 mel over 257 bins has one-bin bands with weights ~0.1) meets
+    a bin far below the frame's level.  xrms is the rms over the frame's UNMASKED spectrum (a band zeroed by
+    SpecAugment removes signal, not rounding noise); a silent frame gives tol = 0: its mel must be exactly 0.
+    (NumPy's own float32 rfft is no yardstick for this floor: numpy 2.x evaluates it in double precision and rounds
+    the result once - its complex error equals the rounding of the fp64 result bit for bit.)"""
+    wav64 = np.asarray(wav, dtype=np.float64)
+    frames = frame_signal(wav64, n_fft, hop) * hann_periodic(n_fft, np.float64)
+    mag = np.abs(np.fft.rfft(frames, n=n_fft, axis=-1))  # [B, C, T, F] (frame-major: no transposed copy)
+    xrms = np.sqrt(np.mean(mag * mag, axis=-1))  # [B, C, T]
+    b = wav64.shape[0]
+    if t_bands is not None:
+        for i in range(b):
+            for off, size in np.asarray(t_bands[i]):
+                mag[i, :, off:off + size, :] = 0
+                xrms[i, :, off:off + size] = 0  # a masked frame is written as exact zeros
+    if f_bands is not None:
+        for i in range(b):
+            for off, size in np.asarray(f_bands[i]):
+                mag[i, :, :, off:off + size] = 0
+    w = linear_to_mel_weight_matrix(n_mel, n_fft // 2 + 1, sample_rate, dtype=np.float32, **mel_kw).astype(np.float64)
+    ref = np.einsum('bctf,fm->bmtc', mag, w, optimize=True)
+    wsum = w.sum(axis=0)  # [M]
+    eps = float(np.finfo(np.float32).eps)
+    tol = rel * np.abs(ref) + ulps * eps * wsum[None, :, None, None] * np.moveaxis(xrms, 1, -1)[:, None, :, :]
+    return ref, tol
+
+
+def mel_err_ratio(mel, ref, tol) -> float:
+    """max |mel - ref| / tol over the elements (<= 1 passes); elements with tol == 0 must be exact."""
+    d = np.abs(np.asarray(mel, np.float64) - ref)
+    zero = tol == 0
+    if np.any(d[zero] != 0):
+        return float('inf')
+    return float((d[~zero] / tol[~zero]).max()) if np.any(~zero) else 0.0
 
 
 def wav_to_logmel(wav, n_fft, hop, n_mel, sample_rate=16000, do_minmax=True,

@@ -105,6 +105,7 @@ def test_round3_entry_points_validate_before_any_launch():
     assert lib.iris_augment_draw(0, 64, 64, 2, 2, 8, 8, 7, None, None, None, None) == INVALID
     assert lib.iris_plan_set_epilogue(None, 0) == INVALID
     assert lib.iris_plan_status(None, None) == INVALID
+    assert lib.iris_plan_set_epilogue_timeout(None, 0) == INVALID
     n = C.c_int(0)
     assert lib.iris_timing_samples(None, 0, None, 0, C.byref(n)) == INVALID
     assert lib.iris_timing_enable(None, 1) == INVALID

@@ -104,6 +104,13 @@ def _fit_worker(rank, world, port, out_dir):
     ns = [torch.zeros_like(n) for _ in range(world)]
     torch.distributed.all_gather(ns, n)
     assert int(ns[0]) == int(ns[1]), ns
+    # BatchNorm running statistics: per replica during the epoch (different data per rank), averaged over the ranks at
+    # every epoch end - so after fit every rank holds, validates and (rank 0) checkpoints the same statistics
+    stats = torch.cat([b.flatten().double() for n_, b in model.named_buffers() if n_.endswith(('running_mean', 'running_var'))])
+    ss = [torch.zeros_like(stats) for _ in range(world)]
+    torch.distributed.all_gather(ss, stats)
+    assert torch.equal(ss[0], ss[1]) and float(stats.abs().sum()) > 0
+    assert os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'  # init_distributed sets the multi-process GPU environment
     v = torch.tensor([h['val_loss'] for h in hist], dtype=torch.float64)
     vs = [torch.zeros_like(v) for _ in range(world)]
     torch.distributed.all_gather(vs, v)
@@ -125,3 +132,27 @@ def test_fit_early_stopping_two_ranks_gloo(tmp_path):
     with open(tmp_path / "log.csv") as f:
         rows = list(_csv.DictReader(f))
     assert len(rows) == res[0]["epochs"] and (tmp_path / "best.pt").exists()
+
+
+def _bn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from challenge_amd import sj_train as S
+    S.init_distributed()
+    bn = torch.nn.BatchNorm1d(5)
+    bn.running_mean.fill_(float(rank + 1))
+    bn.running_var.copy_(torch.arange(5.0) + 10 * rank)
+    bn.num_batches_tracked.fill_(7 + rank)
+    S.average_bn_statistics(bn, world)
+    ok = (torch.allclose(bn.running_mean, torch.full((5,), 1.5)) and torch.allclose(bn.running_var, torch.arange(5.0) + 5.0)
+          and int(bn.num_batches_tracked) == 7 + rank)
+    torch.save({"ok": bool(ok)}, os.path.join(out_dir, f"bn{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_average_bn_statistics_two_ranks_gloo(tmp_path):
+    """running_mean / running_var become the mean over the ranks (one flattened all-reduce); counters are left alone."""
+    port = _free_port()
+    mp.spawn(_bn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(torch.load(tmp_path / f"bn{r}.pt")["ok"] for r in range(2))

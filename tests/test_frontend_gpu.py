@@ -1,7 +1,10 @@
 """GPU parity tests: the HIP frontend (through the C ABI) against the CPU oracle
 and the committed golden vectors.  Tolerances (stated, fp32):
   * spectrum: |dX| <= 2e-6 * max|X|           (same bound the oracle meets vs torch.stft)
-  * mel (before min-max/log): |d| / max(|ref|, 1e-3) <= 1e-5   (BASELINE north_star)
+  * mel (before min-max/log): ONE rule for every shape, input and seed, against the fp64 oracle
+        |d| <= 1e-5 |ref| + 4 eps_fp32 xrms[b,t,c] sum_k W[k,m]        (oracle.frontend_ref.mel_tolerance)
+    = north_star's 1e-5 relative error + the absolute noise floor of any fp32 transform (measured <= 1.9 eps for
+    this kernel, 1.1 scipy's fp32 pocketfft, 2.0 torch.stft over 50 seeds x 5 shapes: profiles/r4/hip_vs_fp64_sweep.log)
   * after min-max: abs 5e-6 on the [0,1] value, i.e. compared as exp(logmel)
 Frame/bin indexing is checked exactly with impulse inputs."""
 import os
@@ -30,6 +33,15 @@ def FE():
 
 def rel_err(a, ref, floor=1e-3):
     return float((np.abs(a - ref) / np.maximum(np.abs(ref), floor)).max())
+
+
+def assert_mel(mel, wav, n_fft, hop, n_mel, sr=16000, **kw):
+    """The stated mel tolerance (module docstring) against the fp64 oracle of `wav`; returns the worst ratio."""
+    ref, tol = R.mel_tolerance(wav, n_fft, hop, n_mel, sr, **kw)
+    assert mel.shape == ref.shape, (mel.shape, ref.shape)
+    ratio = R.mel_err_ratio(mel, ref, tol)
+    assert ratio <= 1.0, f"mel error {ratio:.3f} x the stated tolerance (n_fft {n_fft}, {n_mel} mel)"
+    return ratio
 
 
 def make_plan(g, dev, batch=1, **kw):
@@ -63,7 +75,7 @@ def test_fused_mel_matches_golden(golden_dir, dev, name):
     wav = torch.from_numpy(g["wav"][None]).to(dev)
     mel = plan.wav_to_logmel(wav, minmax=False, log=False).cpu().numpy()[0]
     assert mel.shape == g["mel"].shape
-    assert rel_err(mel, g["mel"]) <= 1e-5
+    assert_mel(mel[None], g["wav"][None], int(g["n_fft"]), int(g["hop"]), int(g["n_mel"]), float(g["sample_rate"]))
     logmel = plan.wav_to_logmel(wav).cpu().numpy()[0]
     assert np.abs(np.exp(logmel) - np.exp(g["logmel"])).max() <= 5e-6
     assert logmel.max() <= 1e-6 and abs(logmel.min() - np.log(1e-8)) <= 1e-3
@@ -79,7 +91,7 @@ def test_unfused_chain_equals_fused(golden_dir, dev, name):
     wav = torch.from_numpy(g["wav"][None]).to(dev)
     spec = plan.stft(wav)
     mel = plan.magmel(spec)
-    assert rel_err(mel.cpu().numpy()[0], g["mel"]) <= 1e-5
+    assert_mel(mel.cpu().numpy(), g["wav"][None], int(g["n_fft"]), int(g["hop"]), int(g["n_mel"]), float(g["sample_rate"]))
     magphase = FE().complex_to_magphase(spec)
     mel2 = plan.magmel(magphase, is_magphase=True)
     assert rel_err(mel2.cpu().numpy(), mel.cpu().numpy()) <= 2e-6
@@ -122,8 +134,7 @@ def test_full_band_mel_uses_upper_half_bins(dev):
         plan = FE().FrontendPlan(n_fft, hop, m, 16000, 1, 1, 6000, dev, lower_edge_hertz=20.0,
                                  upper_edge_hertz=8000.0)
         mel = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), minmax=False, log=False).cpu().numpy()
-        ref = R.wav_to_mel(wav, n_fft, hop, m, 16000, lower_edge_hertz=20.0, upper_edge_hertz=8000.0)
-        assert rel_err(mel, ref) <= 1e-5
+        assert_mel(mel, wav, n_fft, hop, m, 16000, lower_edge_hertz=20.0, upper_edge_hertz=8000.0)
 
 
 def test_batch_channels_and_many_mels(dev):
@@ -133,12 +144,12 @@ def test_batch_channels_and_many_mels(dev):
     out = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), minmax=False, log=False).cpu().numpy()
     ref = R.wav_to_mel(wav, 512, 256, 80, 16000)
     assert out.shape == ref.shape == (5, 80, 36, 2)
-    assert rel_err(out, ref) <= 1e-5
+    assert_mel(out, wav, 512, 256, 80, 16000)
     logm = plan.wav_to_logmel(torch.from_numpy(wav).to(dev)).cpu().numpy()
     assert np.abs(np.exp(logm) - np.exp(R.wav_to_logmel(wav, 512, 256, 80, 16000))).max() <= 5e-6
     plan150 = FE().FrontendPlan(1024, 256, 150, 16000, 2, 8, 9000, dev, upper_edge_hertz=7600.0)
     out = plan150.wav_to_logmel(torch.from_numpy(wav).to(dev), minmax=False, log=False).cpu().numpy()
-    assert rel_err(out, R.wav_to_mel(wav, 1024, 256, 150, 16000, upper_edge_hertz=7600.0)) <= 1e-5
+    assert_mel(out, wav, 1024, 256, 150, 16000, upper_edge_hertz=7600.0)
 
 
 def test_specaugment_bands_fused_and_unfused(dev):
@@ -158,18 +169,18 @@ def test_specaugment_bands_fused_and_unfused(dev):
     plan = FE().FrontendPlan(1024, 256, 64, 16000, 1, b, length, dev)
     x = torch.from_numpy(wav).to(dev)
     fused = plan.wav_to_logmel(x, minmax=False, log=False, t_bands=tb, f_bands=fb).cpu().numpy()
-    assert rel_err(fused, ref) <= 1e-5
+    assert_mel(fused, wav, 1024, 256, 64, 16000, t_bands=tb, f_bands=fb)
     for i in range(b):  # masked frames are exactly zero
         for off, size in tb[i]:
             assert np.all(fused[i, :, off:off + size] == 0)
     spec = plan.stft(x)
     unf = plan.magmel(spec, t_bands=torch.from_numpy(tb), f_bands=torch.from_numpy(fb)).cpu().numpy()
-    assert rel_err(unf, ref) <= 1e-5
+    assert_mel(unf, wav, 1024, 256, 64, 16000, t_bands=tb, f_bands=fb)
     # mask applied to the complex spectrum first (the reference's order) gives the same mel
     masked = spec
     masked = FE().mask_apply(masked, 2, torch.from_numpy(tb), outer_per_group=513)
     masked = FE().mask_apply(masked, 1, torch.from_numpy(fb), outer_per_group=1)
-    assert rel_err(plan.magmel(masked).cpu().numpy(), ref) <= 1e-5
+    assert_mel(plan.magmel(masked).cpu().numpy(), wav, 1024, 256, 64, 16000, t_bands=tb, f_bands=fb)
     logm = plan.wav_to_logmel(x, t_bands=tb, f_bands=fb).cpu().numpy()
     refl = R.wav_to_logmel(wav, 1024, 256, 64, 16000, t_bands=tb, f_bands=fb)
     assert np.abs(np.exp(logm) - np.exp(refl)).max() <= 5e-6
@@ -190,7 +201,7 @@ def test_normalize_flag_and_op(dev):
     # differently from the oracle's (which rounds x/rms to fp32 first): compare at 2e-6
     # of full scale instead of per-element relative error.
     assert np.abs(fused - ref).max() <= 2e-6 * np.abs(ref).max()
-    assert rel_err(fused, ref, floor=0.05) <= 1e-5
+    assert_mel(fused, ref_norm, 512, 256, 80, 16000)
 
 
 def test_minmax_log_generic(dev):
@@ -278,8 +289,7 @@ def test_bands_all_fft_sizes(dev, n_fft, hop, m, c):
     fb = np.stack([np.stack(R.mask_draw(rng, n_f, 16, 2), 1) for _ in range(b)])
     plan = FE().FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
     out = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), minmax=False, log=False, t_bands=tb, f_bands=fb)
-    ref = R.wav_to_mel(wav, n_fft, hop, m, 16000, t_bands=tb, f_bands=fb)
-    assert rel_err(out.cpu().numpy(), ref) <= 1e-5
+    assert_mel(out.cpu().numpy(), wav, n_fft, hop, m, 16000, t_bands=tb, f_bands=fb)
     full = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), t_bands=tb, f_bands=fb).cpu().numpy()
     assert np.abs(np.exp(full) - np.exp(R.wav_to_logmel(wav, n_fft, hop, m, 16000, t_bands=tb, f_bands=fb))).max() <= 5e-6
 
@@ -294,7 +304,7 @@ def test_minimal_and_odd_shapes(dev):
         out = plan.wav_to_logmel(torch.from_numpy(wav).to(dev), minmax=False, log=False).cpu().numpy()
         ref = R.wav_to_mel(wav, n_fft, hop, 32, 16000, upper_edge_hertz=7000.0)
         assert out.shape == ref.shape == (b, 32, 1 + length // hop, 1)
-        assert rel_err(out, ref) <= 1e-5
+        assert_mel(out, wav, n_fft, hop, 32, 16000, upper_edge_hertz=7000.0)
         spec = plan.stft(torch.from_numpy(wav).to(dev)).cpu().numpy()
         full = np.stack([R.to_ref_layout(R.stft(wav[i], n_fft, hop)) for i in range(b)])
         assert np.abs(spec - full).max() <= 3e-6 * np.abs(full).max()
@@ -379,22 +389,40 @@ def test_workgroups_looping_over_several_chunks(dev, monkeypatch):
         small = FE().FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
         monkeypatch.delenv("IRIS_CHUNK_FRAMES")
         x = torch.from_numpy(wav).to(dev)
-        from oracle.torch_cpu_ref import wav_to_logmel_cpu
-        w32 = torch.from_numpy(R.linear_to_mel_weight_matrix(m, n_f, 16000))
-        engine = wav_to_logmel_cpu(torch.from_numpy(wav), w32, n_fft, hop, False, False).numpy()
-        # the reference's own fp32 engine on this input (informational; bounded so that it cannot drift silently)
-        assert rel_err(engine, R.wav_to_mel(wav, n_fft, hop, m, 16000, dtype=np.float64)) <= 5e-5
         for kw in ({}, {"t_bands": tb}, {"t_bands": tb, "f_bands": fb}, {"f_bands": fb}):
             raw = small.wav_to_logmel(x, minmax=False, log=False, **kw)
             assert torch.equal(raw, ref_plan.wav_to_logmel(x, minmax=False, log=False, **kw))
-            # Against the fp64 oracle at ONE stated constant per shape: north_star's 1e-5 at n_fft 1024; 2e-5 at the
-            # n_fft 512 / 80 mel / stereo shape, whose narrow low bands sit ~1000x below the spectral peak, where an fp32
-            # transform's absolute noise floor (eps x rms of the spectrum) shows in the 1e-3-floored relative error:
-            # measured HIP values in profiles/r3/hip_vs_fp64.log.
-            ref64 = R.wav_to_mel(wav, n_fft, hop, m, 16000, dtype=np.float64, **kw)
-            assert rel_err(raw.cpu().numpy(), ref64) <= (1e-5 if n_fft == 1024 else 2e-5)
+            assert_mel(raw.cpu().numpy(), wav, n_fft, hop, m, 16000, **kw)  # the one stated rule, whatever the shape
             full = small.wav_to_logmel(x, **kw)
             assert torch.equal(full, ref_plan.wav_to_logmel(x, **kw))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_reference_default_shape_full_size(dev, seed):
+    """The reference's OWN default shape at full size - n_fft 512, hop 256 (data_utils.py:17), 80 mel over 257 bins
+    (transforms.py:51-53), stereo, batch 12 x 512 frames (sj_train.py:46,59), the six time bands + one frequency band of
+    `augment` (data_utils.py:58-61) and stft_filter(3) (sj_train.py:117) - over several seeds and input levels, held to
+    the same stated rule as every other shape (the 80-mel bank has one-bin bands with weights ~0.1: this is the shape
+    where an fp32 transform's noise floor shows, and where round 3's test carried a seed-tuned constant)."""
+    rng = np.random.default_rng(4000 + seed)
+    n_fft, hop, m, c, b, n_frame = 512, 256, 80, 2, 12, 512
+    length = (n_frame - 1) * hop
+    amp = [0.01, 0.05, 0.1, 0.3, 1.0, 2.0][seed]
+    wav = (rng.standard_normal((b, c, length)) * amp).astype(np.float32)
+    tb = np.stack([np.stack(R.mask_draw(rng, n_frame, 24, 6), 1) for _ in range(b)])
+    fb = np.stack([np.concatenate([np.stack(R.mask_draw(rng, 257, 16, 1), 1), np.array([[1, 3]], np.int32)]) for _ in range(b)])
+    plan = FE().FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
+    x = torch.from_numpy(wav).to(dev)
+    for kw in ({}, {"t_bands": tb, "f_bands": fb}):
+        mel = plan.wav_to_logmel(x, minmax=False, log=False, **kw).cpu().numpy()
+        assert mel.shape == (b, m, n_frame, c)
+        assert_mel(mel, wav, n_fft, hop, m, 16000, **kw)
+        # the unfused drop-in stages on the same input: load_wav's STFT, then complex_to_magphase + magphase_to_mel
+        unf = plan.magmel(plan.stft(x), **{k: torch.from_numpy(v) for k, v in kw.items()}).cpu().numpy()
+        assert_mel(unf, wav, n_fft, hop, m, 16000, **kw)
+        full = plan.wav_to_logmel(x, **kw).cpu().numpy()
+        ref = R.wav_to_logmel(wav, n_fft, hop, m, 16000, **kw)
+        assert np.abs(np.exp(full) - np.exp(ref)).max() <= 5e-6  # after min-max: absolute on the [0, 1] value
 
 
 @pytest.mark.parametrize("n_fft,hop,m,c,sr,b,length", [(2048, 512, 128, 2, 22050, 3, 33075),   # BASELINE configs[4] shape
@@ -414,9 +442,7 @@ def test_fp16_mfma_mel_variant(dev, n_fft, hop, m, c, sr, b, length):
     ref64 = R.wav_to_mel(wav, n_fft, hop, m, sr, dtype=np.float64)
     err = rel_err(got.cpu().numpy(), ref64)
     assert 1e-6 < err <= 2e-3, err                              # really the fp16 path (not bit-equal to fp32), within its tolerance
-    # the fp32 kernel on the same input, at its fixed constants (n_fft 512 / 80 mel / stereo: 2e-5, measured 1.52e-5 - the
-    # narrow-low-band shape of DESIGN.md section 2; the other two 1e-5, measured 1.4e-6 and 8.1e-7)
-    assert rel_err(fp32.cpu().numpy(), ref64) <= (2e-5 if n_fft == 512 else 1e-5)
+    assert_mel(fp32.cpu().numpy(), wav, n_fft, hop, m, sr)  # the fp32 kernel on the same input: the stated fp32 rule
     # min-max + log on top of it (per-wave partials from the MFMA kernel feed the same second kernel)
     full = plan.wav_to_logmel(x).cpu().numpy()
     ref = R.wav_to_logmel(wav, n_fft, hop, m, sr)
@@ -578,3 +604,48 @@ def test_fused_epilogue_plans_on_two_streams_complete(dev):
     torch.cuda.synchronize()
     assert all(p.status() == 0 for p in plans)
     assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
+
+
+def test_fused_epilogue_timeout_is_loud(dev):
+    """A fused-epilogue wait that gives up must surface as an ERROR, not as silent NaN features (advisor / VERDICT round 3).
+    The failure is forced on a healthy device with the test hook `set_epilogue_timeout(0)` (give up after the first sweep:
+    in every clip split over several workgroups, whichever workgroup finishes first finds its peers unpublished).  Then:
+    the affected clips are NaN; the status word is host-visible, so the NEXT call on the plan raises EpilogueTimeout
+    without any synchronisation having been asked for, enqueues nothing and leaves the plan on the two-kernel form, whose
+    results are right again; `raise_on_failure` / `frontend.check_plans` (what `sj_train.fit` calls once per epoch)
+    raise the same way."""
+    from challenge_amd import _native as N
+    rng = np.random.default_rng(9)
+    b, length = 8, 160000                      # 8 clips x 626 frames: every clip is split over ~32 workgroups
+    wav = (rng.standard_normal((b, 1, length)) * 0.1).astype(np.float32)
+    x = torch.from_numpy(wav).to(dev)
+    plan = FE().FrontendPlan(1024, 256, 64, 16000, 1, b, length, dev)
+    good = plan.wav_to_logmel(x).clone()
+    assert plan.status() == 0 and plan.epilogue == "fused" and torch.isfinite(good).all()
+    plan.set_epilogue_timeout(0)
+    bad = plan.wav_to_logmel(x)
+    torch.cuda.synchronize(dev)
+    assert torch.isnan(bad).any()              # chunks whose wait gave up
+    with pytest.raises(N.EpilogueTimeout):
+        plan.wav_to_logmel(x)                  # reported at the next call, nothing enqueued
+    assert plan.epilogue == "two_kernels"
+    plan.set_epilogue_timeout(2_000_000)
+    again = plan.wav_to_logmel(x)              # two-kernel form from now on: correct, and bit-identical to the fused form
+    assert torch.equal(again, good) and plan.status() == 0
+    # the explicit polls
+    plan2 = FE().FrontendPlan(1024, 256, 64, 16000, 1, b, length, dev)
+    plan2.set_epilogue_timeout(0)
+    plan2.wav_to_logmel(x)
+    with pytest.raises(N.EpilogueTimeout, match="n_fft=1024"):
+        FE().check_plans(dev)
+    FE().check_plans(dev)                      # the word was reset, the plan has fallen back
+    assert plan2.epilogue == "two_kernels" and torch.equal(plan2.wav_to_logmel(x), good)
+    # prepared launches (bench / serving loops) report it too
+    plan3 = FE().FrontendPlan(1024, 256, 64, 16000, 1, b, length, dev)
+    call = plan3.prepare(x)
+    call.launch()
+    plan3.set_epilogue_timeout(0)
+    call.launch()
+    torch.cuda.synchronize(dev)
+    with pytest.raises(N.EpilogueTimeout):
+        call.launch()

@@ -439,3 +439,141 @@ def test_model_predict_is_keras_like():
     with torch.no_grad():
         want = model(x)
     assert float((out - want).abs().max()) <= 1e-6
+
+
+# ---------------------------------------------------------------------------
+# Keras checkpoint import (sj_train.load_keras_weights): random Keras-layout arrays -> torch model, against a NumPy
+# forward written from the KERAS layer definitions (channels-last, HWIO kernels, [in, out] Dense, i-f-c-o LSTM)
+# ---------------------------------------------------------------------------
+def _keras_forward_numpy(ws, n_mels, n_frame, n_chan, x, v=9):
+    """Inference forward of define_keras_model (sj_train.py:214-255) in NumPy on x [B, M, T, C], consuming the weight
+    list in Keras' order.  float64 throughout."""
+    ws = [np.asarray(w, np.float64) for w in ws]
+    it = iter(ws)
+
+    def conv_same(x, k, b):  # Conv2D(padding='same'), stride 1: NHWC x HWIO
+        kh, kw = k.shape[:2]
+        ph, pw = kh // 2, kw // 2
+        xp = np.pad(x, ((0, 0), (ph, ph), (pw, pw), (0, 0)))
+        out = np.zeros(x.shape[:3] + (k.shape[3],))
+        for i in range(kh):
+            for j in range(kw):
+                out += np.einsum('bhwc,co->bhwo', xp[:, i:i + x.shape[1], j:j + x.shape[2], :], k[i, j])
+        return out + b
+
+    def bn(x):  # BatchNormalization in inference: epsilon 1e-3
+        g, be, mu, var = next(it), next(it), next(it), next(it)
+        return (x - mu) / np.sqrt(var + 1e-3) * g + be
+
+    def maxpool_same(x):  # MaxPooling2D((2, 2), (2, 2), 'same'): pads bottom / right
+        b, h, w, c = x.shape
+        xp = np.full((b, h + h % 2, w + w % 2, c), -np.inf)
+        xp[:, :h, :w] = x
+        return xp.reshape(b, (h + 1) // 2, 2, (w + 1) // 2, 2, c).max(axis=(2, 4))
+
+    def block(x, n):
+        for _ in range(n):
+            k, b = next(it), next(it)
+            x = np.maximum(bn(conv_same(x, k, b)), 0)
+        return maxpool_same(x)
+
+    def sigmoid(z):
+        return 1.0 / (1.0 + np.exp(-z))
+
+    def lstm(x, kernel, rec, bias, reverse):
+        b, t, _ = x.shape
+        u = rec.shape[0]
+        h, c, out = np.zeros((b, u)), np.zeros((b, u)), np.zeros((b, t, u))
+        for s in (range(t - 1, -1, -1) if reverse else range(t)):
+            z = x[:, s] @ kernel + h @ rec + bias
+            i, f, g, o = sigmoid(z[:, :u]), sigmoid(z[:, u:2 * u]), np.tanh(z[:, 2 * u:3 * u]), sigmoid(z[:, 3 * u:])
+            c = f * c + i * g
+            h = o * np.tanh(c)
+            out[:, s] = h
+        return out
+
+    def fc_bn(x):
+        k, b = next(it), next(it)
+        return np.maximum(bn(x @ k + b), 0)
+
+    x = block(np.asarray(x, np.float64), 2)
+    for _ in range(4):
+        x = block(x, 3)
+    x = np.transpose(x, (0, 2, 1, 3))                      # Permute((2, 1, 3)): [B, T', M', C]
+    x = x.reshape(x.shape[0], x.shape[1], -1)              # Reshape: m' major
+    k, b = next(it), next(it)
+    x = np.maximum(x @ k + b, 0)                           # TimeDistributed(Dense(1024, relu))
+    if v == 9:
+        x = fc_bn(x)
+    x = fc_bn(fc_bn(x))
+    if v == 9:
+        f = [next(it) for _ in range(3)]
+        r = [next(it) for _ in range(3)]
+        x = np.concatenate([lstm(x, *f, reverse=False), lstm(x, *r, reverse=True)], -1)
+    x = fc_bn(x)
+    k, b = next(it), next(it)
+    out = sigmoid(x @ k + b)
+    assert next(it, None) is None
+    return out
+
+
+@pytest.mark.parametrize("v,n_mels,n_chan", [(9, 40, 2), (1, 33, 1)])
+def test_load_keras_weights_matches_a_keras_forward(tmp_path, v, n_mels, n_chan):
+    from challenge_amd import sj_train as S
+    n_frame = 64
+    cfg = S.ARGS().get(['--v', str(v), '--n_mels', str(n_mels), '--n_frame', str(n_frame), '--n_chan', str(n_chan)])
+    model = S.get_model(cfg)
+    shapes = S.keras_weight_shapes(model)
+    assert sum(int(np.prod(sh)) for sh in shapes) == sum(p.numel() for p in model.parameters()) + \
+        sum(b.numel() for n, b in model.named_buffers() if 'running' in n) - (2 * 512 if v == 9 else 0)  # Keras has no bias_hh (2 directions x 4 x 128)
+    rng = np.random.default_rng(v)
+    ws = []
+    for i, sh in enumerate(shapes):
+        if len(sh) == 1:
+            ws.append(rng.uniform(0.5, 1.5, sh).astype(np.float32))  # gamma / beta / mean / variance (> 0) / biases
+        else:
+            fan_in = int(np.prod(sh[:-1]))
+            ws.append((rng.standard_normal(sh) / np.sqrt(fan_in)).astype(np.float32))
+    # three accepted containers: a list, np.savez(*get_weights()), the dump script's '<index>|<name>' keys
+    S.load_keras_weights(model, ws)
+    x = rng.standard_normal((2, n_mels, n_frame, n_chan)).astype(np.float32)
+    want = _keras_forward_numpy(ws, n_mels, n_frame, n_chan, x, v=v)
+    got = model.predict(torch.from_numpy(x)).numpy()
+    assert got.shape == want.shape == (2, n_frame // 32, 3)
+    assert np.abs(got - want).max() <= 1e-5, np.abs(got - want).max()
+    p1, p2 = str(tmp_path / "a.npz"), str(tmp_path / "b.npz")
+    np.savez(p1, *ws)
+    np.savez(p2, **{f"{i:04d}|layer_{i}/w:0": w for i, w in enumerate(ws)})
+    for path in (p1, p2):
+        m2 = S.get_model(cfg)
+        S.load_keras_weights(m2, path)
+        assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), model.state_dict().values()))
+    # wrong architecture / wrong shapes are refused by name
+    with pytest.raises(ValueError, match="left over|ran out"):
+        S.load_keras_weights(S.get_model(cfg), ws[:-2] if v == 9 else ws + [ws[-1]])
+    bad = list(ws)
+    bad[0] = np.transpose(bad[0], (3, 2, 0, 1))  # someone already converted to OIHW
+    with pytest.raises(ValueError, match=r"features\[0\].convs\[0\] Conv2D kernel"):
+        S.load_keras_weights(S.get_model(cfg), bad)
+
+
+def test_main_pretrain_accepts_keras_npz(tmp_path, monkeypatch):
+    """`--pretrain True` (sj_train.py:467-469): `<run name>.npz` next to where `<run name>.pt` would be is loaded."""
+    from challenge_amd import sj_train as S
+    monkeypatch.chdir(tmp_path)
+    argv = ['--v', '9', '--n_mels', '32', '--n_frame', '64', '--n_chan', '2', '--batch_size', '2', '--epochs', '0', '--synthetic',
+            '--pretrain', 'True', '--name', 'imported']
+    cfg = S.ARGS().get(argv)
+    model = S.get_model(cfg)
+    rng = np.random.default_rng(0)
+    ws = [rng.uniform(0.5, 1.5, sh).astype(np.float32) if len(sh) == 1 else (rng.standard_normal(sh) * 0.05).astype(np.float32)
+          for sh in S.keras_weight_shapes(model)]
+    np.savez(S.run_name(cfg).replace('.h5', '.npz'), *ws)
+    seen = {}
+    orig = S.load_keras_weights
+    monkeypatch.setattr(S, 'load_keras_weights', lambda m, w: seen.setdefault('model', orig(m, w)))
+    monkeypatch.setattr(S, 'make_dataset', lambda *a, **k: iter(()))
+    S.main(argv)
+    assert 'model' in seen
+    assert np.allclose(seen['model'].td.weight.detach().cpu().numpy(), ws[[i for i, sh in enumerate(S.keras_weight_shapes(model))
+                                                                      if len(sh) == 2 and sh[1] == 1024][0]].T)
