@@ -93,7 +93,8 @@ struct FusedArgs {
     // {epoch, value} granules slots[chunk][2] (agent-scope sc1 stores / loads; epoch = the plan's launch counter,
     // never 0); a wait that does not complete within ~2 s sets *status and fills the chunk with NaN
     unsigned long long* slots;
-    unsigned* status;
+    unsigned* status;  // device address of the plan's host-resident status word
+    unsigned long long timeout_ticks;
     unsigned epoch;
     int tile_off, pitch, do_minmax, do_log;
     int ablate;  // diagnostic only (IRIS_ABLATE): skip phases, results are wrong when non-zero
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
                             hi = wave_max(h2);
                             break;
                         }
-                        if (__builtin_amdgcn_s_memrealtime() - t_begin > kEpilogueTimeoutTicks) {
+                        if (__builtin_amdgcn_s_memrealtime() - t_begin >= LATE64(timeout_ticks)) {
                             failed = 1;
                             break;
                         }
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
                     red[2 * kFusedWaves + 0] = lo;
                     red[2 * kFusedWaves + 1] = hi;
                     red[2 * kFusedWaves + 2] = __uint_as_float(failed);
-                    if (failed) __hip_atomic_store((unsigned*)LATE64(status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (failed) __hip_atomic_store((unsigned*)LATE64(status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
             __syncthreads();
