@@ -139,18 +139,31 @@ __device__ __forceinline__ void dft(cf (&v)[R]) {
     }
 }
 
-// LDS padding.  DS accesses of 8 bytes are serviced in groups of 16 consecutive
-// lanes over 16 slots of 8 bytes, so an access is conflict-free when the 16 lanes
-// of a group hit 16 distinct slots (complex index mod 16).  pad(i) = i + PM*(i>>4)
-// moves whole 16-point blocks, so the unit-stride reads of a stage (16 aligned
-// consecutive points per group) stay conflict-free for any PM, and PM is chosen per
-// exchange so that the strided writes of the producing stage are conflict-free too:
-//   NS == 1 or NS >= 16 : PM = 1;   otherwise PM = 16/R (R >= 4) or NS (R == 2).
-// Every address a stage touches is pad(base) + compile-time offset (no carry into
-// the block index), i.e. one base VGPR per access pattern + immediate offsets.
-template <int PM>
-__device__ __forceinline__ constexpr int lds_pad(int i) { return i + PM * (i >> 4); }
-constexpr int stage_pm(int NS, int R) { return (NS == 1 || NS >= 16) ? 1 : (R == 2 ? NS : 16 / R); }
+// LDS padding.  pad(i) = i + PM * (i >> SH) moves whole blocks of 2^SH points, per exchange:
+//   * ds_write_b64 is serviced 16 lanes at a time over 16 slots of 8 bytes (bank = (a / 4) mod 32) and occupies its
+//     issue path for ~6 cycles whatever the LDS array does, so the strided writes of a stage want their 16 lanes on
+//     16 distinct slots (complex index mod 16);
+//   * a single ds_read_b64 is serviced 32 lanes at a time over 32 slots (bank = (a / 4) mod 64): the unit-stride reads
+//     of the next stage are conflict-free only if the 32 consecutive points of a lane group stay consecutive, i.e. no
+//     pad inside an aligned block of 32 (merged ds_read2_b64 reads are serviced like the writes, 16 at a time).
+//   NS == 1          PM 1, SH 4: the writes have stride R, a pad after every 16 points is what spreads them; a 32-lane
+//                    read group then straddles one pad (one 2-way conflict per group - no padding satisfies both sides;
+//                    brute-force search over PM <= 16, SH 3..6: scripts/microbench/lds_pad_search.py)
+//   NS >= 16         no padding: 16 consecutive lanes write 16 consecutive points, reads are contiguous
+//   R == 8, NS == 8  PM 4, SH 5: lanes b and b + 8 write 64 points apart = 2 blocks of 32 = 8 slots apart (mod 16), and
+//                    nothing is padded inside a block of 32: writes AND 32-lane reads conflict-free (PM 2, SH 4 - round
+//                    1 to 3 - left every read group with a conflict: 32 instead of 16 LDS cycles per exchange)
+//   otherwise        PM = 16 / R (R >= 4) or NS (R == 2), SH 4
+// Every address a stage touches is pad(base) + compile-time offset (no carry into the block index), i.e. one base VGPR
+// per access pattern + immediate offsets.
+struct PadCfg {
+    int pm, sh;
+};
+template <int PM, int SH = 4>
+__device__ __forceinline__ constexpr int lds_pad(int i) { return i + PM * (i >> SH); }
+constexpr PadCfg stage_pad(int NS, int R) {
+    return NS == 1 ? PadCfg{1, 4} : (NS >= 16 ? PadCfg{0, 4} : ((R == 8 && NS == 8) ? PadCfg{4, 5} : PadCfg{R == 2 ? NS : 16 / R, 4}));
+}
 constexpr int lds_padded(int n, int pm_max) { return n + pm_max * (n >> 4) + 1; }  // +1: slot NC is addressable
 
 // Orders this wave's LDS accesses for the compiler; a wave's DS instructions execute
@@ -168,7 +181,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 // exp(-2 pi i ((lane + 64u) mod NS) t / (NS R)), index u*(R-1) + t-1.
 template <int P, int R, int NS, bool LAST>
 __device__ __forceinline__ void stage_fwd(cf (&x)[P], const cf* tw, cf* lds, int lane) {
-    constexpr int U = P / R, PM = stage_pm(NS, R);
+    constexpr int U = P / R, PM = stage_pad(NS, R).pm, SH = stage_pad(NS, R).sh;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         cf v[R];
@@ -184,26 +197,26 @@ __device__ __forceinline__ void stage_fwd(cf (&x)[P], const cf* tw, cf* lds, int
             for (int t = 0; t < R; ++t) x[u + t * U] = v[t];
         } else {
             const int b = lane + kWave * u;
-            cf* wp = lds + lds_pad<PM>((b / NS) * (NS * R) + (b % NS));
+            cf* wp = lds + lds_pad<PM, SH>((b / NS) * (NS * R) + (b % NS));
 #pragma unroll
-            for (int t = 0; t < R; ++t) wp[lds_pad<PM>(t * NS)] = v[t];
+            for (int t = 0; t < R; ++t) wp[lds_pad<PM, SH>(t * NS)] = v[t];
         }
     }
 }
 
 template <int P, int R, int NS, bool SINGLE = false>
 __device__ __forceinline__ void stage_load(cf (&x)[P], const cf* lds, int lane) {
-    constexpr int PM = stage_pm(NS, R);
-    const cf* rp = lds + lds_pad<PM>(lane);
+    constexpr int PM = stage_pad(NS, R).pm, SH = stage_pad(NS, R).sh;
+    const cf* rp = lds + lds_pad<PM, SH>(lane);
     if constexpr (SINGLE) {
         // volatile: keeps one ds_read_b64 per point (2 LDS cycles per 512 B) instead of the merged
         // ds_read2_b64 (8 cycles per 1 KiB)
         const volatile lds_cf* vp = (const volatile lds_cf*)rp;
 #pragma unroll
-        for (int q = 0; q < P; ++q) x[q] = vp[lds_pad<PM>(kWave * q)];
+        for (int q = 0; q < P; ++q) x[q] = vp[lds_pad<PM, SH>(kWave * q)];
     } else {
 #pragma unroll
-        for (int q = 0; q < P; ++q) x[q] = rp[lds_pad<PM>(kWave * q)];
+        for (int q = 0; q < P; ++q) x[q] = rp[lds_pad<PM, SH>(kWave * q)];
     }
 }
 
@@ -225,7 +238,8 @@ __device__ __forceinline__ void stage_multi(cf (&x)[S][P], const cf* tw, cf* con
     }
 }
 
-// Per-size configuration: points per lane, table sizes, largest pad multiplier.
+// Per-size configuration: points per lane, table sizes, PMMAX = bound of the padded extent over all exchanges in units of
+// NC / 16 points (n_fft 1024: max(NC / 16 [PM 1, SH 4], 4 NC / 32 [PM 4, SH 5]) = 2 NC / 16).
 template <int LOG2N>
 struct FftCfg;
 
