@@ -299,6 +299,8 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                           "hipgraph": graphed, "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if world > 1 else "none", "device_ms_per_phase": breakdown,
                           "allreduce": comm},
         "bf16_autocast_opt_in": bf16,
+        # whether the c3 / c4 numbers above ran on the shipped, tuned MIOpen perf-db or on this build's own defaults
+        "miopen_db": S.miopen_db_status(),
     }
 
 

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool_nchw(const float* x, con
 // channels-last convolution output z [rows = N H W, C] (the convolution itself stays MIOpen; its bias is NOT added by a
 // separate pass: batch normalisation subtracts the batch mean, so y does not depend on the bias - it only shifts the
 // running mean, which is accounted for here - and its gradient is identically zero):
-//   forward   k_bn_stats        per-channel sum, sum of squares of z (fp32 per thread over <= 32 rows, fp64 atomics per block)
+//   forward   k_bn_stats        per-channel sum, sum of squares of z - K, K = row 0 of the channel (fp32 per thread over <= 32 rows, fp64 atomics per block)
 //             k_bn_relu_apply   y = max(gamma (z - mean) rstd + beta, 0); block 0 updates the running statistics
 //   backward  k_bn_reduce<true>      g = dy [y > 0]; sum g, sum g xhat per channel (same reduction scheme)
 //             k_bn_relu_bwd_dx       dz = gamma rstd (g - sum_g / M - xhat sum_gx / M); block 0 writes dgamma, dbeta
@@ -393,6 +393,12 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float* z, const float* 
         const int c = c0 + tx;
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
         float4 mu = s0, rs = s0, sc = s0, sh = s0;
+        // forward statistics are SHIFTED sums, sum (z - K) and sum (z - K)^2 with K = the channel's value in row 0 (the same K
+        // in every block; the consumers read it back from z): E[z^2] - E[z]^2 on raw fp32 partial sums loses the variance of
+        // a channel whose |mean| is far above its spread (clamped to 0: rstd = 1 / sqrt(eps)); shifted, the partial sums are
+        // of the size of the spread itself
+        float4 kz = s0;
+        if (!BWD && c < C4) kz = z4[c];
         if (BWD && c < C4) {
             mu = reinterpret_cast<const float4*>(mean)[c];
             rs = reinterpret_cast<const float4*>(rstd)[c];
@@ -406,8 +412,9 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float* z, const float* 
             for (size_t r = r_begin + ty; r < r_end; r += tys) {
                 const float4 v = z4[r * C4 + c];
                 if constexpr (!BWD) {
-                    s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-                    s1.x = fmaf(v.x, v.x, s1.x); s1.y = fmaf(v.y, v.y, s1.y); s1.z = fmaf(v.z, v.z, s1.z); s1.w = fmaf(v.w, v.w, s1.w);
+                    const float ux = v.x - kz.x, uy = v.y - kz.y, uz = v.z - kz.z, uw = v.w - kz.w;
+                    s0.x += ux; s0.y += uy; s0.z += uz; s0.w += uw;
+                    s1.x = fmaf(ux, ux, s1.x); s1.y = fmaf(uy, uy, s1.y); s1.z = fmaf(uz, uz, s1.z); s1.w = fmaf(uw, uw, s1.w);
                 } else {
                     const float4 d = d4[r * C4 + c];
                     const float gx = fmaf(v.x, sc.x, sh.x) > 0.f ? d.x : 0.f, gy = fmaf(v.y, sc.y, sh.y) > 0.f ? d.y : 0.f;
@@ -445,7 +452,9 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* z, float* y,
     extern __shared__ float coef[];  // [2][C]: scale = gamma rstd, shift = beta - mean scale  (y = max(z scale + shift, 0))
     const int C = 4 * C4;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double m = bn_sum(sums, C, c) * inv_m, var = fmax(bn_sum(sums, C, C + c) * inv_m - m * m, 0.0);
+        // sums are of (z - K), K = z[row 0][c] (k_bn_reduce): mean = K + E[z - K], var = E[(z - K)^2] - E[z - K]^2
+        const double ms = bn_sum(sums, C, c) * inv_m, var = fmax(bn_sum(sums, C, C + c) * inv_m - ms * ms, 0.0);
+        const double m = (double)z[c] + ms;
         const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
         coef[c] = gamma[c] * rs;
         coef[C + c] = beta[c] - mu * (gamma[c] * rs);
@@ -542,7 +551,9 @@ __global__ __launch_bounds__(256) void k_bn_relu_pool_apply(const float* z, floa
     extern __shared__ float coef[];  // [2][C], formed exactly as k_bn_relu_apply forms them
     const int C = 4 * C4;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double m = bn_sum(sums, C, c) * inv_m, var = fmax(bn_sum(sums, C, C + c) * inv_m - m * m, 0.0);
+        // sums are of (z - K), K = z[row 0][c] (k_bn_reduce): mean = K + E[z - K], var = E[(z - K)^2] - E[z - K]^2
+        const double ms = bn_sum(sums, C, c) * inv_m, var = fmax(bn_sum(sums, C, C + c) * inv_m - ms * ms, 0.0);
+        const double m = (double)z[c] + ms;
         const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
         coef[c] = gamma[c] * rs;
         coef[C + c] = beta[c] - mu * (gamma[c] * rs);

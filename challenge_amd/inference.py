@@ -85,8 +85,9 @@ def features_for_eval(spec: torch.Tensor, config) -> torch.Tensor:
 
 @torch.no_grad()
 def predict_frames(model, features: torch.Tensor, config, overlap_hop: int = 512, batch_size: int = 32,
-                   smoothing: bool = True) -> torch.Tensor:
-    """features [M, T, C'] -> thresholded frame predictions [T, K] (metrics.py:56-81).
+                   smoothing: bool = True, threshold: bool = True) -> torch.Tensor:
+    """features [M, T, C'] -> thresholded frame predictions [T, K] (metrics.py:56-81); `threshold=False` returns the
+    averaged (and smoothed) probabilities the reference thresholds at 0.5 (metrics.py:81) instead.
     (For repeated evaluation pass `sj_train.InferenceEngine(model)` instead of the model: the same function with the
     eval-mode BatchNorms folded away and the HIP epilogues / LSTM launch, 1.4x the module's rate; or
     `sj_train.fold_batchnorm(model)` for the folding alone.)"""
@@ -106,7 +107,7 @@ def predict_frames(model, features: torch.Tensor, config, overlap_hop: int = 512
     preds = preds.t()
     if smoothing:
         preds = smooth(preds)
-    return (preds >= 0.5).to(torch.float32)
+    return (preds >= 0.5).to(torch.float32) if threshold else preds
 
 
 def evaluate_wav(model, wav, config, sample_rate: int = 16000, overlap_hop: int = 512, device=None) -> torch.Tensor:

@@ -1457,6 +1457,35 @@ def distributed_env(env=None):
     return env
 
 
+def miopen_db_status() -> str:
+    """Did MIOpen pick up the shipped perf-db / find-db (`_use_shipped_miopen_db`)?  Call AFTER the model's convolutions have
+    run once.  The files are keyed by MIOpen's build string and the GPU (arch + CU count) in their NAMES: a matching MIOpen
+    reads and appends to the shipped names, any other build ignores them and - having had to search - writes files under its
+    own name next to them.  'used' / 'ignored: ...' / 'off: ...' (bench.py records it as extra.miopen_db: the tuned db is
+    worth 13.7 vs 15.1 ms per training step, so a line must say which of the two it measured)."""
+    path = os.environ.get("MIOPEN_USER_DB_PATH")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+    if os.environ.get("IRIS_MIOPEN_DB", "1") == "0":
+        return "off: IRIS_MIOPEN_DB=0"
+    try:
+        shipped = {f for f in os.listdir(src) if f.endswith("db.txt")}
+    except OSError:
+        shipped = set()
+    if not path or not shipped:
+        return "off: no shipped db in use"
+    if not (os.path.basename(os.path.dirname(path)) == "_run" or os.path.basename(path).startswith("iris_miopen_db_")):
+        return "off: MIOPEN_USER_DB_PATH set by the user"
+    try:
+        present = {f for f in os.listdir(path) if f.endswith("db.txt")}
+    except OSError:
+        return "off: " + path + " unreadable"
+    foreign = sorted(present - shipped)
+    if foreign:
+        return ("ignored: this MIOpen build wrote " + ", ".join(foreign[:2]) + " - its build string / GPU differs from the shipped "
+                + sorted(shipped)[-1])
+    return "used"
+
+
 def init_distributed():
     """One process per GPU (torchrun): returns (rank, world, device).  Backend 'nccl' is
     RCCL on ROCm; 'gloo' on CPU-only hosts (tests)."""

@@ -277,8 +277,9 @@ int iris_bias_relu_maxpool(const float* x, const float* bias, float* y, int batc
  * batch normalisation removes the batch mean, so the output does not depend on the bias - it only shifts the running
  * mean (conv_bias, nullable, is added there) - and the bias gradient is identically zero.
  *   forward : iris_bn_stats (sums_zeroed: DEVICE double [iris_bn_sums_len(channels)], zero on entry: per-channel sum and sum
- *             of squares, spread over several copies so that the blocks' atomics do not queue on one address; the
- *             consumers below add the copies up)
+ *             of squares of z - K, K = the channel's value in row 0 of z - shifted sums, so that a channel whose |mean| is
+ *             far above its spread keeps its variance; spread over several copies so that the blocks' atomics do not queue
+ *             on one address; the consumers below add the copies up and read K back from z)
  *             iris_bn_relu_apply: y = max(gamma (z - mean) rstd + beta, 0), biased variance; running_mean / running_var
  *             updated in place ((1 - momentum) old + momentum new, unbiased variance); save_mean / save_rstd [channels] out
  *   backward: iris_bn_relu_bwd_reduce (sums_zeroed, same length: sum g, sum g xhat with g = dy [y > 0]; the mask is

@@ -382,13 +382,23 @@ def test_configure_miopen_points_at_a_copy_of_the_shipped_db(monkeypatch):
     for f in files:
         assert open(os.path.join(dst, f), "rb").read() == open(os.path.join(shipped, f), "rb").read()
     assert os.environ["MIOPEN_FIND_MODE"] == "NORMAL"
+    # miopen_db_status: 'used' while MIOpen only touches the shipped names, 'ignored' once a different MIOpen build has
+    # written db files under its own build string next to them
+    assert S.miopen_db_status() == "used"
+    foreign = os.path.join(dst, "gfx950100.HIP.9_9_9_deadbeef.ufdb.txt")
+    open(foreign, "w").write("x")
+    try:
+        assert S.miopen_db_status().startswith("ignored: this MIOpen build wrote gfx950100.HIP.9_9_9_deadbeef.ufdb.txt")
+    finally:
+        os.remove(foreign)
     monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")   # the user's choice wins
     S.configure_miopen()
     assert os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
+    assert S.miopen_db_status().startswith("off: MIOPEN_USER_DB_PATH")
     monkeypatch.delenv("MIOPEN_USER_DB_PATH")
     monkeypatch.setenv("IRIS_MIOPEN_DB", "0")
     S.configure_miopen()
-    assert "MIOPEN_USER_DB_PATH" not in os.environ
+    assert "MIOPEN_USER_DB_PATH" not in os.environ and S.miopen_db_status() == "off: IRIS_MIOPEN_DB=0"
     monkeypatch.delenv("MIOPEN_FIND_MODE", raising=False)
 
 
