@@ -149,7 +149,7 @@ __device__ __forceinline__ void dft(cf (&v)[R]) {
 //   NS == 1          PM 1, SH 4: the writes have stride R, a pad after every 16 points is what spreads them; a 32-lane
 //                    read group then straddles one pad (one 2-way conflict per group - no padding satisfies both sides;
 //                    brute-force search over PM <= 16, SH 3..6: scripts/microbench/lds_pad_search.py)
-//   NS >= 16         no padding: 16 consecutive lanes write 16 consecutive points, reads are contiguous
+//   NS >= 16         PM 1, SH 4 (16 consecutive lanes write 16 consecutive points: any block pad works)
 //   R == 8, NS == 8  PM 4, SH 5: lanes b and b + 8 write 64 points apart = 2 blocks of 32 = 8 slots apart (mod 16), and
 //                    nothing is padded inside a block of 32: writes AND 32-lane reads conflict-free (PM 2, SH 4 - round
 //                    1 to 3 - left every read group with a conflict: 32 instead of 16 LDS cycles per exchange)
@@ -162,8 +162,14 @@ struct PadCfg {
 template <int PM, int SH = 4>
 __device__ __forceinline__ constexpr int lds_pad(int i) { return i + PM * (i >> SH); }
 constexpr PadCfg stage_pad(int NS, int R) {
-    return NS == 1 ? PadCfg{1, 4} : (NS >= 16 ? PadCfg{0, 4} : ((R == 8 && NS == 8) ? PadCfg{4, 5} : PadCfg{R == 2 ? NS : 16 / R, 4}));
+    // (NS >= 16 could go unpadded, but only n_fft 1024 reads with single ds_read_b64 - every other size uses the merged reads,
+    // which are serviced 16 lanes at a time and have no conflict to lose - and at n_fft 2048 the unpadded form cost the
+    // 168-register variant 20 bytes of scratch: those exchanges keep PM 1)
+    return (NS == 1 || NS >= 16) ? PadCfg{1, 4} : ((R == 8 && NS == 8) ? PadCfg{4, 5} : PadCfg{R == 2 ? NS : 16 / R, 4});
 }
+// the untangle exchange (unit-stride writes, reversed unit-stride reads): unpadded where the reads are single ds_read_b64
+// (32 lanes read 32 consecutive points downwards = 32 distinct slots), PM 1 elsewhere (as rounds 1 to 3)
+constexpr int untangle_pm(int log2n) { return log2n == IRIS_SINGLE_READS_LOG2N ? 0 : 1; }
 constexpr int lds_padded(int n, int pm_max) { return n + pm_max * (n >> 4) + 1; }  // +1: slot NC is addressable
 
 // Orders this wave's LDS accesses for the compiler; a wave's DS instructions execute

@@ -303,7 +303,27 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
         }
     };
     int f[S], fn[S];  // frames in registers / frames in flight to the landing buffers
-    if (g0 < a.n_chunks) {  // first frames of the first chunk: in flight while the constants are fetched
+    // The constant block is REQUESTED before the first frames (round 4): a wave's loads return in order, so with the frames
+    // requested first the L2-resident constants could only be staged once the frames' HBM round trip had completed (the
+    // staging loop's wait read vmcnt(0)), and the 0.6 us of LDS reads behind the barrier started from there.  Requested
+    // first they are staged and read while the frames are still on their way (the wait in front of the LDS stores leaves the
+    // frame loads outstanding).  (Round 2's IRIS_CONSTS_FIRST experiment reordered the source lines only and measured
+    // "equal": the compiler had kept vmcnt(0).)
+#ifndef IRIS_CONSTS_FIRST
+#define IRIS_CONSTS_FIRST 1
+#endif
+    // The staging itself is LDS-DMA (global_load_lds_dwordx4 from inline asm, one 1-KiB row of the block per instruction,
+    // rows w, w + W, ... by wave w): no registers, nothing for the compiler's wait-count pass to be conservative about -
+    // for loads it knows it merges the interior / edge paths of the frame loads and falls back to vmcnt(0), which drains
+    // the frames too.  The wait is set by hand below: vmcnt(P) once a wave has frame loads behind its rows (at most P
+    // of them may stay outstanding: the rows are older and land first), vmcnt(0) for a wave without a frame.
+    constexpr bool kConstsFirst = IRIS_CONSTS_FIRST && DIRECT;
+    if constexpr (kConstsFirst) {
+        const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+        for (int v = wv; v < ConstLayout<LOG2N>::NV4; v += kFusedWaves)  // wave-uniform
+            dma_frame_x4<8>(a.consts + v * (kWave * 4), stage_lds + (unsigned)v * (kWave * 16u), (unsigned)lane * 16u);
+    }
+    if (g0 < a.n_chunks) {  // first frames of the first chunk: in flight while the constants are staged and read
         const int b = chunk_clip(g0);
 #pragma unroll
         for (int st = 0; st < S; ++st) f[st] = wv * S + st;
@@ -318,7 +338,13 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
         static_assert(!DIRECT || kLandBytes >= kStageBytes, "constant block does not fit the landing area");
         float4* stage = reinterpret_cast<float4*>(DIRECT ? smem : xbuf0);
         const float4* g = reinterpret_cast<const float4*>(a.consts);
-        for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
+        if constexpr (kConstsFirst) {
+            const bool has_frame = g0 < a.n_chunks && wv * S < chunk_nt(g0, chunk_clip(g0)) * a.C && !ABL(8);  // wave-uniform
+            if (has_frame) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            for (int i = threadIdx.x; i < ConstLayout<LOG2N>::NV4 * kWave; i += blockDim.x) stage[i] = g[i];
+        }
         if (threadIdx.x == 0) *next_frame = 2 * kFusedWaves * S;
         if constexpr (BANDS) {
             if (a.t_bands && g0 < a.n_chunks) {

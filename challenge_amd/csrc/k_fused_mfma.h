@@ -28,14 +28,14 @@ template <int LOG2N>
 __device__ __forceinline__ void untangle_mag_half(const cf (&x)[FftCfg<LOG2N>::P], const cf* post, cf* lds, _Float16* row,
                                                   int kb_pad, int lane) {
     constexpr int P = FftCfg<LOG2N>::P;
-    cf* wp = lds + lds_pad<0>(lane);
+    cf* wp = lds + lds_pad<untangle_pm(LOG2N)>(lane);
 #pragma unroll
-    for (int q = P / 2; q < P; ++q) wp[lds_pad<0>(kWave * q)] = x[q];
+    for (int q = P / 2; q < P; ++q) wp[lds_pad<untangle_pm(LOG2N)>(kWave * q)] = x[q];
     wave_sync_lds();
-    const cf* rp = lds + lds_pad<0>(kWave - lane);
+    const cf* rp = lds + lds_pad<untangle_pm(LOG2N)>(kWave - lane);
     cf zp[P / 2];
 #pragma unroll
-    for (int q = 0; q < P / 2; ++q) zp[q] = rp[lds_pad<0>(kWave * (P - 1 - q))];
+    for (int q = 0; q < P / 2; ++q) zp[q] = rp[lds_pad<untangle_pm(LOG2N)>(kWave * (P - 1 - q))];
     if (lane == 0) zp[0] = x[0];  // k = 0 pairs with itself
 #pragma unroll
     for (int q = 0; q < P / 2; ++q) {

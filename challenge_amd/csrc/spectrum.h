@@ -39,19 +39,19 @@ __device__ __forceinline__ void untangle_multi(const cf (&x)[S][FftCfg<LOG2N>::P
     // rows P/2 .. P-1 (lane 0 reads row P - q, lane 0): only the upper half is ever fetched
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        cf* wp = lds[s] + lds_pad<0>(lane);
+        cf* wp = lds[s] + lds_pad<untangle_pm(LOG2N)>(lane);
 #pragma unroll
-        for (int q = P / 2; q < P; ++q) wp[lds_pad<0>(kWave * q)] = x[s][q];
+        for (int q = P / 2; q < P; ++q) wp[lds_pad<untangle_pm(LOG2N)>(kWave * q)] = x[s][q];
     }
     wave_sync_lds();
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         // lane 0, q 0 pairs with itself (slot NC is addressable but unused)
-        const cf* rp = lds[s] + lds_pad<0>(kWave - lane);
+        const cf* rp = lds[s] + lds_pad<untangle_pm(LOG2N)>(kWave - lane);
 #pragma unroll
         for (int q = 0; q < P / 2; ++q) {
             const cf zk = x[s][q];
-            cf zp = rp[lds_pad<0>(kWave * (P - 1 - q))];
+            cf zp = rp[lds_pad<untangle_pm(LOG2N)>(kWave * (P - 1 - q))];
             if (q == 0 && lane == 0) zp = zk;
             const cf zc = mk(zp.x, -zp.y);  // conj(Z[NC-k])
             cf e = zk + zc;                 // 2 E
@@ -97,19 +97,19 @@ template <int LOG2N, bool HI, int S>
 __device__ __forceinline__ void untangle_mag(const cf (&x)[S][FftCfg<LOG2N>::P], const cf* post, cf* const (&lds)[S],
                                              float* const (&mag)[S], int lane) {
     constexpr int P = FftCfg<LOG2N>::P, NC = (1 << LOG2N) / 2;
-    static_assert(8 * lds_pad<0>(NC / 2 + 1) >= 4 * (NC + 1), "magnitudes would overwrite partner rows");
+    static_assert(8 * lds_pad<untangle_pm(LOG2N)>(NC / 2 + 1) >= 4 * (NC + 1), "magnitudes would overwrite partner rows");
 #if !IRIS_NO_UNTANGLE_X
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        cf* wp = lds[s] + lds_pad<0>(lane);
+        cf* wp = lds[s] + lds_pad<untangle_pm(LOG2N)>(lane);
 #pragma unroll
-        for (int q = P / 2; q < P; ++q) wp[lds_pad<0>(kWave * q)] = x[s][q];
+        for (int q = P / 2; q < P; ++q) wp[lds_pad<untangle_pm(LOG2N)>(kWave * q)] = x[s][q];
     }
     wave_sync_lds();
 #endif
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        const cf* rp = lds[s] + lds_pad<0>(kWave - lane);
+        const cf* rp = lds[s] + lds_pad<untangle_pm(LOG2N)>(kWave - lane);
         cf zp[P / 2];
 #if IRIS_NO_UNTANGLE_X
         (void)rp;
@@ -119,10 +119,10 @@ __device__ __forceinline__ void untangle_mag(const cf (&x)[S][FftCfg<LOG2N>::P],
         if constexpr (LOG2N == IRIS_SINGLE_READS_LOG2N) {
             const volatile lds_cf* vp = (const volatile lds_cf*)rp;
 #pragma unroll
-            for (int q = 0; q < P / 2; ++q) zp[q] = vp[lds_pad<0>(kWave * (P - 1 - q))];
+            for (int q = 0; q < P / 2; ++q) zp[q] = vp[lds_pad<untangle_pm(LOG2N)>(kWave * (P - 1 - q))];
         } else {
 #pragma unroll
-            for (int q = 0; q < P / 2; ++q) zp[q] = rp[lds_pad<0>(kWave * (P - 1 - q))];
+            for (int q = 0; q < P / 2; ++q) zp[q] = rp[lds_pad<untangle_pm(LOG2N)>(kWave * (P - 1 - q))];
         }
 #endif
         if (lane == 0) zp[0] = x[s][0];  // k = 0 pairs with itself
