@@ -199,6 +199,26 @@ __device__ __forceinline__ unsigned long long late_arg64(unsigned offset) {
                  : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "s"(offset) : "memory");
     return v;
 }
+// The epilogue's arguments in ONE round trip to the scalar cache (five separate late loads, each with its own wait, stood
+// on the critical path between a workgroup's last frame and its publication / write-out: ~0.1 us each)
+struct LateEpilogueArgs {
+    unsigned long long out, slots;
+    unsigned epoch, do_minmax, do_log;
+};
+template <unsigned OFF_OUT, unsigned OFF_SLOTS, unsigned OFF_EPOCH, unsigned OFF_MM, unsigned OFF_LG>
+__device__ __forceinline__ LateEpilogueArgs late_epilogue_args() {
+    LateEpilogueArgs r;
+    asm volatile("s_load_dwordx2 %0, %5, %6\n\t"
+                 "s_load_dwordx2 %1, %5, %7\n\t"
+                 "s_load_dword %2, %5, %8\n\t"
+                 "s_load_dword %3, %5, %9\n\t"
+                 "s_load_dword %4, %5, %10\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(r.out), "=&s"(r.slots), "=&s"(r.epoch), "=&s"(r.do_minmax), "=&s"(r.do_log)
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFF_OUT), "n"(OFF_SLOTS), "n"(OFF_EPOCH), "n"(OFF_MM), "n"(OFF_LG)
+                 : "memory");
+    return r;
+}
 #define LATE32(field) late_arg32((unsigned)offsetof(FusedArgs, field))
 #define LATE64(field) late_arg64((unsigned)offsetof(FusedArgs, field))
 constexpr unsigned long long kEpilogueTimeoutTicks = 200000000ull;  // s_memrealtime runs at 100 MHz: 2 s
@@ -688,6 +708,9 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
             float* red = tile + (size_t)a.M * a.pitch;  // [2 * waves + 4]
             int le = lane;  // epilogue lane index, hidden from loop-invariant code motion: per-lane addresses of the
             asm volatile("" : "+v"(le));  // epilogue must not be hoisted across the frame loop (they would spill there)
+            const LateEpilogueArgs late = late_epilogue_args<(unsigned)offsetof(FusedArgs, out), (unsigned)offsetof(FusedArgs, slots),
+                                                             (unsigned)offsetof(FusedArgs, epoch), (unsigned)offsetof(FusedArgs, do_minmax),
+                                                             (unsigned)offsetof(FusedArgs, do_log)>();
             if (lane == 0) {
                 red[wv] = mn;
                 red[kFusedWaves + wv] = mx;
@@ -699,9 +722,9 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
                 lo = wave_min(lo);
                 hi = wave_max(hi);
                 unsigned failed = 0;
-                if (LATE32(do_minmax) && a.chunks_per_clip > 1) {
-                    gu64* slots = (gu64*)LATE64(slots) + 2 * (size_t)b * a.chunks_per_clip;
-                    const unsigned epoch = LATE32(epoch);
+                if (late.do_minmax && a.chunks_per_clip > 1) {
+                    gu64* slots = (gu64*)late.slots + 2 * (size_t)b * a.chunks_per_clip;
+                    const unsigned epoch = late.epoch;
                     const unsigned long long tag = (unsigned long long)epoch << 32;
                     if (lane == 0) {
                         const int ci = chunk - b * a.chunks_per_clip;
@@ -743,33 +766,42 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
             const float cmn = red[2 * kFusedWaves], cmx = red[2 * kFusedWaves + 1];
             const bool failed = __float_as_uint(red[2 * kFusedWaves + 2]) != 0;
             const float inv = 1.0f / fmaxf(cmx - cmn, 1e-8f);
-            const int mm = (int)LATE32(do_minmax), lg = (int)LATE32(do_log);
+            const int mm = (int)late.do_minmax, lg = (int)late.do_log;
             const unsigned rowpitch_e = (unsigned)a.T * (unsigned)a.C * 4u;
-            float* const out_e = (float*)LATE64(out) + ((size_t)b * a.M * a.T + t0) * a.C;
-            // wave w owns rows w, w + W, ... of the tile and walks them as ONE flat run of (rows x nwf) elements, 64 at a
-            // time, so that no lane idles on a row's ragged tail (79 columns = 64 + 15); (row, column) advance without a
-            // division: 64 = q nwf + r
+            float* const out_e = (float*)late.out + ((size_t)b * a.M * a.T + t0) * a.C;
+            // Write-out: wave w owns rows w, w + W, ... of the tile and walks them row by row, 64 columns at a time, with every
+            // address formed on the SCALAR unit (row base in an SGPR pair, lane offset = 4 lane): 8 vector instructions per trip.
+            // All waves of the CU run this phase at the same time, so it is bound by vector ISSUE: the round-3 form (one flat
+            // run over the wave's elements: 5 trips instead of 8 for 79 columns, but ~35 vector instructions per trip for the
+            // (row, column) walk, a 32-bit multiply and the selects, plus an integer division up front) cost as many issue
+            // slots as a whole frame's transform.
             int we = wv;  // the wave index, hidden from loop-invariant code motion like `le` (row offsets would otherwise be
             asm volatile("" : "+s"(we));  // precomputed into scalar registers that the frame loop has none to spare for)
-            const int rows_w = (a.M - we + kFusedWaves - 1) / kFusedWaves;
-            const int total = rows_w * nwf, q64 = kWave / nwf, r64 = kWave - q64 * nwf;
-            int jr = le / nwf, f0 = le - jr * nwf;
-            // software-pipelined by one element: the next LDS read is in flight behind this element's math and store
-            unsigned m = (unsigned)(we + jr * kFusedWaves);
-            float cur = le < total ? tile[__umul24(m, (unsigned)a.pitch) + f0] : 0.f;
-            for (int e = le; e < total; e += kWave) {
-                const unsigned off = m * rowpitch_e + (unsigned)f0 * 4u;  // byte offset m * row pitch + 4 f0 < 2^32 (host check)
-                f0 += r64;
-                jr += q64;
-                if (f0 >= nwf) {
-                    f0 -= nwf;
-                    ++jr;
+            const unsigned l4 = (unsigned)le * 4u;
+            const float* trow = tile + (size_t)we * a.pitch;   // uniform (LDS)
+            const char* grow = reinterpret_cast<const char*>(out_e) + (size_t)we * rowpitch_e;  // uniform
+            int wstep = kFusedWaves;  // laundered like `we`: the two row strides below are chunk-invariant and would otherwise be
+            asm volatile("" : "+s"(wstep));  // hoisted into scalar registers that live across the frame loop
+            const size_t tstep = (size_t)wstep * a.pitch, gstep = (size_t)wstep * rowpitch_e;
+            int m = we, c0 = 0;
+            // software-pipelined by one trip: the next LDS read is in flight behind this trip's math and store
+            float cur = (m < a.M && le < nwf) ? trow[le] : 0.f;
+            while (m < a.M) {  // uniform
+                const bool act = c0 + le < nwf;
+                const char* gdst = grow + (size_t)c0 * 4;
+                c0 += kWave;
+                if (c0 >= nwf) {
+                    c0 = 0;
+                    m += kFusedWaves;
+                    trow += tstep;
+                    grow += gstep;
                 }
-                m = (unsigned)(we + jr * kFusedWaves);
-                const float nxt = e + kWave < total ? tile[__umul24(m, (unsigned)a.pitch) + f0] : 0.f;
-                float y = minmax_log_value(cur, cmn, inv, mm, lg, 1e-8f);
+                const float nxt = (m < a.M && c0 + le < nwf) ? trow[c0 + le] : 0.f;
+                float y = cur;
+                if (mm) y = (y - cmn) * inv;                                   // uniform branches: the flags are scalars
+                if (lg) y = __builtin_amdgcn_logf(y + 1e-8f) * 0.69314718055994530942f;   // = minmax_log_value, same bits
                 if (failed) y = NAN;
-                asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(y), "s"(out_e) : "memory");
+                if (act) asm volatile("global_store_dword %0, %1, %2" ::"v"(l4), "v"(y), "s"(gdst) : "memory");
                 cur = nxt;
             }
         }
