@@ -67,10 +67,27 @@ __global__ __launch_bounds__(64 * stft_waves(LOG2N), stft_waves(LOG2N) * stft_wg
         load_frame<LOG2N>(x, a.wav + ((size_t)b * a.C + c) * a.L, a.L, (t0 + tl) * a.hop - N / 2, lane);
     };
 
+    // Walk order of a chunk's tiles (round 4): chunks with an ODD index inside their clip walk their tiles BACKWARDS.  The
+    // layout's row pitch (T 2C floats) is in general no multiple of the 128-byte line, so a run of a row starts and ends
+    // inside a line, and the line at a chunk edge is completed by the NEIGHBOURING chunk's workgroup.  With every chunk
+    // walking forwards the two halves of that line were written a whole chunk time apart (the first tile of chunk k + 1 at
+    // the start of the kernel, the last tile of chunk k at its end): the half-written line left the L2 in between and went to
+    // HBM as a masked write - twice.  With alternating directions both neighbours of an edge reach it at the same end of
+    // their walk (an even number of chunks per clip also pairs a row's end with the next row's start), so the halves meet in
+    // the clip's L2 (a clip's chunks share an XCD) - no transform is recomputed, no data exchanged.
+    // step i of a chunk of c_nt frames -> (first frame offset inside the chunk, frames)
+    auto tile_of = [&](int i, int c_nt, bool backward, int& tt, int& nt) {
+        const int n_tiles = (c_nt + a.tile_frames - 1) / a.tile_frames;
+        const int k = backward ? n_tiles - 1 - i : i;
+        tt = k * a.tile_frames;
+        nt = min(a.tile_frames, c_nt - tt);
+    };
     const int g0 = xcd_remap(blockIdx.x, gridDim.x);
     if (g0 < a.n_chunks) {  // first frame: in flight while the constants are fetched
         const int b = chunk_clip(g0);
-        if (wv < min(chunk_nt(g0, b), a.tile_frames) * a.C) fetch(b, chunk_t0(g0, b), wv);
+        int tt, nt;
+        tile_of(0, chunk_nt(g0, b), ((g0 - b * a.chunks_per_clip) & 1) != 0, tt, nt);
+        if (wv < nt * a.C) fetch(b, chunk_t0(g0, b) + tt, wv);
     }
     cf tw[NTW], post[P / 2], win[P];
     {
@@ -89,9 +106,17 @@ __global__ __launch_bounds__(64 * stft_waves(LOG2N), stft_waves(LOG2N) * stft_wg
     for (int chunk = g0; chunk < a.n_chunks; chunk += gridDim.x) {
       const int b = chunk_clip(chunk);
       const int c_t0 = chunk_t0(chunk, b), c_nt = chunk_nt(chunk, b);
-      if (chunk != g0 && wv < min(c_nt, a.tile_frames) * a.C) fetch(b, c_t0, wv);
-      for (int tt = 0; tt < c_nt; tt += a.tile_frames) {
-        const int t0 = c_t0 + tt, nt = min(a.tile_frames, c_nt - tt);
+      const bool backward = ((chunk - b * a.chunks_per_clip) & 1) != 0;
+      const int n_tiles = (c_nt + a.tile_frames - 1) / a.tile_frames;
+      if (chunk != g0) {
+          int tt0, nt0;
+          tile_of(0, c_nt, backward, tt0, nt0);
+          if (wv < nt0 * a.C) fetch(b, c_t0 + tt0, wv);
+      }
+      for (int ti = 0; ti < n_tiles; ++ti) {
+        int tt, nt;
+        tile_of(ti, c_nt, backward, tt, nt);
+        const int t0 = c_t0 + tt;
         const int nwf = nt * a.C;
         for (int f = wv; f < nwf; f += W) {
 #pragma unroll
@@ -102,8 +127,13 @@ __global__ __launch_bounds__(64 * stft_waves(LOG2N), stft_waves(LOG2N) * stft_wg
             const cf mid = mk(x[P / 2].x, -x[P / 2].y);  // X[NC/2] = conj(Z[NC/2]) (lane 0)
             // x is dead: the next frame (of this tile, or the first of the chunk's next tile) loads
             // behind the tile writes and the write-out
-            if (f + W < nwf) fetch(b, t0, f + W);
-            else if (tt + nt < c_nt && wv < min(a.tile_frames, c_nt - tt - nt) * a.C) fetch(b, t0 + nt, wv);
+            if (f + W < nwf) {
+                fetch(b, t0, f + W);
+            } else if (ti + 1 < n_tiles) {
+                int ttn, ntn;
+                tile_of(ti + 1, c_nt, backward, ttn, ntn);
+                if (wv < ntn * a.C) fetch(b, c_t0 + ttn, wv);
+            }
             const int tl = (a.C == 1) ? f : f / a.C, c = f - tl * a.C;
             float* col = tile_out + tl * C2 + c;
 #pragma unroll
@@ -118,6 +148,11 @@ __global__ __launch_bounds__(64 * stft_waves(LOG2N), stft_waves(LOG2N) * stft_wg
                 col[(NC / 2) * row] = mid.x;
                 col[(NC / 2) * row + a.C] = mid.y;
             }
+        }
+        if (wv >= nwf && ti + 1 < n_tiles) {  // a wave without a frame in this tile (a backward walk starts with the chunk's short
+            int ttn, ntn;                      // tile) still needs its first frame of the next one
+            tile_of(ti + 1, c_nt, backward, ttn, ntn);
+            if (wv < ntn * a.C) fetch(b, c_t0 + ttn, wv);
         }
         __syncthreads();
         // write-out: wave w owns rows w, w + W, ...; a row is one contiguous run of nt * 2C floats.
