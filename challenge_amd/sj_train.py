@@ -442,6 +442,11 @@ class FusedAGC:
         self._sig = None
         self._table = None
         self._slow = []
+        # tables by (parameter, gradient) address set: with the gradients dropped every step (zero_grad(set_to_none=True): no
+        # zero fills, and AccumulateGrad takes the incoming gradient instead of adding it to a zeroed buffer - 84 launches
+        # fewer per step of the v9 CRNN, profiles/r4/accum_probe.log) the caching allocator hands the gradient buffers back
+        # at a small number of recurring address sets (2 observed), each of which gets its table once
+        self._cache = {}
 
     @staticmethod
     def _rows_of(p):
@@ -473,13 +478,33 @@ class FusedAGC:
             rec[:, 0], rec[:, 1], rec[:, 2] = base_p + idx, base_g + idx, length
             recs.append(rec)
         table = np.concatenate(recs) if recs else np.zeros((0, 3), np.int64)
-        # pinned staging + asynchronous copy: legal while a hipGraph is being captured (it becomes a copy node of the graph)
-        host = torch.from_numpy(table)
+        # pinned staging + asynchronous copy: legal while a hipGraph is being captured (it becomes a copy node of the graph).
+        # Under capture the buffers must already exist (`reserve`, called by GraphedTrainStep before the capture starts:
+        # allocating pinned memory inside a capture invalidates it); the staging buffer stays alive for as long as a captured
+        # copy may replay from it.
+        reserved = getattr(self, '_reserved', None)
+        if reserved is not None and tuple(reserved[0].shape) == tuple(table.shape):
+            host, dev_table = reserved
+            self._reserved = None
+            host.numpy()[...] = table
+            dev_table.copy_(host, non_blocking=True)
+            self._host_table, self._table = host, dev_table
+        else:
+            host = torch.from_numpy(table)
+            if self.params[0].is_cuda:
+                host = host.pin_memory()
+                self._host_table = host
+            self._table = host.to(self.params[0].device, non_blocking=True)
+        self._sig = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
+
+    def reserve(self) -> None:
+        """Allocate the table and its pinned staging buffer NOW (outside any capture), sized for every parameter having a
+        gradient in a layout the kernel takes; the next `_build` fills them in place."""
+        rows = sum(self._rows_of(p)[0] for p in self.params)
+        host = torch.empty((rows, 3), dtype=torch.int64)
         if self.params[0].is_cuda:
             host = host.pin_memory()
-            self._host_table = host  # keeps the staging buffer alive for as long as a captured copy may replay from it
-        self._table = host.to(self.params[0].device, non_blocking=True)
-        self._sig = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
+        self._reserved = (host, torch.empty((rows, 3), dtype=torch.int64, device=self.params[0].device))
 
     def freeze(self) -> None:
         """After a hipGraph capture: the table and its pinned staging buffer are referenced by the graph and must never be
@@ -493,7 +518,14 @@ class FusedAGC:
                                "called eagerly; eager steps use the model's own instance")
         sig = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
         if sig != self._sig:
-            self._build()
+            hit = self._cache.get(sig)
+            if hit is not None:
+                self._sig, self._table, self._slow, self._host_table = sig, hit[0], hit[1], hit[2]
+            else:
+                self._build()
+                if len(self._cache) >= 8:
+                    self._cache.clear()
+                self._cache[self._sig] = (self._table, self._slow, getattr(self, '_host_table', None))
         dev = self.params[0].device
         if self._table.shape[0]:
             from . import _native as N
@@ -858,15 +890,16 @@ class CustomModel(nn.Module):
         x, y = data
         self.train()
         self.bump_generation()
-        fused = self.use_agc and x.is_cuda  # one HIP launch for AGC + clipvalue over the whole model
-        # fused: keep the gradient buffers in place (measured: dropping them saves the zero + accumulate
-        # kernels, 1.3 ms, but the buffers then move and FusedAGC re-uploads its table every step: +0.8 ms net)
-        self.optimizer.zero_grad(set_to_none=not fused)
+        # the gradients are dropped, not zeroed: AccumulateGrad then takes each incoming gradient instead of adding it to a
+        # zeroed buffer (84 elementwise launches and the zero fills fewer per step); FusedAGC keeps one table per recurring
+        # address set of the gradient buffers, so nothing is re-uploaded in steady state
+        self.optimizer.zero_grad(set_to_none=True)
         y_pred = self._call(x)
         loss = self.loss_fn(y, y_pred)
         mark('forward')
         loss.backward()  # under DDP the bucketed RCCL all-reduce overlaps with this
         mark('backward')
+        fused = self.use_agc and x.is_cuda  # one HIP launch for AGC + clipvalue over the whole model
         if fused:
             if self._fused_agc is None:
                 object.__setattr__(self, '_fused_agc', FusedAGC(list(self.parameters())))
@@ -1592,6 +1625,9 @@ class GraphedTrainStep:
         # `model.train_step` later (e.g. a ragged last batch) builds a SEPARATE FusedAGC instead of rebuilding - and
         # freeing - the buffers the graph replays from.
         self._agc = FusedAGC(list(model.parameters())) if model.use_agc else None
+        if self._agc is not None:
+            self._agc.reserve()
+            torch.cuda.synchronize(x.device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             model.train()
