@@ -47,7 +47,7 @@ STRONG_GLOBAL_BATCH = 256       # --strong: c2 clips over all ranks (= 8 x 32)
 STRONG_GLOBAL_TRAIN_BATCH = 512  # --strong: c4 training batch over all ranks
 ALGO_BYTES_PER_AUDIO_S = 4 * SR + 4 * N_MEL * SR // HOP  # fp32 wave in + fp32 mel out = 80,000
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
-PMC_JSON = os.path.join("profiles", "r3", "pmc_traffic.json")
+PMC_JSON = os.path.join("profiles", "r4", "pmc_traffic.json")
 
 
 def cpu_baseline(wav_cpu: np.ndarray):
@@ -365,7 +365,7 @@ def kernel_source_sha() -> str:
 
 
 def committed_traffic():
-    """HBM bytes per launch of the step's kernels from the committed PMC passes (profiles/r3/pmc_traffic.json,
+    """HBM bytes per launch of the step's kernels from the committed PMC passes (profiles/r4/pmc_traffic.json,
     written by scripts/pmc_summarise.py).  Refused (None + reason) when the kernel sources changed since.
     Returns (dominant-kernel bytes, whole-step bytes, note)."""
     path = os.path.join(ROOT, PMC_JSON)
@@ -680,8 +680,9 @@ def main():
                 "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
                 "how": f"kernel-timing pass after the timed region: {KERNEL_PASS} rotating steps with a HIP event pair around each "
                        "kernel on the launch stream (hipExtLaunchKernel); `achieved` = algorithmic bytes / MEAN duration of the "
-                       "dominant kernel.  Such a pair reads marker-end -> kernel-end, i.e. the dispatch gap in front of the kernel "
-                       "is inside it: 1-2 us above rocprofv3's duration of the same kernel (profiles/r3/), so `frac` errs low",
+                       "dominant kernel.  Such a pair reads marker-end -> kernel-end on the launch stream; against rocprofv3's "
+                       "duration of the same kernel under the same command the two agree within ~1 us, either way round "
+                       "(profiles/r4/driver_cmd_kernel_stats.csv vs bench_driver_cmd.json of the same session)",
             }
             if len(k1):
                 kernel_ms, k2_ms = float(k1.mean()), (float(k2.mean()) if len(k2) else 0.0)
