@@ -90,5 +90,17 @@ for case in range(n_cases):
     bad += not (ok or flip)
     flips += flip
     print(("ok  " if ok else "flip" if flip else "FAIL"), desc, f"worst {worst} {errs[worst]:.1e}")
+    if not (ok or flip):  # diagnostics: is it a mask decided within rounding?  the stock ops against themselves on x (1 + 1e-7)
+        ref2 = copy.deepcopy(ref)
+        for q in ref2.parameters():
+            q.grad = None
+        xc = (x * (1 + 1e-7)).clone().requires_grad_(needs_grad)
+        set_flags(False)
+        yc = ref2(xc)
+        yc.backward(g)
+        self_err = max(rel(pc.grad, pb.grad) for (n, pc), (_, pb) in zip(ref2.named_parameters(), ref.named_parameters())
+                       if pb.grad is not None and not (n.endswith("0.bias") or n == "fc.bias"))
+        print(f"     out {errs['out']:.1e}; outputs with a different sign of activity: {int(((ya > 0) != (yb > 0)).sum())} of {ya.numel()}; "
+              f"stock ops vs themselves on x (1 + 1e-7): worst gradient {self_err:.1e}; all: " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items() if v > 2e-4))
 print("failures:", bad, " flips:", flips)
 sys.exit(1 if bad else 0)
