@@ -320,6 +320,9 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->timeout_ticks = kEpilogueTimeoutTicks;
     p->epoch = 0;
     p->epilogue = IRIS_EPILOGUE_FUSED;
+    // a CU mask takes compute units away from this process without changing the device's reported CU count: the fused
+    // epilogue's co-residency (grid <= CUs) would not hold, so such an environment starts on the two-kernel form
+    if (getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK")) p->epilogue = IRIS_EPILOGUE_TWO_KERNELS;
     if (const char* e = getenv("IRIS_EPILOGUE")) p->epilogue = atoi(e) == IRIS_EPILOGUE_TWO_KERNELS ? IRIS_EPILOGUE_TWO_KERNELS : IRIS_EPILOGUE_FUSED;
     p->timing = 0;
     p->launch_no = 0;

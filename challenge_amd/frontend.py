@@ -116,7 +116,9 @@ class FrontendPlan:
         self._handle = handle
         self._lock = threading.Lock()
         self.mel_precision = "fp32"
-        self.epilogue = "two_kernels" if os.environ.get("IRIS_EPILOGUE") == "1" else "fused"
+        masked = "ROC_GLOBAL_CU_MASK" in os.environ or "HSA_CU_MASK" in os.environ  # the library starts such plans on two kernels
+        env = os.environ.get("IRIS_EPILOGUE")
+        self.epilogue = "two_kernels" if (env == "1" or (masked and env is None)) else "fused"
         _LIVE_PLANS.add(self)
 
     @classmethod

@@ -134,6 +134,7 @@ int iris_plan_set_mel_precision(iris_plan* plan, int precision);
  *                              iris_plan_status / since that call's predecessor are suspect.  Use TWO_KERNELS from the
  *                              start for pipelines that overlap plans.
  *   IRIS_EPILOGUE_TWO_KERNELS  fused kernel (raw mel + per-wave partials), then the min-max / log kernel.
+ * A plan created while ROC_GLOBAL_CU_MASK or HSA_CU_MASK is set starts on TWO_KERNELS (a CU mask breaks the co-residency).
  * IRIS_EPILOGUE=1 in the environment at plan creation selects TWO_KERNELS (test / A-B hook; so do IRIS_CHUNK_FRAMES=n,
  * frames per chunk of the fused kernel, and IRIS_MAGMEL_GENERIC - test hooks read once per plan, never per launch).
  * iris_plan_status: synchronises with the device, then 0 = every bounded wait so far completed, 1 = one gave up (the

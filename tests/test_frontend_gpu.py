@@ -649,3 +649,22 @@ def test_fused_epilogue_timeout_is_loud(dev):
     torch.cuda.synchronize(dev)
     with pytest.raises(N.EpilogueTimeout):
         call.launch()
+
+
+def test_cu_mask_environment_starts_on_two_kernels(dev, monkeypatch):
+    """A CU mask takes compute units away without changing the reported CU count, which would break the fused epilogue's
+    co-residency: a plan created while ROC_GLOBAL_CU_MASK / HSA_CU_MASK is set starts on the two-kernel form (same bits);
+    IRIS_EPILOGUE=0 overrides."""
+    rng = np.random.default_rng(12)
+    wav = (rng.standard_normal((4, 1, 40000)) * 0.1).astype(np.float32)
+    x = torch.from_numpy(wav).to(dev)
+    ref_plan = FE().FrontendPlan(1024, 256, 64, 16000, 1, 4, 40000, dev)
+    assert ref_plan.epilogue == "fused"
+    want = ref_plan.wav_to_logmel(x).clone()
+    monkeypatch.setenv("HSA_CU_MASK", "0:0-255")   # read by this library at plan creation only (the runtime is already up)
+    masked = FE().FrontendPlan(1024, 256, 64, 16000, 1, 4, 40000, dev)
+    assert masked.epilogue == "two_kernels" and masked.fused_kernel_name().endswith("false>")
+    assert torch.equal(masked.wav_to_logmel(x), want)
+    monkeypatch.setenv("IRIS_EPILOGUE", "0")
+    forced = FE().FrontendPlan(1024, 256, 64, 16000, 1, 4, 40000, dev)
+    assert forced.epilogue == "fused" and forced.fused_kernel_name().endswith("true>")
