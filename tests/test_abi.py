@@ -153,3 +153,52 @@ def test_product_package_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in text and "from oracle" not in text, fn
+
+
+def test_hot_kernels_use_no_scratch_and_fit_their_wave_budget(tmp_path):
+    """Static check on the device assembly (hipcc cross-compiles here): no variant of the fused kernel, the STFT kernel or the
+    min-max / log kernel may use scratch memory (a kernel with scratch pays ~5 us more per dispatch on this chip, and a spill
+    inside the frame loop costs far more - both happened silently during round 4 before this test existed), and every fused
+    variant must fit the register budget of the wave count it is launched with (`fused_waves`: 16 waves = 128 VGPRs,
+    12 = 168, 8 = 256)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "challenge_amd", "csrc", "iris_frontend.hip")
+    asm = str(tmp_path / "iris_frontend.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-S", "--cuda-device-only",
+                    "-o", asm, src], check=True, capture_output=True)
+    name, cur, rows = None, {}, []
+    for line in open(asm):
+        m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", line)
+        if m:
+            name, cur = m.group(1), {}
+            continue
+        if name:
+            m = re.match(r"\s*\.amdhsa_(next_free_vgpr|private_segment_fixed_size)\s+(\d+)", line)
+            if m:
+                cur[m.group(1)] = int(m.group(2))
+            if ".end_amdhsa_kernel" in line:
+                rows.append((name, cur))
+                name = None
+    names = subprocess.run(["c++filt"] + [r[0] for r in rows], capture_output=True, text=True).stdout.split("\n")
+    hot = [(d, c) for (n, c), d in zip(rows, names) if any(k in d for k in ("k_wav_to_mel", "k_stft", "k_minmax_log_apply", "k_magmel"))]
+    assert len(hot) >= 90, len(hot)   # the fused variants + the MFMA / STFT / magmel / min-max kernels
+    spills = [(d, c["private_segment_fixed_size"]) for d, c in hot if c.get("private_segment_fixed_size", 0)]
+    assert not spills, spills
+    for d, c in hot:
+        m = re.match(r"void k_wav_to_mel<(\d+), (\d+), (true|false), (true|false), 1, (true|false)>", d)
+        if not m:
+            continue
+        log2n, mode, hi, bands, fuse = int(m.group(1)), int(m.group(2)), m.group(3) == "true", m.group(4) == "true", m.group(5) == "true"
+        if log2n >= 11:
+            waves = 12 if (not bands and not hi and (not fuse or mode != 2)) else 8
+        elif log2n == 10:
+            waves = 12 if bands else 16
+        else:
+            waves = 16
+        budget = {16: 128, 12: 168, 8: 256}[waves]
+        assert c["next_free_vgpr"] <= budget, (d, c["next_free_vgpr"], budget)
