@@ -66,7 +66,7 @@ def cpu_baseline(wav_cpu: np.ndarray):
     ta = []
     for _ in range(reps_a):
         t0 = time.perf_counter()
-        R.wav_to_logmel(wav_cpu, N_FFT, HOP, N_MEL, SR)
+        ref_logmel = R.wav_to_logmel(wav_cpu, N_FFT, HOP, N_MEL, SR)
         ta.append(time.perf_counter() - t0)
     a_rate = audio_s / float(np.median(ta))
     # B: torch CPU; small FFTs oversubscribe badly, so try a few thread counts and keep the best
@@ -104,7 +104,31 @@ def cpu_baseline(wav_cpu: np.ndarray):
                    f"{b_threads} threads, median of {b_runs} runs = {b_rate:.0f}; A=NumPy oracle, 1 thread, median of "
                    f"{reps_a} = {a_rate:.0f}; host has {cores} hardware threads; CPU: {model}"),
         "numpy_1thread": round(a_rate, 1), "torch_best": round(b_rate, 1), "torch_best_threads": b_threads,
-    }
+    }, ref_logmel
+
+
+def parity(wav_cpu: np.ndarray, gpu_logmel: np.ndarray, gpu_mel: np.ndarray, ref_logmel: np.ndarray):
+    """The checker leg ("mel parity check on the same run"): what the timed kernel wrote for batch 0 of the
+    rotation against the oracle on the same waveforms, plus one launch without min-max / log for the mel magnitudes.
+    `mel_rule_ratio` <= 1 is the stated tolerance (oracle.frontend_ref.mel_tolerance: 1e-5 |ref| + 4 eps xrms sum W against
+    the fp64 oracle); `mel_rel_err_floor_1e-3` is SURVEY 8(d)'s literal metric max |d| / max(|ref|, 1e-3), reported beside it
+    (torch.stft fp32, the engine the reference runs, reads 1.1e-5 on this config by that metric: profiles/r4/hip_vs_fp64_sweep.log)."""
+    from oracle import frontend_ref as R
+    ref, tol = R.mel_tolerance(wav_cpu, N_FFT, HOP, N_MEL, SR)
+    ratio = R.mel_err_ratio(gpu_mel, ref, tol)
+    d = np.abs(gpu_mel.astype(np.float64) - ref)
+    floor = float((d / np.maximum(np.abs(ref), 1e-3)).max())
+    strict, covered = R.mel_strict_rel_err(gpu_mel, ref, tol)  # north_star's literal 1e-5 on every ordinary element
+    logabs = float(np.abs(np.exp(gpu_logmel.astype(np.float64)) - np.exp(ref_logmel.astype(np.float64))).max())
+    ok = bool(ratio <= 1.0 and strict <= 1e-5 and logabs <= 5e-6)
+    return {"checked": f"c2 batch 0 of the rotation, {wav_cpu.shape[0]} x {wav_cpu.shape[2] // SR} s: the timed kernel's own output "
+                       "(log-mel) + one launch without min-max / log (mel) vs the oracle on the same waveforms",
+            "ok": ok, "mel_rule_ratio": round(ratio, 4), "mel_rel_err_floor_1e-3": float(f"{floor:.3e}"),
+            "mel_strict_rel_err": float(f"{strict:.3e}"), "mel_strict_covers": round(covered, 5),
+            "logmel_exp_abs": float(f"{logabs:.3e}"),
+            "bounds": {"mel_rule_ratio": 1.0, "mel_strict_rel_err": 1e-5, "logmel_exp_abs": 5e-6},
+            "strict": "|mel - ref| / |ref| over the elements whose relative term dominates the rule (|ref| >= 0.048 xrms sum W)",
+            "rule": "|mel - ref_fp64| <= 1e-5 |ref| + 4 eps_fp32 xrms[b,t,c] sum_k W[k,m] (oracle.frontend_ref.mel_tolerance)"}
 
 
 def side_measurements(dev, rank, world, steps, fence, strong=False):
@@ -138,7 +162,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
             fn()
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if S.collectives_on(world):
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -216,10 +240,10 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         bf16 = {"fwd_ms_per_step": round(1e3 * t_fb, 3), "fwd_audio_s_per_s": round(world * audio_s / t_fb, 1),
                 "train_ms_per_step": round(1e3 * t_tb, 3), "train_audio_s_per_s": round(world * audio_s / t_tb, 1),
                 "max_abs_dev_of_sigmoid_outputs_vs_fp32": round(dev_abs, 6),
-                "note": "opt-in (torch.autocast bf16 around the CRNN only; the frontend stays fp32); the reference trains in "
-                        "fp32, so fp32 stays the default and the reported metric.  Under autocast the model runs the stock "
-                        "torch / MIOpen ops: the HIP BatchNorm / ReLU / MaxPool / LSTM / first-layer passes are fp32 only, "
-                        "which is why the fp32 step has caught up with this one"}
+                "note": "NOT a bf16 path of this library: a smoke run of torch.autocast(bf16) around the CRNN with the STOCK torch / "
+                        "MIOpen ops - every HIP pass (BatchNorm / ReLU / MaxPool / LSTM / first layer) is fp32 only and bypassed "
+                        "under autocast, the frontend stays fp32.  The reference trains in fp32: fp32 is the default and the "
+                        "reported metric; this entry only shows that autocast does not break the step"}
     except Exception as exc:  # an opt-in extra must never take the bench line down
         bf16 = {"error": repr(exc)[:200]}
 
@@ -296,9 +320,9 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         "crnn_matrix_core_bound": mfma,
         "c4_train_step": {"audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3),
                           "batch_per_gpu": batch, "n_gpus": world, "params": sum(p.numel() for p in model.parameters()),
-                          "hipgraph": graphed, "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if world > 1 else "none", "device_ms_per_phase": breakdown,
+                          "hipgraph": graphed, "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if ddp is not None else "none", "device_ms_per_phase": breakdown,
                           "allreduce": comm},
-        "bf16_autocast_opt_in": bf16,
+        "autocast_bf16_smoke_stock_ops": bf16,
         # whether the c3 / c4 numbers above ran on the shipped, tuned MIOpen perf-db or on this build's own defaults
         "miopen_db": S.miopen_db_status(),
     }
@@ -472,6 +496,58 @@ def batch_sweep(dev, fence, steps):
     return rows
 
 
+def config_rooflines(dev, fence, steps):
+    """The fused step at the other BASELINE shapes, each as a fraction of the HBM roofline (event-timed kernel, inputs
+    rotating through > 256 MiB): c1 (one 2 s clip - launch-bound by construction), c3 with its SpecAugment / stft_filter
+    bands, the reference's own default shape (n_fft 512, hop 256, 80 mel, stereo) at its default batch 12 and at 64.
+    c2 is the headline; c5 has its own entry.  Algorithmic bytes = B (4 C L + 4 M T C)."""
+    from challenge_amd.frontend import FrontendPlan, normalize
+    rows = {}
+    shapes = [("c1_1x2s", 1024, 256, 64, 16000, 1, 1, 32000, False),
+              ("c3_64x8.2s_specaugment_bands", 1024, 256, 64, 16000, 1, 64, 130816, True),
+              ("reference_default_n512_m80_stereo_b12", 512, 256, 80, 16000, 2, 12, 130816, False),
+              ("reference_default_n512_m80_stereo_b64", 512, 256, 80, 16000, 2, 64, 130816, False)]
+    for name, n_fft, hop, m, sr, c, b, length, bands in shapes:
+        plan = FrontendPlan(n_fft, hop, m, sr, c, b, length, dev)
+        t = plan.num_frames(length)
+        algo = b * (c * length * 4 + m * t * c * 4)
+        copies = max(2, min(64, -(-(300 << 20) // algo)))
+        gen = torch.Generator(device=dev).manual_seed(11 + b)
+        wavs = [normalize(torch.randn(b, c, length, generator=gen, device=dev)) for _ in range(copies)]
+        outs = [torch.empty((b, m, t, c), device=dev) for _ in range(copies)]
+        kw = {}
+        if bands:  # data_utils.augment: 6 time bands of < 24 frames, 1 frequency band of < 16 linear bins (transforms.py:12-40)
+            rng = np.random.default_rng(5)
+            ts, fs = rng.integers(0, 24, (b, 6)), rng.integers(0, 16, (b, 1))
+            tb = np.stack([rng.integers(0, t - ts), ts], -1).astype(np.int32)
+            fb = np.stack([rng.integers(0, n_fft // 2 + 1 - fs), fs], -1).astype(np.int32)
+            kw = {"t_bands": torch.from_numpy(tb).to(dev), "f_bands": torch.from_numpy(fb).to(dev)}
+        calls = [plan.prepare(wavs[i], out=outs[i], **kw) for i in range(copies)]
+        for i in range(max(copies, 8)):
+            calls[i % copies].launch()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            calls[i % copies].launch()
+        fence()
+        dt = (time.perf_counter() - t0) / steps
+        plan.timing_enable(1)
+        for i in range(steps + 4):
+            calls[i % copies].launch()
+        fence()
+        k, k2 = plan.timing_samples(0), plan.timing_samples(1)
+        plan.timing_enable(False)
+        k_ms = float(k.mean()) + (float(k2.mean()) if len(k2) else 0.0)
+        rows[name] = {"kernel": plan.fused_kernel_name(with_bands=bands), "form": "two_kernels" if len(k2) else "fused_epilogue",
+                      "algorithmic_bytes_per_launch": algo, "kernel_us": round(1e3 * k_ms, 2), "step_us": round(1e6 * dt, 2),
+                      "frac_of_8TBs": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "step_frac_of_8TBs": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4),
+                      "audio_s_per_s": round(b * length / sr / dt, 1)}
+        del calls, wavs, outs, plan
+        torch.cuda.empty_cache()
+    return rows
+
+
 def device_identity(dev):
     """What tells two ranks' devices apart in the JSON line: PCI bus id and uuid where torch exposes them."""
     p = torch.cuda.get_device_properties(dev)
@@ -514,9 +590,9 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:  # ranks started by the driver's own `python -m torch.distributed.run ... bench.py`: same environment as
-        from challenge_amd.sj_train import distributed_env  # self_launch gives its children, before the first GPU call
-        distributed_env()
+    if world > 1 or os.environ.get("IRIS_FORCE_PG") == "1":  # ranks started by the driver's own `python -m torch.distributed.run
+        from challenge_amd.sj_train import distributed_env  # ... bench.py`: same environment as self_launch gives its children,
+        distributed_env()                                   # before the first GPU call
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
     # test hook: IRIS_BENCH_SHARE_GPU=1 lets several ranks share cuda:0 over gloo, to exercise the N > 1
     # control flow (self-launch, barriers, max over ranks, DDP) on a one-GPU box; never set in a real run
@@ -526,13 +602,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
-    if world > 1:
+    # IRIS_FORCE_PG=1 (sj_train.force_process_group): the process group, DDP and every collective of the line at world size 1
+    # too - a one-GPU box then runs the REAL backend (RCCL communicator, DDP's reducer on RCCL's stream, barrier / all-reduce
+    # / all_gather_object of this script) instead of skipping it
+    force_pg = world == 1 and os.environ.get("IRIS_FORCE_PG") == "1"
+    coll = world > 1 or force_pg
+    if coll:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=dev)  # RCCL
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL
         backend = dist.get_backend()
         if not share and backend != "nccl":  # the N > 1 line is about RCCL over xGMI; anything else is a mis-launch
             print(f"bench.py: world {world} runs on backend '{backend}', expected 'nccl' (RCCL)", file=sys.stderr)
@@ -564,7 +646,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -580,7 +662,7 @@ def main():
     fence()
     elapsed_local = time.perf_counter() - t0
     elapsed = elapsed_local
-    if world > 1:
+    if coll:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -634,7 +716,7 @@ def main():
                    "global_batch": world * batch, "parallelism": f"dp{world}"},
         "stft_mel_fwd_audio_s_per_s": None,
     }
-    if world > 1:  # self-audit of the N > 1 run: who ran where, and did the collective backend see N ranks
+    if coll:  # self-audit of the N > 1 run: who ran where, and did the collective backend see N ranks
         mine = {"rank": rank, "local_rank": local_rank, "device": device_identity(dev),
                 "value": round(audio_s_per_step * args.steps / elapsed_local, 1),
                 "ms_per_step": round(1e3 * elapsed_local / args.steps, 5)}
@@ -651,11 +733,20 @@ def main():
                             "allreduce_exposed_ms at the top level of this line (c4: frontend + CRNN forward / backward + "
                             "RCCL gradient all-reduce + AGC + Adam, batch 64 per GPU)")
         result.update({"train_step_ms": None, "train_step_audio_s_per_s": None, "allreduce_exposed_ms": None, "grad_bytes": None})
+        if force_pg:
+            result["forced_process_group"] = ("IRIS_FORCE_PG=1: world size 1 with the process group, DDP and every collective "
+                                              "on; allreduce_exposed_ms is then the floor of the bucket launches (no peer)")
     import threading
     done_lock, done = threading.Lock(), []
     # what the final line needs from the device is fetched now: finish() may run while the GPU is stuck
     kernel_name = plan.fused_kernel_name()
     cpu_input = wavs[0].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    gpu_logmel = gpu_mel = None
+    if cpu_input is not None:  # parity leg: batch 0 as the timed kernel wrote it + its mel magnitudes (one extra launch)
+        gpu_logmel = outs[0].cpu().numpy()
+        gpu_mel = plan.wav_to_logmel(wavs[0], minmax=False, log=False).cpu().numpy()
+
+    parity_ok = []
 
     def finish(extras):
         """Rank 0: assemble and print the ONE JSON line (once: the watchdog below may get here first)."""
@@ -668,7 +759,7 @@ def main():
                 if "c3_best_fp32_audio_s_per_s" in extras:
                     result["stft_mel_fwd_audio_s_per_s"] = extras["c3_best_fp32_audio_s_per_s"]
                 c4 = extras.get("c4_train_step")
-                if world > 1 and c4:  # the scaling curve of the END-TO-END TRAINING STEP, at the top level of the line
+                if coll and c4:  # the scaling curve of the END-TO-END TRAINING STEP, at the top level of the line
                     comm = c4.get("allreduce") or {}
                     result.update({"train_step_ms": c4.get("ms_per_step"), "train_step_audio_s_per_s": c4.get("audio_s_per_s"),
                                    "allreduce_exposed_ms": comm.get("exposed_allreduce_ms_per_step"),
@@ -704,7 +795,9 @@ def main():
             roof["two_kernel_form"] = two
             result["roofline"] = roof
             if cpu_input is not None:
-                result["cpu_baseline"] = cpu_baseline(cpu_input)
+                result["cpu_baseline"], ref_logmel = cpu_baseline(cpu_input)
+                result["parity"] = parity(cpu_input, gpu_logmel, gpu_mel, ref_logmel)
+                parity_ok.append(result["parity"]["ok"])
             print(json.dumps(result), flush=True)
 
     # A side measurement that hangs (one rank failing inside a collective while the others wait) must not take the
@@ -712,7 +805,7 @@ def main():
     def abandon():
         print(f"bench.py: rank {rank}: side measurements exceeded {args.extras_limit} s, abandoned", file=sys.stderr, flush=True)
         finish({"error": f"side measurements exceeded {args.extras_limit} s and were abandoned"})
-        os._exit(0)
+        os._exit(0 if all(parity_ok) else 3)
     timer = threading.Timer(args.extras_limit, abandon)
     timer.daemon = True
     if not args.no_extras:
@@ -729,6 +822,7 @@ def main():
             extras = {"error": repr(exc)[:300]}
         if world == 1 and "error" not in extras:
             extras["k1_batch_sweep"] = batch_sweep(dev, fence, max(args.extra_steps, 20))
+            extras["roofline_per_config"] = config_rooflines(dev, fence, max(args.extra_steps, 40))
             # BASELINE configs[4]: 22.05 kHz stereo, n_fft 2048, 128 mel - banded fp32 (default) vs fp16 MFMA variant
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import gpu_c5
@@ -756,8 +850,11 @@ def main():
                                                   "step_us": round(1e6 * dt, 2)}
     timer.cancel()
     finish(extras)
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
+    if parity_ok and not all(parity_ok):  # a fast kernel whose results differ from the reference's is not done
+        print("bench.py: parity check against the oracle FAILED (see the `parity` field)", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

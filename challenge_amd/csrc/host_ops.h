@@ -34,9 +34,10 @@ static hipError_t launch_stft(const StftArgs& a, int grid, size_t lds, hipStream
     return hipGetLastError();
 }
 
-extern "C" int iris_stft(iris_plan* p, const float* wav, float* spec, int batch, int len, void* stream) {
+extern "C" int iris_stft(iris_plan* p, const float* wav, float* spec, int batch, int len, int flags, void* stream) {
     int rc = check_wav_args(p, wav, spec, batch, len, "iris_stft");
     if (rc) return rc;
+    if (flags & ~IRIS_F_NORMALIZE) return fail(IRIS_E_INVALID, "iris_stft: flags 0x%x (only IRIS_F_NORMALIZE applies)", flags);
     DeviceGuard guard(p->device);
     StftArgs a;
     a.wav = wav;
@@ -70,6 +71,15 @@ extern "C" int iris_stft(iris_plan* p, const float* wav, float* spec, int batch,
     if (lds > 160 * 1024) return fail(IRIS_E_UNSUPPORTED, "iris_stft: %zu B of LDS", lds);
     const int grid = std::min(a.n_chunks, p->num_cu * wgs);
     hipStream_t s = (hipStream_t)stream;
+    a.sumsq = nullptr;
+    a.n_sq = 0;
+    if (flags & IRIS_F_NORMALIZE) {  // the clip's sum of squares as partial sums in the plan's workspace, folded by the kernel
+        const size_t row = (size_t)p->channels * len;
+        a.n_sq = (int)((row + kChunk - 1) / kChunk);
+        if ((size_t)batch * a.n_sq > p->ws_floats) return fail(IRIS_E_CAPACITY, "iris_stft: workspace too small");
+        k_sumsq_partial<<<dim3(a.n_sq, batch), 256, 0, s>>>(wav, p->d_ws, row, a.n_sq);
+        a.sumsq = p->d_ws;
+    }
     hipError_t e;
     switch (p->log2n) {
         case 11: e = launch_stft<11>(a, grid, lds, s); break;
@@ -474,6 +484,7 @@ static int bn_check(const void* a, const void* b, size_t rows, int channels, con
         return fail(IRIS_E_UNSUPPORTED, "%s: rows %zu, channels %d (a positive multiple of 4, <= 4096)", who, rows, channels);
     return IRIS_OK;
 }
+static bool bn_overlap(const float* z, const float* y, size_t n_z) { return y < z + n_z && z < y + n_z; }
 static int grid_bn(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 2048); }  // fat blocks: the per-block coefficient setup is amortised
 static unsigned bn_reduce_grid(size_t rows, int C4, int rows_per_pass = kBnRows) {
     const int cols = std::min(C4, 256), tys = 256 / cols;
@@ -503,6 +514,9 @@ extern "C" int iris_bn_relu_apply(const float* z, float* y, size_t rows, int cha
     if (rc) return rc;
     if (!sums || !gamma || !beta || !running_mean || !running_var || !save_mean || !save_rstd)
         return fail(IRIS_E_INVALID, "iris_bn_relu_apply: NULL argument");
+    // every block re-reads K = row 0 of z (the shift of the sums) while other blocks write y: in place, a block could
+    // overwrite row 0 before its neighbours have read K
+    if (bn_overlap(z, y, rows * (size_t)channels)) return fail(IRIS_E_INVALID, "iris_bn_relu_apply: y must not overlap z (not an in-place op)");
     const size_t n4 = rows * (size_t)(channels / 4);
     const double m = (double)rows;
     k_bn_relu_apply<<<grid_bn(n4), 256, 2 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(z, y, n4, channels / 4, 1.0 / m, rows > 1 ? m / (m - 1.0) : 1.0, sums,
@@ -552,6 +566,7 @@ extern "C" int iris_bn_relu_pool_apply(const float* z, float* p, int batch, int 
                                        float* running_mean, float* running_var, float* save_mean, float* save_rstd, void* stream) {
     int rc = bn_pool_check(z, p, batch, height, width, channels, "iris_bn_relu_pool_apply");
     if (rc) return rc;
+    if (bn_overlap(z, p, (size_t)batch * height * width * channels)) return fail(IRIS_E_INVALID, "iris_bn_relu_pool_apply: p must not overlap z");
     if (!sums || !gamma || !beta || !running_mean || !running_var || !save_mean || !save_rstd)
         return fail(IRIS_E_INVALID, "iris_bn_relu_pool_apply: NULL argument");
     const size_t n4 = (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);

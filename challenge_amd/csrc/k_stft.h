@@ -21,6 +21,8 @@ struct StftArgs {
     int tile_frames;                 // capacity of the LDS tile (frames)
     int chunks_per_clip, n_chunks;   // balanced split of a clip's T frames: sizes differ by at most one
     int chunk_base, chunk_rem;
+    const float* sumsq;  // nullable [B, n_sq] partial sums of squares of the clip (IRIS_F_NORMALIZE)
+    int n_sq;
 };
 
 // (n_fft 2048 keeps 16 points per lane and both spectrum halves: it needs more than 256 registers)
@@ -108,6 +110,14 @@ __global__ __launch_bounds__(64 * stft_waves(LOG2N), stft_waves(LOG2N) * stft_wg
       const int c_t0 = chunk_t0(chunk, b), c_nt = chunk_nt(chunk, b);
       const bool backward = ((chunk - b * a.chunks_per_clip) & 1) != 0;
       const int n_tiles = (c_nt + a.tile_frames - 1) / a.tile_frames;
+      float scale = 1.0f;  // normalize: the STFT is linear, so 1 / (10 rms) scales the spectrum as it is written
+      if (a.sumsq != nullptr) {
+          float sq = 0.f;
+          const float* ssq = opaque(a.sumsq) + (size_t)b * a.n_sq;
+          for (int i = lane; i < a.n_sq; i += kWave) sq += ssq[i];
+          sq = wave_sum(sq);
+          scale = 1.0f / (sqrtf(sq / ((float)a.C * (float)a.L)) * 10.0f);
+      }
       if (chunk != g0) {
           int tt0, nt0;
           tile_of(0, c_nt, backward, tt0, nt0);
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(64 * stft_waves(LOG2N), stft_waves(LOG2N) * stft_wg
                 for (; k + 3 * W < F; k += 4 * W) {
                     float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = tile_out[(k + j * W) * row + r];
+                    for (int j = 0; j < 4; ++j) v[j] = tile_out[(k + j * W) * row + r] * scale;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         asm volatile(STFT_ST ::"v"(off), "v"(v[j]),
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(64 * stft_waves(LOG2N), stft_waves(LOG2N) * stft_wg
                                      : "memory");
                 }
                 for (; k < F; k += W) {
-                    const float v = tile_out[k * row + r];
+                    const float v = tile_out[k * row + r] * scale;
                     asm volatile(STFT_ST ::"v"(off), "v"(v), "s"(out0 + (size_t)k * pitch)
                                  : "memory");
                 }

@@ -42,13 +42,14 @@ def read_wav_file(wav_fname: str):
     return np.ascontiguousarray(data.T), int(sr)
 
 
-def stft_array(wav: torch.Tensor, n_fft: int = 512) -> torch.Tensor:
+def stft_array(wav: torch.Tensor, n_fft: int = 512, normalize: bool = False) -> torch.Tensor:
     """Spectrogram(n_fft, power=None) of wav [chan, samples] on a ROCm device, in the
-    reference layout [freq, time, chan*2] (re block, im block) (data_utils.py:17-27)."""
+    reference layout [freq, time, chan*2] (re block, im block) (data_utils.py:17-27); `normalize` folds
+    data_utils.py:22-23's wav / (10 rms) into the transform (no normalised copy of the waveform)."""
     if wav.dim() != 2:
         raise ValueError("wav must be [chan, samples]")
     plan = _fe.get_plan(wav.device, n_fft, None, 80, _SR, int(wav.shape[0]), 1, int(wav.shape[1]))
-    return plan.stft(wav.unsqueeze(0))[0]
+    return plan.stft(wav.unsqueeze(0), normalize=normalize)[0]
 
 
 def load_wav_array(wav, sample_rate: int = _SR, device=None) -> torch.Tensor:
@@ -60,7 +61,10 @@ def load_wav_array(wav, sample_rate: int = _SR, device=None) -> torch.Tensor:
     device = _default_device() if device is None else torch.device(device)
     wav = torch.as_tensor(np.asarray(wav, dtype=np.float32) if not isinstance(wav, torch.Tensor) else wav)
     wav = wav.to(device=device, dtype=torch.float32)
-    return stft_array(normalize(wav), 512)
+    # normalize + STFT as ONE transform launch behind a partial-sums launch (iris_stft with IRIS_F_NORMALIZE): the
+    # two-kernel iris_normalize pass over the waveform cost as much as the transform itself.  Equal to
+    # stft_array(normalize(wav)) up to the fp32 rounding of the scaled samples (<= 2e-6 of the spectrum's peak)
+    return stft_array(wav, 512, normalize=True)
 
 
 def load_wav(wav_fname: str, device=None) -> torch.Tensor:

@@ -217,14 +217,15 @@ class FrontendPlan:
         return wav, int(wav.shape[0]), int(wav.shape[2])
 
     # ---- ops ---------------------------------------------------------------
-    def stft(self, wav: torch.Tensor) -> torch.Tensor:
-        """wav [B,C,L] -> spec [B,F,T,2C] (load_wav, data_utils.py:17-27)."""
+    def stft(self, wav: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """wav [B,C,L] -> spec [B,F,T,2C] (load_wav, data_utils.py:17-27).  `normalize`: the wav / (10 rms) of
+        data_utils.py:22-23 folded in (per clip, all channels jointly; the spectrum is scaled as it is written)."""
         wav, b, length = self._check_wav(wav)
         t = self.num_frames(length)
         spec = torch.empty((b, self.n_bins, t, 2 * self.channels), dtype=torch.float32, device=self.device)
         with self._lock, torch.cuda.device(self.device):
             rc = N.lib().iris_stft(self._handle, wav.data_ptr(), spec.data_ptr(), b, length,
-                                   _stream_ptr(self.device))
+                                   N.IRIS_F_NORMALIZE if normalize else 0, _stream_ptr(self.device))
         N.check(rc, "iris_stft")
         return spec
 

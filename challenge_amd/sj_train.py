@@ -483,8 +483,12 @@ class FusedAGC:
         # allocating pinned memory inside a capture invalidates it); the staging buffer stays alive for as long as a captured
         # copy may replay from it.
         reserved = getattr(self, '_reserved', None)
-        if reserved is not None and tuple(reserved[0].shape) == tuple(table.shape):
-            host, dev_table = reserved
+        if reserved is not None and reserved[0].shape[0] >= table.shape[0]:
+            # `reserve` sized the buffers for EVERY parameter having a gradient in a layout the kernel takes; a parameter
+            # without a gradient or on the torch path (`_slow`) only makes the table shorter: fill a prefix and hand the
+            # kernel the actual row count (no allocation inside a capture whatever the row count turns out to be)
+            n = int(table.shape[0])
+            host, dev_table = reserved[0][:n], reserved[1][:n]
             self._reserved = None
             host.numpy()[...] = table
             dev_table.copy_(host, non_blocking=True)
@@ -495,7 +499,13 @@ class FusedAGC:
                 host = host.pin_memory()
                 self._host_table = host
             self._table = host.to(self.params[0].device, non_blocking=True)
-        self._sig = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
+        self._sig = self._signature()
+
+    def _signature(self):
+        """(parameter address, gradient address, gradient strides) per parameter: a gradient buffer handed back at the same
+        address in another layout must not reuse a table built for the old one (fast / slow classification, row stride)."""
+        return tuple((p.data_ptr(),) + ((-1, ()) if p.grad is None else (p.grad.data_ptr(), tuple(p.grad.stride())))
+                     for p in self.params)
 
     def reserve(self) -> None:
         """Allocate the table and its pinned staging buffer NOW (outside any capture), sized for every parameter having a
@@ -516,7 +526,7 @@ class FusedAGC:
         if getattr(self, '_frozen', False):
             raise RuntimeError("FusedAGC: this instance belongs to a captured hipGraph (GraphedTrainStep) and cannot be "
                                "called eagerly; eager steps use the model's own instance")
-        sig = tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
+        sig = self._signature()
         if sig != self._sig:
             hit = self._cache.get(sig)
             if hit is not None:
@@ -1519,10 +1529,27 @@ def miopen_db_status() -> str:
     return "used"
 
 
-def init_distributed():
+def force_process_group() -> bool:
+    """IRIS_FORCE_PG=1: create the process group, wrap the model in DistributedDataParallel and run every collective of
+    `fit` even at world size 1.  A one-GPU box then executes the REAL backend (RCCL: communicator initialisation under
+    HSA_ENABLE_IPC_MODE_LEGACY=0, DDP's reducer on RCCL's stream next to the raw-pointer HIP passes on torch's current
+    stream, the all-reduce kernels themselves) - what a gloo run with two ranks sharing the device cannot show."""
+    return os.environ.get('IRIS_FORCE_PG', '0') == '1'
+
+
+def collectives_on(world: int) -> bool:
+    """Do `fit` / `average_bn_statistics` / the bench issue their collectives?  world > 1, or a forced group at world 1."""
+    return world > 1 or (force_process_group() and torch.distributed.is_available() and torch.distributed.is_initialized())
+
+
+def init_distributed(force_group: Optional[bool] = None):
     """One process per GPU (torchrun): returns (rank, world, device).  Backend 'nccl' is
-    RCCL on ROCm; 'gloo' on CPU-only hosts (tests)."""
+    RCCL on ROCm; 'gloo' on CPU-only hosts (tests).  `force_group` (default: IRIS_FORCE_PG=1) creates the group at world
+    size 1 as well - in a fresh process, at its first GPU call, never after a re-exec."""
     distributed_env()  # before torch.cuda.is_available(): that call already initialises the HIP runtime
+    if force_group:
+        os.environ['IRIS_FORCE_PG'] = '1'
+    force_group = force_process_group() if force_group is None else force_group
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -1531,13 +1558,13 @@ def init_distributed():
         device = torch.device('cuda', local)
     else:
         device = torch.device('cpu')
-    if world > 1 and not torch.distributed.is_initialized():
+    if (world > 1 or force_group) and not torch.distributed.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if device.type == 'cuda':
-            torch.distributed.init_process_group('nccl', device_id=device)
+            torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
-            torch.distributed.init_process_group('gloo')
+            torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
     return rank, world, device
 
 
@@ -1549,7 +1576,7 @@ DDP_BUCKET_MB = int(os.environ.get("IRIS_DDP_BUCKET_MB", "12"))
 
 
 def wrap_ddp(model: CustomModel, device, world: int):
-    if world <= 1:
+    if not collectives_on(world):
         return None
     from torch.nn.parallel import DistributedDataParallel as DDP
     # ONE collective per step - the bucketed gradient all-reduce: BatchNorm statistics stay per replica during the epoch
@@ -1566,7 +1593,7 @@ def average_bn_statistics(model: nn.Module, world: int) -> None:
     all-reduce per epoch over the 46 running_mean / running_var vectors flattened together - so that every rank validates,
     and rank 0 saves, the same model.  (The mean of per-rank variances ignores the spread of the per-rank means: the
     running averages of identically distributed shards, where that spread is O(1 / sqrt(steps)).)"""
-    if world <= 1:
+    if not collectives_on(world):
         return
     bufs = [b for name, b in model.named_buffers() if name.endswith(('running_mean', 'running_var'))]
     if not bufs:
@@ -1659,12 +1686,16 @@ class GraphedTrainStep:
                 g['lr'] = float(value)
 
 
+_PLAN_CHECK_ON_CPU = False  # test hook (tests/test_ddp_gloo.py): consult the frontend plans' status for a CPU-resident loss too
+
+
 def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=None, validation_steps=16,
         scheduler=None, csv_path=None, checkpoint_path=None, patience=None, rank=0, world=1, verbose=True,
         swa=None):
     """Minimal Keras-fit equivalent for this path: per-epoch LR schedule, CSV log,
     best-val-loss checkpoint, early stopping, TerminateOnNaN (sj_train.py:489-519)."""
     best, bad, history = math.inf, 0, []
+    coll = collectives_on(world)  # world > 1, or a forced process group at world 1 (IRIS_FORCE_PG=1)
     it = iter(train_set)
     for epoch in range(epochs):
         if scheduler is not None:
@@ -1675,17 +1706,28 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
         for _ in range(steps_per_epoch):
             losses.append(model.train_step(next(it))['loss'])
         loss = torch.stack(losses).mean()
-        if world > 1:
-            torch.distributed.all_reduce(loss)  # one scalar per epoch
-            loss = loss / world
+        # The one place per epoch where the frontend plans' status words are read for certain (the hot path also reports a
+        # failed earlier launch at the plan's next call, without a sync): EpilogueTimeout naming the plan instead of training
+        # on NaN features.  Under DDP the failure of ONE rank must not leave the others waiting in the collectives below, so
+        # the verdict rides along with the epoch loss in the same all-reduce and every rank raises after it.
+        plan_failure = None
+        if loss.is_cuda or _PLAN_CHECK_ON_CPU:
+            try:
+                _fe.check_plans(loss.device)
+            except _fe.N.EpilogueTimeout as exc:
+                plan_failure = exc
+        if coll:
+            pack = torch.stack([loss, loss.new_tensor(1.0 if plan_failure is not None else 0.0)])
+            torch.distributed.all_reduce(pack)  # two scalars per epoch
+            loss, failed_ranks = pack[0] / world, int(round(float(pack[1])))
+            if failed_ranks and plan_failure is None:
+                plan_failure = _fe.N.EpilogueTimeout(f"{failed_ranks} other rank(s) of this job reported a failed fused min-max / "
+                                                     "log epilogue (NaN features); stopping with them")
+        if plan_failure is not None:
+            raise plan_failure
         row = {'epoch': epoch, 'loss': float(loss), 'lr': model.optimizer.param_groups[0]['lr'],
                'time': time.time() - t0}
-        if loss.is_cuda:
-            # float(loss) has just synchronised: the one place per epoch where the frontend plans' status words are read
-            # for certain (the hot path also reports a failed earlier launch at the plan's next call, without a sync).
-            # Raises EpilogueTimeout naming the plan instead of training on NaN features.
-            _fe.check_plans(loss.device)
-        if world > 1:
+        if coll:
             average_bn_statistics(model, world)
         if not math.isfinite(row['loss']):
             if verbose and rank == 0:
@@ -1694,7 +1736,7 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
         if validation_data is not None:
             vit = iter(validation_data)
             vl = torch.stack([model.test_step(next(vit))['loss'] for _ in range(validation_steps)]).mean()
-            if world > 1:  # every rank validates its own shard: the monitored value is the mean over ranks
+            if coll:  # every rank validates its own shard: the monitored value is the mean over ranks
                 torch.distributed.all_reduce(vl)
                 vl = vl / world
             row['val_loss'] = float(vl)
@@ -1722,7 +1764,7 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
             if improved and checkpoint_path:
                 torch.save(model.state_dict(), checkpoint_path)
         stop = patience is not None and not improved and bad >= patience  # Keras EarlyStopping: wait >= patience, tested on a non-improving epoch
-        if world > 1:  # belt and braces: one int per epoch, rank 0's decision wins
+        if coll:  # belt and braces: one int per epoch, rank 0's decision wins
             flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=loss.device)
             torch.distributed.broadcast(flag, src=0)
             stop = bool(int(flag.item()))
@@ -1787,7 +1829,7 @@ def main(argv=None):
             print('best model:', NAME.replace('.h5', '_SWA.pt'))
     except NO_SWA_ERROR:
         pass
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     if rank == 0:
         print(NAME.split('.h5')[0])

@@ -171,8 +171,12 @@ int iris_normalize(const float* wav, float* out, int n_rows, size_t row_len, flo
  * STFT of load_wav (data_utils.py:17-27): reflect-pad n_fft/2, frame at `hop`,
  * periodic Hann, one-sided FFT, no normalisation, written in the reference's
  * [B, F, T, 2C] re-block / im-block layout.
+ * flags: 0, or IRIS_F_NORMALIZE = `normalize` of load_wav (data_utils.py:22-23, :32-34: wav / (10 rms), rms over all
+ *        channels of a clip jointly) folded into the transform: one partial-sums launch, then the spectrum is scaled by
+ *        1 / (10 rms) as it is written (the STFT is linear) - the normalised waveform is never materialised.  Differs
+ *        from normalising first by the fp32 rounding of the scaled samples (<= 2e-6 of the spectrum's peak).
  */
-int iris_stft(iris_plan* plan, const float* wav, float* spec, int batch, int len,
+int iris_stft(iris_plan* plan, const float* wav, float* spec, int batch, int len, int flags,
               void* stream);
 
 /*
@@ -291,6 +295,8 @@ int iris_bias_relu_maxpool(const float* x, const float* bias, float* y, int batc
  *             recomputed from z with the forward's own expression, y is not read)
  *             iris_bn_relu_bwd_dx: dz = gamma rstd (g - sum_g / M - xhat sum_gx / M); dgamma = sum g xhat, dbeta = sum g
  * channels: a multiple of 4, <= 4096; every pointer DEVICE, 16-byte aligned tensors.  Run on the current HIP device.
+ * NOT in-place: y (and p below) must not overlap z - every block of the apply passes reads K back from row 0 of z while
+ * others write their outputs (IRIS_E_INVALID otherwise).
  */
 size_t iris_bn_sums_len(int channels);
 int iris_bn_stats(const float* z, size_t rows, int channels, double* sums_zeroed, void* stream);

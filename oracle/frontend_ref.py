@@ -657,6 +657,22 @@ def mel_tolerance(wav, n_fft, hop, n_mel, sample_rate=16000, t_bands=None, f_ban
     return ref, tol
 
 
+def mel_strict_rel_err(mel, ref, tol, rel=MEL_REL_TOL):
+    """(worst |mel - ref| / |ref|, fraction of elements covered) over the ORDINARY elements: those where the relative
+    term of `mel_tolerance` is at least the noise-floor term (rel |ref| >= tol - rel |ref|, i.e. |ref| >= 0.048 xrms sum W
+    with the default constants - ~99 % of the elements of a white-noise input even on the reference's one-bin bands).
+    On them north_star's bound is asserted LITERALLY: the result must be <= 1e-5.  The noise-floor term only decides the
+    remaining elements - bins far below their frame's level, where the "relative error" of any fp32 transform is
+    (absolute rounding noise) / (a value near 0)."""
+    ref = np.asarray(ref, np.float64)
+    rel_term = rel * np.abs(ref)
+    ordinary = (rel_term >= (tol - rel_term)) & (ref != 0)
+    if not np.any(ordinary):
+        return 0.0, 0.0
+    d = np.abs(np.asarray(mel, np.float64) - ref)
+    return float((d[ordinary] / np.abs(ref[ordinary])).max()), float(ordinary.mean())
+
+
 def mel_err_ratio(mel, ref, tol) -> float:
     """max |mel - ref| / tol over the elements (<= 1 passes); elements with tol == 0 must be exact."""
     d = np.abs(np.asarray(mel, np.float64) - ref)

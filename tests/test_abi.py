@@ -99,6 +99,7 @@ def test_round3_entry_points_validate_before_any_launch():
     assert lib.iris_bn_stats(p16, 16, 6, p16, None) == UNSUPPORTED
     assert lib.iris_bn_stats(p16, 16, 8192, p16, None) == UNSUPPORTED         # more than 4096 channels
     assert lib.iris_bn_relu_apply(None, None, 16, 8, None, None, None, None, 1e-3, 0.01, None, None, None, None, None) == INVALID
+    assert lib.iris_bn_relu_apply(p16, p16, 16, 8, p16, p16, p16, None, 1e-3, 0.01, p16, p16, p16, p16, None) == INVALID  # y aliases z
     assert lib.iris_bn_relu_bwd_reduce(None, p16, 16, 8, p16, p16, p16, p16, p16, None) == INVALID
     assert lib.iris_bn_relu_bwd_dx(None, p16, p16, 16, 8, p16, p16, p16, p16, p16, p16, p16, None) == INVALID
     assert lib.iris_mix_draw(None, None, None, 1, 64, 4, 4, 0.5, 1.0, 1.0, 7, None, None, None, None) == INVALID
@@ -155,22 +156,30 @@ def test_product_package_never_imports_oracle():
                 assert "import oracle" not in text and "from oracle" not in text, fn
 
 
-def test_hot_kernels_use_no_scratch_and_fit_their_wave_budget(tmp_path):
-    """Static check on the device assembly (hipcc cross-compiles here): no variant of the fused kernel, the STFT kernel or the
-    min-max / log kernel may use scratch memory (a kernel with scratch pays ~5 us more per dispatch on this chip, and a spill
-    inside the frame loop costs far more - both happened silently during round 4 before this test existed), and every fused
-    variant must fit the register budget of the wave count it is launched with (`fused_waves`: 16 waves = 128 VGPRs,
-    12 = 168, 8 = 256)."""
-    import re
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    """The device assembly of the library as `make all` compiles it (hipcc cross-compiles gfx950 here, ~30 s, once per module)."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "challenge_amd", "csrc", "iris_frontend.hip")
-    asm = str(tmp_path / "iris_frontend.s")
+    asm = str(tmp_path_factory.mktemp("asm") / "iris_frontend.s")
     subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-S", "--cuda-device-only",
                     "-o", asm, src], check=True, capture_output=True)
+    return asm
+
+
+def test_hot_kernels_use_no_scratch_and_fit_their_wave_budget(device_asm):
+    """Static check on the device assembly (hipcc cross-compiles here): no variant of the fused kernel, the STFT kernel or the
+    min-max / log kernel may use scratch memory (a kernel with scratch pays ~5 us more per dispatch on this chip, and a spill
+    inside the frame loop costs far more - both happened silently during round 4 before this test existed), and every fused
+    variant must fit the register budget of the wave count it is launched with (`fused_waves`: 16 waves = 128 VGPRs,
+    12 = 168, 8 = 256)."""
+    import re
+    import subprocess
+    asm = device_asm
     name, cur, rows = None, {}, []
     for line in open(asm):
         m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", line)
@@ -202,3 +211,49 @@ def test_hot_kernels_use_no_scratch_and_fit_their_wave_budget(tmp_path):
             waves = 16
         budget = {16: 128, 12: 168, 8: 256}[waves]
         assert c["next_free_vgpr"] <= budget, (d, c["next_free_vgpr"], budget)
+
+
+def test_hand_set_vmcnt_has_enough_loads_behind_the_staging_rows(device_asm):
+    """The fused kernel stages its constant block by LDS-DMA (`global_load_lds_dwordx4` from inline asm) BEFORE the first frame
+    loads and waits for it with a hand-set `s_waitcnt vmcnt(P)` (csrc/k_fused.h: a wave's vector-memory operations return in
+    order, so once at most P are outstanding the older staging rows have landed).  That is only correct while the compiler
+    really issues AT LEAST P vector-memory loads between the last staging row and the wait on every path that loads a frame:
+    if it ever merges, widens or sinks those loads, constants would be read from LDS before they arrive - silently wrong
+    twiddles / window / mel weights.  Checked here on the assembly of every variant: each basic block between the staging
+    loop and the hand-set wait that holds frame loads holds >= P of them."""
+    import re
+    text = open(device_asm).read()
+    fns = re.split(r"\n(?=_Z12k_wav_to_melILi\d+E[^\n]*:\s)", text)
+    checked = 0
+    for fn in fns[1:]:
+        head = fn.split(":", 1)[0]
+        body = fn.split(".end_amdhsa_kernel")[0] if ".end_amdhsa_kernel" in fn else fn
+        body = body.split("s_endpgm")[0]
+        lines = body.split("\n")
+        # the hand-set wait: `s_waitcnt vmcnt(N)`, N > 0, as the only instruction of an inline-asm statement
+        wait_at, n_wait = None, None
+        for i, ln in enumerate(lines):
+            m = re.match(r"\s*s_waitcnt vmcnt\((\d+)\)\s*$", ln)
+            if m and int(m.group(1)) > 0 and i > 0 and "ASMSTART" in lines[i - 1] and "ASMEND" in lines[i + 1]:
+                wait_at, n_wait = i, int(m.group(1))
+                break
+        if wait_at is None:
+            continue   # variants without direct frame loads have no hand-set wait
+        log2n = int(re.match(r"_Z12k_wav_to_melILi(\d+)E", head).group(1))
+        assert n_wait == (1 << log2n) // 128, (head, n_wait)   # P = points per lane
+        dma = [i for i in range(wait_at) if "global_load_lds_dwordx4" in lines[i]]
+        assert dma, head
+        # basic blocks of the region in between: split at labels and branches
+        blocks, cur = [], 0
+        for ln in lines[dma[-1] + 1:wait_at]:
+            t = ln.strip()
+            if re.match(r"\.LBB\d+_\d+:", t) or t.startswith(("s_cbranch", "s_branch")):
+                blocks.append(cur)
+                cur = 0
+            elif re.match(r"global_load_(dword|dwordx2|dwordx3|dwordx4|ubyte|ushort)\b", t):
+                cur += 1
+        blocks.append(cur)
+        loaded = [b for b in blocks if b]
+        assert loaded and min(loaded) >= n_wait, (head, n_wait, blocks)
+        checked += 1
+    assert checked >= 40, checked   # every direct-load variant of the fused kernel (with / without epilogue, bands, mel modes)

@@ -36,12 +36,23 @@ def rel_err(a, ref, floor=1e-3):
 
 
 def assert_mel(mel, wav, n_fft, hop, n_mel, sr=16000, **kw):
-    """The stated mel tolerance (module docstring) against the fp64 oracle of `wav`; returns the worst ratio."""
+    """The stated mel tolerance (module docstring) against the fp64 oracle of `wav`; returns the worst ratio.
+    Two assertions: the rule on EVERY element, and north_star's literal 1e-5 relative error on every ordinary element
+    (those where the rule's relative term is at least its noise-floor term: `R.mel_strict_rel_err`)."""
     ref, tol = R.mel_tolerance(wav, n_fft, hop, n_mel, sr, **kw)
     assert mel.shape == ref.shape, (mel.shape, ref.shape)
     ratio = R.mel_err_ratio(mel, ref, tol)
+    strict, covered = R.mel_strict_rel_err(mel, ref, tol)
+    print(f"mel n_fft {n_fft} M {n_mel} {mel.shape}: rule ratio {ratio:.3f}, strict rel-err {strict:.2e} on {100 * covered:.2f} % of "
+          f"the elements, rel-err with the 1e-3 floor {rel_err(mel, ref):.2e}")
     assert ratio <= 1.0, f"mel error {ratio:.3f} x the stated tolerance (n_fft {n_fft}, {n_mel} mel)"
+    assert strict <= 1e-5, f"mel relative error {strict:.2e} > 1e-5 on an ordinary element (n_fft {n_fft}, {n_mel} mel)"
     return ratio
+
+
+# the bound the committed golden mel vectors were accepted under (SURVEY 8(d): max |d| / max(|ref|, 1e-3)); the reference's
+# default shape (80 mel over 257 bins: one-bin bands) reads up to 2e-5 under it for every fp32 engine, the others 1e-5
+GOLDEN_MEL_BOUND = {"refdefault_stereo": 2e-5}
 
 
 def make_plan(g, dev, batch=1, **kw):
@@ -75,6 +86,8 @@ def test_fused_mel_matches_golden(golden_dir, dev, name):
     wav = torch.from_numpy(g["wav"][None]).to(dev)
     mel = plan.wav_to_logmel(wav, minmax=False, log=False).cpu().numpy()[0]
     assert mel.shape == g["mel"].shape
+    # against the COMMITTED vector (independent of today's oracle code and mel matrix), at the bound it was accepted under
+    assert rel_err(mel, g["mel"]) <= GOLDEN_MEL_BOUND.get(name, 1e-5), rel_err(mel, g["mel"])
     assert_mel(mel[None], g["wav"][None], int(g["n_fft"]), int(g["hop"]), int(g["n_mel"]), float(g["sample_rate"]))
     logmel = plan.wav_to_logmel(wav).cpu().numpy()[0]
     assert np.abs(np.exp(logmel) - np.exp(g["logmel"])).max() <= 5e-6
@@ -91,6 +104,7 @@ def test_unfused_chain_equals_fused(golden_dir, dev, name):
     wav = torch.from_numpy(g["wav"][None]).to(dev)
     spec = plan.stft(wav)
     mel = plan.magmel(spec)
+    assert rel_err(mel.cpu().numpy()[0], g["mel"]) <= GOLDEN_MEL_BOUND.get(name, 1e-5)  # the committed vector, old bound
     assert_mel(mel.cpu().numpy(), g["wav"][None], int(g["n_fft"]), int(g["hop"]), int(g["n_mel"]), float(g["sample_rate"]))
     magphase = FE().complex_to_magphase(spec)
     mel2 = plan.magmel(magphase, is_magphase=True)
@@ -202,6 +216,17 @@ def test_normalize_flag_and_op(dev):
     # of full scale instead of per-element relative error.
     assert np.abs(fused - ref).max() <= 2e-6 * np.abs(ref).max()
     assert_mel(fused, ref_norm, 512, 256, 80, 16000)
+    # the same flag on the STFT (load_wav's normalize + Spectrogram as one transform launch): the spectrum is scaled as it is
+    # written; equal to normalising first up to the fp32 rounding of the scaled samples, per clip over all channels jointly
+    x = torch.from_numpy(raw).to(dev)
+    folded = plan.stft(x, normalize=True).cpu().numpy()
+    first = plan.stft(FE().normalize(x)).cpu().numpy()
+    oracle = np.stack([R.to_ref_layout(R.stft(ref_norm[i], 512, 256)) for i in range(3)])
+    for i in range(3):
+        peak = np.abs(oracle[i]).max()
+        assert np.abs(folded[i] - first[i]).max() <= 2e-6 * peak and np.abs(folded[i] - oracle[i]).max() <= 3e-6 * peak
+    with pytest.raises(ValueError):
+        FE().N.check(FE().N.lib().iris_stft(plan._handle, x.data_ptr(), x.data_ptr(), 3, 7000, 1, None), "iris_stft")  # IRIS_F_MINMAX
 
 
 def test_minmax_log_generic(dev):
@@ -276,6 +301,64 @@ def test_linearity_and_silence_at_full_size(dev):
     un = plan.magmel(sa)
     fu = plan.wav_to_logmel(a.to(dev), minmax=False, log=False)
     assert float(((un - fu).abs() / un.abs().clamp_min(1e-3)).max()) <= 2e-6
+
+
+def _augment_bands(rng, b, n_t, n_f):
+    """`augment` + stft_filter(3) as band lists: six time bands of < 24 frames, one frequency band of < 16 linear bins
+    (data_utils.py:58-61, transforms.py:12-40), bins 1..3 zeroed (data_utils.py:126-136, sj_train.py:117)."""
+    tb = np.stack([np.stack(R.mask_draw(rng, n_t, 24, 6), 1) for _ in range(b)]).astype(np.int32)
+    fb = np.zeros((b, 2, 2), np.int32)
+    for i in range(b):
+        off, size = R.mask_draw(rng, n_f, 16, 1)
+        fb[i, 0] = [off[0], size[0]]
+        fb[i, 1] = [1, 3]
+    return tb, fb
+
+
+def test_c2_full_size_matches_oracle(dev):
+    """BASELINE configs[1] AT ITS FULL SIZE (32 x 10 s mono, n_fft 1024, hop 256, 64 mel - the bench headline) against
+    the fp64 oracle, element by element: the one-launch fused-epilogue form that bench.py times, with and without the
+    SpecAugment / stft_filter bands, plus the log-mel output against the oracle's."""
+    rng = np.random.default_rng(1234)
+    b, length = 32, 160000
+    wav = R.normalize(rng.standard_normal((b, length)).astype(np.float32)).reshape(b, 1, length)
+    plan = FE().FrontendPlan(1024, 256, 64, 16000, 1, b, length, dev)
+    assert plan.epilogue == "fused"
+    x = torch.from_numpy(wav).to(dev)
+    tb, fb = _augment_bands(rng, b, 1 + length // 256, 513)
+    for kw in ({}, {"t_bands": tb, "f_bands": fb}):
+        mel = plan.wav_to_logmel(x, minmax=False, log=False, **kw).cpu().numpy()
+        assert mel.shape == (b, 64, 626, 1)
+        assert_mel(mel, wav, 1024, 256, 64, 16000, **kw)
+        plan.timing_enable(1)
+        for _ in range(5):   # the first 4 calls after enabling are never sampled
+            logmel = plan.wav_to_logmel(x, **kw)
+        torch.cuda.synchronize()
+        assert len(plan.timing_samples(0)) >= 1 and len(plan.timing_samples(1)) == 0, "the step was not ONE launch"
+        plan.timing_enable(False)
+        ref_log = R.wav_to_logmel(wav, 1024, 256, 64, 16000, **kw)
+        assert np.abs(np.exp(logmel.cpu().numpy()) - np.exp(ref_log)).max() <= 5e-6
+    plan.raise_on_failure()
+
+
+def test_c5_full_size_matches_oracle(dev):
+    """BASELINE configs[4] at full size (16 x 10 s stereo at 22.05 kHz, n_fft 2048, hop 512, 128 mel) in the DEFAULT fp32
+    banded form, against the fp64 oracle (the fp16-MFMA variant has its own test at 2e-3)."""
+    rng = np.random.default_rng(2205)
+    b, c, length = 16, 2, 220500
+    wav = np.stack([R.normalize(rng.standard_normal((c, length)).astype(np.float32)) for _ in range(b)])
+    plan = FE().FrontendPlan(2048, 512, 128, 22050, c, b, length, dev)
+    assert plan.mel_precision == "fp32"
+    x = torch.from_numpy(wav).to(dev)
+    mel = plan.wav_to_logmel(x, minmax=False, log=False).cpu().numpy()
+    assert mel.shape == (b, 128, 431, 2)
+    assert_mel(mel, wav, 2048, 512, 128, 22050)
+    logmel = plan.wav_to_logmel(x).cpu().numpy()
+    assert np.abs(np.exp(logmel) - np.exp(R.wav_to_logmel(wav, 2048, 512, 128, 22050))).max() <= 5e-6
+    tb, fb = _augment_bands(rng, b, 431, 1025)
+    mel = plan.wav_to_logmel(x, minmax=False, log=False, t_bands=tb, f_bands=fb).cpu().numpy()
+    assert_mel(mel, wav, 2048, 512, 128, 22050, t_bands=tb, f_bands=fb)
+    plan.raise_on_failure()
 
 
 @pytest.mark.parametrize("n_fft,hop,m,c", [(512, 256, 80, 2), (2048, 512, 128, 2), (256, 64, 40, 1), (1024, 256, 64, 2)])

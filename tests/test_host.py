@@ -327,9 +327,20 @@ def test_bench_cpu_baseline_leg_runs_without_gpu():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     bench = importlib.import_module("bench")
     wav = (np.random.default_rng(0).standard_normal((2, 1, 16000)) * 0.1).astype(np.float32)
-    r = bench.cpu_baseline(wav)
+    r, ref_logmel = bench.cpu_baseline(wav)
     assert r["kind"] == "port" and r["unit"] == "audio-s/s" and r["value"] > 0 and r["cores"] >= 1
     assert r["value"] == max(r["numpy_1thread"], r["torch_best"])
+    # the parity leg of the same line (bench.parity): fed with the torch-CPU fp32 path in the GPU's place it must pass, and a
+    # result that is off by 1e-4 must fail it
+    from oracle import frontend_ref as R
+    from oracle.torch_cpu_ref import wav_to_logmel_cpu
+    assert ref_logmel.shape == (2, 64, 63, 1)
+    mel32 = R.wav_to_mel(wav, 1024, 256, 64, 16000)
+    par = bench.parity(wav, ref_logmel, mel32, ref_logmel)
+    assert par["ok"] and par["mel_rule_ratio"] <= 1.0 and par["mel_strict_rel_err"] <= 1e-5 and par["logmel_exp_abs"] == 0.0
+    assert 0 < par["mel_rel_err_floor_1e-3"] <= 1e-5 and par["mel_strict_covers"] > 0.9
+    bad = bench.parity(wav, ref_logmel, mel32 * np.float32(1.0001), ref_logmel)
+    assert not bad["ok"] and bad["mel_rule_ratio"] > 1.0
 
 
 def test_bench_gpus_argument_without_devices():
