@@ -485,7 +485,7 @@ def batch_sweep(dev, fence, steps):
         # from B = 128 on a chunk's mel tile no longer fits the LDS at this geometry: the library takes the two-kernel form by
         # itself, and `k1_us` is then the fused kernel WITHOUT the epilogue (the second kernel is listed beside it)
         rows.append({"batch": b, "distinct_batches": copies, "bytes_touched_per_cycle": copies * per_batch,
-                     "form": "two_kernels" if len(k2) else "fused_epilogue",
+                     "form": "two_kernels" if len(k2) else "fused_epilogue", "epilogue": plan.last_epilogue(),
                      "second_kernel_us": round(1e3 * float(k2.mean()), 2) if len(k2) else None,
                      "k1_us": round(1e3 * k_ms, 2), "k1_us_median": round(1e3 * float(np.median(k)), 2) if len(k) else None,
                      "k1_frac_of_8TBs": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -539,6 +539,7 @@ def config_rooflines(dev, fence, steps):
         plan.timing_enable(False)
         k_ms = float(k.mean()) + (float(k2.mean()) if len(k2) else 0.0)
         rows[name] = {"kernel": plan.fused_kernel_name(with_bands=bands), "form": "two_kernels" if len(k2) else "fused_epilogue",
+                      "epilogue": plan.last_epilogue(),
                       "algorithmic_bytes_per_launch": algo, "kernel_us": round(1e3 * k_ms, 2), "step_us": round(1e6 * dt, 2),
                       "frac_of_8TBs": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "step_frac_of_8TBs": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4),

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("IRIS_LIB") or os.path.join(_HERE, "csrc", "libiris_fr
 
 IRIS_F_MINMAX, IRIS_F_LOG, IRIS_F_NORMALIZE = 1, 2, 4
 IRIS_MEL_F32, IRIS_MEL_F16_MFMA = 0, 1
-IRIS_EPILOGUE_FUSED, IRIS_EPILOGUE_TWO_KERNELS = 0, 1
+IRIS_EPILOGUE_FUSED, IRIS_EPILOGUE_TWO_KERNELS, IRIS_EPILOGUE_IN_PLACE = 0, 1, 2
 IRIS_E_EPILOGUE_TIMEOUT = -5
 
 # every symbol include/iris_frontend.h declares, with (restype, argtypes)
@@ -73,6 +73,7 @@ SIGNATURES = {
     "iris_bias_relu_nchw": (_i, [_vp, _vp, _sz, _i, _sz, _vp]),
     "iris_bias_relu_maxpool_nchw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "iris_plan_kernel_name": (_i, [_vp, _i, C.c_char_p, _i]),
+    "iris_plan_last_epilogue": (_i, [_vp, C.POINTER(_i)]),
     "iris_timing_enable": (_i, [_vp, _i]),
     "iris_timing_read": (_i, [_vp, C.POINTER(_i), _fp]),
     "iris_timing_samples": (_i, [_vp, _i, _fp, _i, C.POINTER(_i)]),

@@ -94,6 +94,7 @@ struct iris_plan {
     size_t n_slots;
     unsigned epoch;  // launches of the fused-epilogue kernel so far (granule tag; never 0)
     int epilogue;    // IRIS_EPILOGUE_*
+    int last_form;   // form the last iris_wav_to_logmel call of this plan took: IRIS_EPILOGUE_* (-1: none yet / nothing to apply)
     unsigned long long* d_dbg;  // diagnostic stamps (IRIS_DIAG builds only; nullptr otherwise)
     int ablate;                 // IRIS_DIAG builds: IRIS_ABLATE bits, read once at plan creation
     bool magmel_generic;        // IRIS_MAGMEL_GENERIC set at plan creation: iris_magmel takes the generic kernel

@@ -211,7 +211,7 @@ static void fused_geometry(const iris_plan* p, int batch, int T, int per_cu, int
 // Geometry + grid of the fused kernel: one workgroup per CU (every wave the registers allow), checked once per
 // (kernel, batch, frames) against the occupancy the hardware really grants and cached in the plan - the hot launch
 // path does no runtime query.
-static int fused_config(iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, bool bands, bool fuse,
+static int fused_config(iris_plan* p, fused_kernel_t kernel, int batch, int T, int streams, bool bands, int fuse,
                         int* chunk_frames, int* chunks_per_clip, int* grid, size_t* lds) {
     for (const iris_plan::FusedGeom& g : p->geom_cache)
         if (g.kernel == (const void*)kernel && g.batch == batch && g.T == T) {
@@ -223,7 +223,7 @@ static int fused_config(iris_plan* p, fused_kernel_t kernel, int batch, int T, i
         }
     fused_geometry(p, batch, T, 1, chunk_frames, chunks_per_clip);
     *lds = fused_lds_bytes(p, streams, bands, *chunk_frames, fuse);
-    if (fuse) *lds = fused_tile_off(*lds) + fused_tile_bytes(p, streams, bands, *chunk_frames);
+    if (fuse) *lds = fused_tile_off(*lds) + fused_tile_bytes(p, streams, bands, *chunk_frames, fuse);
     *grid = std::min(batch * *chunks_per_clip, p->num_cu);
     if (p->geom_cache.size() >= 64) p->geom_cache.clear();
     if (*lds > 160 * 1024) {
@@ -295,10 +295,13 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     // min-max / log inside the kernel (one launch) unless: nothing to apply, the MFMA variant, two frame streams
     // (diag), the plan says two kernels, the stream is being captured (the epoch is a host counter: it would be
     // frozen in the graph), or the chunk's mel tile does not fit the LDS
-    bool fuse = (do_minmax || do_log) && !mfma && streams == 1 && p->epilogue == IRIS_EPILOGUE_FUSED;
+    // fuse: 0 = two kernels, 1 = epilogue from the chunk's LDS tile, 2 = epilogue in place through `out` (chunks whose tile does
+    // not fit the LDS: whole clips per workgroup at large batches; or the plan asks for it, IRIS_EPILOGUE_IN_PLACE)
+    int fuse = ((do_minmax || do_log) && !mfma && streams == 1 && p->epilogue != IRIS_EPILOGUE_TWO_KERNELS)
+                   ? (p->epilogue == IRIS_EPILOGUE_IN_PLACE ? 2 : 1) : 0;
     if (fuse) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) fuse = false;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) fuse = 0;
     }
     fused_kernel_t kernel = nullptr;
     int grid = 0;
@@ -312,17 +315,22 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         lds = mfma_lds_bytes(p);
         grid = std::min(batch * a.chunks_per_clip, p->num_cu);
     } else {
-        if (fuse) {
-            kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams, true);
-            rc = fused_config(p, kernel, batch, a.T, streams, bands, true, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds);
-            // no fused epilogue when the tile does not fit, or when a clip has more chunks than the grid has workgroups
-            // (a workgroup would then wait for a chunk it has yet to process itself)
-            if (rc == IRIS_E_UNSUPPORTED || (size_t)batch * a.chunks_per_clip > p->n_slots || a.chunks_per_clip > grid) fuse = false;
-            else if (rc) return rc;
+        for (; fuse == 1 || fuse == 2; ++fuse) {
+            kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams, fuse);
+            rc = fused_config(p, kernel, batch, a.T, streams, bands, fuse, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds);
+            // no fused epilogue when a clip has more chunks than the grid has workgroups (a workgroup would then wait for a
+            // chunk it has yet to process itself); when the LDS tile does not fit, the in-place form is next
+            if ((size_t)batch * a.chunks_per_clip > p->n_slots || a.chunks_per_clip > grid) {
+                fuse = 0;
+                break;
+            }
+            if (rc == IRIS_OK) break;
+            if (rc != IRIS_E_UNSUPPORTED) return rc;
         }
+        if (fuse > 2) fuse = 0;
         if (!fuse) {
-            kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams, false);
-            if ((rc = fused_config(p, kernel, batch, a.T, streams, bands, false, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
+            kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams, 0);
+            if ((rc = fused_config(p, kernel, batch, a.T, streams, bands, 0, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))
                 return rc;
         }
     }
@@ -333,11 +341,12 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     a.tile_off = a.pitch = 0;
     a.do_minmax = do_minmax;
     a.do_log = do_log;
+    p->last_form = (do_minmax || do_log) ? (fuse == 1 ? IRIS_EPILOGUE_FUSED : (fuse == 2 ? IRIS_EPILOGUE_IN_PLACE : IRIS_EPILOGUE_TWO_KERNELS)) : -1;
     if (fuse) {
         if (++p->epoch == 0) p->epoch = 1;
         a.epoch = p->epoch;
-        a.pitch = fused_tile_pitch(p, a.chunk_frames);
-        a.tile_off = (int)fused_tile_off(fused_lds_bytes(p, streams, bands, a.chunk_frames, true));
+        a.pitch = fuse == 1 ? fused_tile_pitch(p, a.chunk_frames) : 0;
+        a.tile_off = (int)fused_tile_off(fused_lds_bytes(p, streams, bands, a.chunk_frames, fuse));
     }
     if ((size_t)p->n_mel * a.T * p->channels * 4 > 0xffffffffull || (size_t)a.T * p->channels * 4 >= (1u << 24))
         return fail(IRIS_E_UNSUPPORTED, "iris_wav_to_logmel: clip too long (%d frames x %d channels)", a.T, p->channels);
@@ -484,7 +493,7 @@ static int bn_check(const void* a, const void* b, size_t rows, int channels, con
         return fail(IRIS_E_UNSUPPORTED, "%s: rows %zu, channels %d (a positive multiple of 4, <= 4096)", who, rows, channels);
     return IRIS_OK;
 }
-static bool bn_overlap(const float* z, const float* y, size_t n_z) { return y < z + n_z && z < y + n_z; }
+static bool bn_overlap(const float* z, size_t n_z, const float* y, size_t n_y) { return y < z + n_z && z < y + n_y; }
 static int grid_bn(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 2048); }  // fat blocks: the per-block coefficient setup is amortised
 static unsigned bn_reduce_grid(size_t rows, int C4, int rows_per_pass = kBnRows) {
     const int cols = std::min(C4, 256), tys = 256 / cols;
@@ -516,7 +525,7 @@ extern "C" int iris_bn_relu_apply(const float* z, float* y, size_t rows, int cha
         return fail(IRIS_E_INVALID, "iris_bn_relu_apply: NULL argument");
     // every block re-reads K = row 0 of z (the shift of the sums) while other blocks write y: in place, a block could
     // overwrite row 0 before its neighbours have read K
-    if (bn_overlap(z, y, rows * (size_t)channels)) return fail(IRIS_E_INVALID, "iris_bn_relu_apply: y must not overlap z (not an in-place op)");
+    if (bn_overlap(z, rows * (size_t)channels, y, rows * (size_t)channels)) return fail(IRIS_E_INVALID, "iris_bn_relu_apply: y must not overlap z (not an in-place op)");
     const size_t n4 = rows * (size_t)(channels / 4);
     const double m = (double)rows;
     k_bn_relu_apply<<<grid_bn(n4), 256, 2 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(z, y, n4, channels / 4, 1.0 / m, rows > 1 ? m / (m - 1.0) : 1.0, sums,
@@ -566,7 +575,8 @@ extern "C" int iris_bn_relu_pool_apply(const float* z, float* p, int batch, int 
                                        float* running_mean, float* running_var, float* save_mean, float* save_rstd, void* stream) {
     int rc = bn_pool_check(z, p, batch, height, width, channels, "iris_bn_relu_pool_apply");
     if (rc) return rc;
-    if (bn_overlap(z, p, (size_t)batch * height * width * channels)) return fail(IRIS_E_INVALID, "iris_bn_relu_pool_apply: p must not overlap z");
+    if (bn_overlap(z, (size_t)batch * height * width * channels, p, (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2) * channels))
+        return fail(IRIS_E_INVALID, "iris_bn_relu_pool_apply: p must not overlap z");
     if (!sums || !gamma || !beta || !running_mean || !running_var || !save_mean || !save_rstd)
         return fail(IRIS_E_INVALID, "iris_bn_relu_pool_apply: NULL argument");
     const size_t n4 = (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
@@ -613,9 +623,9 @@ extern "C" int iris_plan_kernel_name(const iris_plan* p, int with_bands, char* o
     if (p->mel_precision == 1 && !with_bands)
         snprintf(out, (size_t)capacity, "k_wav_to_mel_mfma<%d>", p->log2n);
     else
-        snprintf(out, (size_t)capacity, "k_wav_to_mel<%d,%d,%s,%s,1,%s>", p->log2n, p->mel_mode,
+        snprintf(out, (size_t)capacity, "k_wav_to_mel<%d,%d,%s,%s,1,%d>", p->log2n, p->mel_mode,
                  (p->need_hi && p->mel_mode != 0 && p->mel_mode != 3) ? "true" : "false", with_bands ? "true" : "false",
-                 p->epilogue == IRIS_EPILOGUE_FUSED ? "true" : "false");
+                 p->epilogue == IRIS_EPILOGUE_FUSED ? 1 : (p->epilogue == IRIS_EPILOGUE_IN_PLACE ? 2 : 0));
     return IRIS_OK;
 }
 

@@ -155,7 +155,7 @@ static int plan_streams(const iris_plan* p) {
 
 // LDS of the fused kernel: landing + exchange buffers of every wave (the constant block is
 // staged through the exchange area once), the frame queue, the MELMODE 1 tables
-static size_t fused_lds_bytes(const iris_plan* p, int streams, bool bands, int chunk_frames = 0, bool fuse = false) {
+static size_t fused_lds_bytes(const iris_plan* p, int streams, bool bands, int chunk_frames = 0, int fuse = 0) {
     const size_t xbuf = (wave_buf_bytes(p->log2n) + 15) & ~(size_t)15;
     const size_t waves = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse, p->mel_mode) * streams;
     const size_t stage = (size_t)const_nv4(p->log2n) * 64 * 16;
@@ -170,20 +170,21 @@ static size_t fused_lds_bytes(const iris_plan* p, int streams, bool bands, int c
 // fused epilogue: mel tile [M][pitch] (+ the workgroup's reduction scratch) behind everything else, 16-byte aligned
 static int fused_tile_pitch(const iris_plan* p, int chunk_frames) { return (chunk_frames * p->channels) | 1; }
 static size_t fused_tile_off(size_t lds_without_tile) { return (lds_without_tile + 15) & ~(size_t)15; }
-static size_t fused_tile_bytes(const iris_plan* p, int streams, bool bands, int chunk_frames) {
-    const size_t waves = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, true, p->mel_mode);
-    return ((size_t)p->n_mel * fused_tile_pitch(p, chunk_frames) + 2 * waves + 4) * 4;
+// (fuse 2 - the in-place form - keeps only the reduction scratch there)
+static size_t fused_tile_bytes(const iris_plan* p, int streams, bool bands, int chunk_frames, int fuse = 1) {
+    const size_t waves = (size_t)fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse, p->mel_mode);
+    return ((fuse == 1 ? (size_t)p->n_mel * fused_tile_pitch(p, chunk_frames) : 0) + 2 * waves + 4) * 4;
 }
 
 typedef void (*fused_kernel_t)(const FusedArgs);
 
-template <int LOG2N, int MELMODE, int S, bool FUSE>
+template <int LOG2N, int MELMODE, int S, int FUSE>
 static fused_kernel_t fused_kernel_hb(bool hi, bool bands) {
     if (hi)
         return bands ? k_wav_to_mel<LOG2N, MELMODE, true, true, S, FUSE> : k_wav_to_mel<LOG2N, MELMODE, true, false, S, FUSE>;
     return bands ? k_wav_to_mel<LOG2N, MELMODE, false, true, S, FUSE> : k_wav_to_mel<LOG2N, MELMODE, false, false, S, FUSE>;
 }
-template <int LOG2N, int S, bool FUSE>
+template <int LOG2N, int S, int FUSE>
 static fused_kernel_t fused_kernel_mm(int mel_mode, bool hi, bool bands) {
     if constexpr (LOG2N <= 10) {
         if (mel_mode == 0)  // register weights exist only for the half-spectrum variant up to n_fft 1024
@@ -196,16 +197,18 @@ static fused_kernel_t fused_kernel_mm(int mel_mode, bool hi, bool bands) {
 }
 // two frame streams per wave exist for n_fft 512 / 1024, in diagnostic builds only
 template <int LOG2N>
-static fused_kernel_t fused_kernel_m(int mel_mode, bool hi, bool bands, int streams, bool fuse) {
+static fused_kernel_t fused_kernel_m(int mel_mode, bool hi, bool bands, int streams, int fuse) {
 #if IRIS_DIAG
     if constexpr (LOG2N == 9 || LOG2N == 10) {
-        if (streams == 2) return fused_kernel_mm<LOG2N, 2, false>(mel_mode, hi, bands);
+        if (streams == 2) return fused_kernel_mm<LOG2N, 2, 0>(mel_mode, hi, bands);
     }
 #endif
     (void)streams;
-    return fuse ? fused_kernel_mm<LOG2N, 1, true>(mel_mode, hi, bands) : fused_kernel_mm<LOG2N, 1, false>(mel_mode, hi, bands);
+    if (fuse == 2) return fused_kernel_mm<LOG2N, 1, 2>(mel_mode, hi, bands);
+    return fuse ? fused_kernel_mm<LOG2N, 1, 1>(mel_mode, hi, bands) : fused_kernel_mm<LOG2N, 1, 0>(mel_mode, hi, bands);
 }
-static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands, int streams, bool fuse = false) {
+// fuse: 0 = raw mel + per-wave partials (two-kernel form), 1 = epilogue from an LDS tile, 2 = epilogue in place through `out`
+static fused_kernel_t fused_kernel(int log2n, int mel_mode, bool hi, bool bands, int streams, int fuse = 0) {
     switch (log2n) {
         case 11: return fused_kernel_m<11>(mel_mode, hi, bands, streams, fuse);
         case 10: return fused_kernel_m<10>(mel_mode, hi, bands, streams, fuse);
@@ -243,8 +246,8 @@ static hipError_t allow_big_lds(const iris_plan* p) {
     for (int v = 0; v < (IRIS_DIAG ? 4 : 2); ++v) {
         const int streams = (v & 2) ? 2 : 1;
         if (streams == 2 && p->log2n != 9 && p->log2n != 10) continue;
-        for (int fuse = 0; fuse < (streams == 1 ? 2 : 1); ++fuse) {
-            e = hipFuncSetAttribute((const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, (v & 1) != 0, streams, fuse != 0),
+        for (int fuse = 0; fuse < (streams == 1 ? 3 : 1); ++fuse) {
+            e = hipFuncSetAttribute((const void*)fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, (v & 1) != 0, streams, fuse),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
             if (e != hipSuccess) return e;
         }
@@ -320,10 +323,14 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     p->timeout_ticks = kEpilogueTimeoutTicks;
     p->epoch = 0;
     p->epilogue = IRIS_EPILOGUE_FUSED;
+    p->last_form = -1;
     // a CU mask takes compute units away from this process without changing the device's reported CU count: the fused
     // epilogue's co-residency (grid <= CUs) would not hold, so such an environment starts on the two-kernel form
     if (getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK")) p->epilogue = IRIS_EPILOGUE_TWO_KERNELS;
-    if (const char* e = getenv("IRIS_EPILOGUE")) p->epilogue = atoi(e) == IRIS_EPILOGUE_TWO_KERNELS ? IRIS_EPILOGUE_TWO_KERNELS : IRIS_EPILOGUE_FUSED;
+    if (const char* e = getenv("IRIS_EPILOGUE")) {
+        const int v = atoi(e);
+        p->epilogue = (v == IRIS_EPILOGUE_TWO_KERNELS || v == IRIS_EPILOGUE_IN_PLACE) ? v : IRIS_EPILOGUE_FUSED;
+    }
     p->timing = 0;
     p->launch_no = 0;
     p->ev_used = 0;
@@ -678,7 +685,7 @@ extern "C" int iris_plan_set_mel_precision(iris_plan* p, int precision) {
 
 extern "C" int iris_plan_set_epilogue(iris_plan* p, int mode) {
     if (!p) return fail(IRIS_E_INVALID, "iris_plan_set_epilogue: NULL plan");
-    if (mode != IRIS_EPILOGUE_FUSED && mode != IRIS_EPILOGUE_TWO_KERNELS)
+    if (mode != IRIS_EPILOGUE_FUSED && mode != IRIS_EPILOGUE_TWO_KERNELS && mode != IRIS_EPILOGUE_IN_PLACE)
         return fail(IRIS_E_INVALID, "iris_plan_set_epilogue: unknown mode %d", mode);
     p->epilogue = mode;
     return IRIS_OK;
@@ -699,6 +706,12 @@ extern "C" int iris_plan_status(iris_plan* p, int* status) {
     DeviceGuard guard(p->device);
     HIP_TRY(hipDeviceSynchronize());  // every launch of the plan so far has finished (and its system-scope store landed)
     *status = take_status(p) ? 1 : 0;
+    return IRIS_OK;
+}
+
+extern "C" int iris_plan_last_epilogue(const iris_plan* p, int* form) {
+    if (!p || !form) return fail(IRIS_E_INVALID, "iris_plan_last_epilogue: NULL argument");
+    *form = p->last_form;
     return IRIS_OK;
 }
 

@@ -27,8 +27,11 @@
 //   BANDS     = SpecAugment / filter bands present (time bands: per-chunk bitmap, masked frames skip
 //               the transform; frequency bands: folded into the chunk's band weights)
 //   S         = frames in flight per wave (1; 2 exists in diagnostic builds for n_fft 512 / 1024 and measured slower)
-//   FUSE      = min-max / log inside the kernel (LDS mel tile + clip-level granule exchange, see the epilogue) instead of
-//               per-wave partials for a second kernel
+//   FUSE      = min-max / log inside the kernel (clip-level granule exchange, see the epilogue) instead of per-wave
+//               partials for a second kernel: 1 = the chunk's mel values wait in an LDS tile and reach HBM once, finished;
+//               2 = chunks whose tile would not fit the LDS (whole clips per workgroup at large batches): the raw mel
+//               goes to `out` as in the unfused form and the SAME workgroup finishes its chunk's rows in place once the
+//               clip's range is known - its own stores, a barrier apart, read back through L2 / Infinity Cache
 // ---------------------------------------------------------------------------
 // One workgroup per CU holding every wave of the CU: all waves are of one age class for the issue
 // arbiter (which favours older waves) and share one frame queue.
@@ -57,10 +60,11 @@ constexpr bool fused_direct(int log2n) { return IRIS_DIRECT_LOAD && log2n <= IRI
 #ifndef IRIS_FUSE2048_12
 #define IRIS_FUSE2048_12 1
 #endif
-#define IRIS_FUSE12(fuse, mel_mode) (!(fuse) || (IRIS_FUSE2048_12 && (mel_mode) != 2))
+#define IRIS_FUSE12(fuse, mel_mode) (!(fuse) || (IRIS_FUSE2048_12 && (mel_mode) != 2 && (fuse) != 2))
 // fuse: the variant applies min-max / log itself; its epilogue-only kernel arguments are loaded late (late_arg*), which
-// keeps twelve waves at n_fft 2048 free of scratch - except with the global band table (mel_mode 2), which stays at 8
-constexpr int fused_waves(int log2n, int streams = 1, bool bands = false, bool hi = false, bool fuse = false, int mel_mode = 1) {
+// keeps twelve waves at n_fft 2048 free of scratch - except with the global band table (mel_mode 2) and in the in-place
+// form (fuse 2: the frame loop also keeps the output row addressing live), which stay at 8
+constexpr int fused_waves(int log2n, int streams = 1, bool bands = false, bool hi = false, int fuse = 0, int mel_mode = 1) {
     return streams > 1 ? IRIS_S2_WAVES
                        : (log2n >= 11 ? ((IRIS_W2048 == 0 && fused_direct(11) && !bands && !hi && IRIS_FUSE12(fuse, mel_mode)) ? 12 : (IRIS_W2048 ? IRIS_W2048 : 8))
                                       : (log2n == 10 ? (bands ? 12 : IRIS_W1024) : 16));
@@ -223,7 +227,7 @@ __device__ __forceinline__ LateEpilogueArgs late_epilogue_args() {
 #define LATE64(field) late_arg64((unsigned)offsetof(FusedArgs, field))
 constexpr unsigned long long kEpilogueTimeoutTicks = 200000000ull;  // s_memrealtime runs at 100 MHz: 2 s
 
-template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S, bool FUSE>
+template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S, int FUSE>
 __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE), fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE) / 4) void k_wav_to_mel(const FusedArgs a) {
     constexpr int kFusedWaves = fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
         __syncthreads();
         // FUSE: the constants are (re)read from the staging area at the top of every chunk instead, so that they are
         // dead - and their 72 registers free - during the epilogue
-        if constexpr (!FUSE) load_consts<LOG2N>(reinterpret_cast<const float*>(stage), lane, tw, post, win, wreg, lo0);
+        if constexpr (FUSE == 0) load_consts<LOG2N>(reinterpret_cast<const float*>(stage), lane, tw, post, win, wreg, lo0);
         if constexpr (MELMODE == 1) {
             const int* fbc = nullptr;
             if constexpr (BANDS) {
@@ -391,8 +395,8 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
     }
     for (int chunk = g0; chunk < a.n_chunks; chunk += gridDim.x) {
         PH_BEGIN();
-        if constexpr (FUSE) {
-            static_assert(!FUSE || DIRECT, "the staging area must survive the frame loop");
+        if constexpr (FUSE != 0) {
+            static_assert(FUSE == 0 || DIRECT, "the staging area must survive the frame loop");
             load_consts<LOG2N>(reinterpret_cast<const float*>(smem), lane, tw, post, win, wreg, lo0);
         }
         const int b = chunk_clip(chunk);
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
             // LDS table where the chunk starts) instead of touching the magnitudes of every frame.
             if constexpr (MELMODE == 0) {
                 if (fb) {
-                    if (!FUSE && chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);  // pristine weights (not hoisted)
+                    if (FUSE == 0 && chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);  // pristine weights (not hoisted)
                     for (int i = 0; i < a.n_fb; ++i) {  // band bounds are wave-uniform (scalar loads)
                         const int off = fb[2 * i] - lo0, end = off + fb[2 * i + 1];
 #pragma unroll
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
             }
             if constexpr (MELMODE == 3) {  // two windows of 8 bins: wreg[0..7] at lo0 & 0xffff, wreg[8..15] at lo0 >> 16
                 if (fb) {
-                    if (!FUSE && chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);
+                    if (FUSE == 0 && chunk != g0) reload_wreg<LOG2N>(opaque(a.consts), lane, wreg);
                     for (int i = 0; i < a.n_fb; ++i) {
                         const int offa = fb[2 * i] - (lo0 & 0xffff), enda = offa + fb[2 * i + 1];
                         const int offb = fb[2 * i] - (lo0 >> 16), endb = offb + fb[2 * i + 1];
@@ -476,13 +480,13 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
         // (the whole output is a few MB).  No LDS tile, no workgroup barrier, no write-out phase:
         // after the prologue the waves only share the frame queue.
         // address = (uniform) out + ((b M T + t0) C + f) * 4  +  (per lane) m * T * C * 4
-        const unsigned rowpitch_b = FUSE ? 0u : (unsigned)a.T * (unsigned)a.C * 4u;
-        float* const chunk_out = FUSE ? nullptr : a.out + ((size_t)b * a.M * a.T + t0) * a.C;
+        const unsigned rowpitch_b = FUSE == 1 ? 0u : (unsigned)a.T * (unsigned)a.C * 4u;
+        float* const chunk_out = FUSE == 1 ? nullptr : a.out + ((size_t)b * a.M * a.T + t0) * a.C;
         // FUSE: the value goes to the chunk's LDS tile [M][pitch] instead (pitch is odd: the 64 lanes of a frame hit
         // 64 different banks); min-max / log and the coalesced write-out follow once the clip's range is known
         float* const tile = reinterpret_cast<float*>(smem + a.tile_off);
         auto store_band = [&](int fidx, int m, float v) {
-            if constexpr (FUSE) {
+            if constexpr (FUSE == 1) {
                 tile[__umul24((unsigned)m, (unsigned)a.pitch) + fidx] = v;
             } else {
                 const unsigned off = __umul24((unsigned)m, rowpitch_b);  // host checks rowpitch < 2^24
@@ -692,7 +696,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
         PH_BEGIN();
         mn = wave_min(mn);
         mx = wave_max(mx);
-        if constexpr (!FUSE) {
+        if constexpr (FUSE == 0) {
             // every wave leaves its own (min, max) partial for k_minmax_log_apply
             if (lane == 0) {
                 a.partial[((size_t)chunk * kFusedWaves + wv) * 2 + 0] = mn;
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
             // (1 / max(max - min, 1e-8)), ln(x + 1e-8) -> coalesced rows of out[b, m, t0 .. t0 + nt, :].  Every workgroup publishes before
             // it waits and all workgroups of the grid are resident (grid <= CUs), so the waits always complete; the
             // sweep is bounded all the same (status word + NaN output instead of a hang).
-            float* red = tile + (size_t)a.M * a.pitch;  // [2 * waves + 4]
+            float* red = tile + (FUSE == 1 ? (size_t)a.M * a.pitch : 0);  // [2 * waves + 4]
             int le = lane;  // epilogue lane index, hidden from loop-invariant code motion: per-lane addresses of the
             asm volatile("" : "+v"(le));  // epilogue must not be hoisted across the frame loop (they would spill there)
             const LateEpilogueArgs late = late_epilogue_args<(unsigned)offsetof(FusedArgs, out), (unsigned)offsetof(FusedArgs, slots),
@@ -715,6 +719,10 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
                 red[wv] = mn;
                 red[kFusedWaves + wv] = mx;
             }
+            // FUSE 2: the frame loop's stores were issued from inline asm, invisible to the compiler's wait-count pass - this
+            // wave's raw mel must have reached the L2 before any wave of the workgroup reads it back (a workgroup's waves
+            // share one vector L1, write-through: workgroup-scope visibility needs the wait and the barrier, no cache action)
+            if constexpr (FUSE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // tile complete, wave ranges visible
             if (ABL(512) && threadIdx.x == 0 && a.dbg) a.dbg[4 + kDbgWg * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
             if (wv == 0) {
@@ -783,7 +791,31 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
             int wstep = kFusedWaves;  // laundered like `we`: the two row strides below are chunk-invariant and would otherwise be
             asm volatile("" : "+s"(wstep));  // hoisted into scalar registers that live across the frame loop
             const size_t tstep = (size_t)wstep * a.pitch, gstep = (size_t)wstep * rowpitch_e;
-            int m = we, c0 = 0;
+            if constexpr (FUSE == 2) {
+                // In place: wave w finishes rows w, w + W, ... of ITS chunk's columns out[b, m, t0 .. t0 + nt, :] - four 256-byte
+                // pieces of a row in flight per trip, read back from where this workgroup's own frame loop put them
+                for (int m2 = we; m2 < a.M; m2 += kFusedWaves, grow += gstep) {  // uniform
+                    float* const row = reinterpret_cast<float*>(const_cast<char*>(grow));
+                    for (int c1 = 0; c1 < nwf; c1 += 4 * kWave) {  // uniform
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int idx = c1 + j * kWave + le;
+                            v[j] = idx < nwf ? row[idx] : 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int idx = c1 + j * kWave + le;
+                            float y = v[j];
+                            if (mm) y = (y - cmn) * inv;
+                            if (lg) y = __builtin_amdgcn_logf(y + 1e-8f) * 0.69314718055994530942f;  // = minmax_log_value, same bits
+                            if (failed) y = NAN;
+                            if (idx < nwf) row[idx] = y;
+                        }
+                    }
+                }
+            }
+            int m = FUSE == 2 ? a.M : we, c0 = 0;
             // software-pipelined by one trip: the next LDS read is in flight behind this trip's math and store
             float cur = (m < a.M && le < nwf) ? trow[le] : 0.f;
             while (m < a.M) {  // uniform

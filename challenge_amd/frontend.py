@@ -118,7 +118,7 @@ class FrontendPlan:
         self.mel_precision = "fp32"
         masked = "ROC_GLOBAL_CU_MASK" in os.environ or "HSA_CU_MASK" in os.environ  # the library starts such plans on two kernels
         env = os.environ.get("IRIS_EPILOGUE")
-        self.epilogue = "two_kernels" if (env == "1" or (masked and env is None)) else "fused"
+        self.epilogue = "two_kernels" if (env == "1" or (masked and env is None)) else ("in_place" if env == "2" else "fused")
         _LIVE_PLANS.add(self)
 
     @classmethod
@@ -157,9 +157,17 @@ class FrontendPlan:
         """'fused' (default): min-max / log inside the fused kernel, one launch per call.  'two_kernels': raw mel +
         per-wave partials, then the min-max / log kernel - for several plans running CONCURRENTLY on one device
         (see iris_plan_set_epilogue in include/iris_frontend.h); calls under hipGraph capture take it by themselves."""
-        code = {"fused": N.IRIS_EPILOGUE_FUSED, "two_kernels": N.IRIS_EPILOGUE_TWO_KERNELS}[mode]
+        code = {"fused": N.IRIS_EPILOGUE_FUSED, "two_kernels": N.IRIS_EPILOGUE_TWO_KERNELS, "in_place": N.IRIS_EPILOGUE_IN_PLACE}[mode]
         N.check(N.lib().iris_plan_set_epilogue(self._handle, code), "iris_plan_set_epilogue")
         self.epilogue = mode
+
+    def last_epilogue(self) -> Optional[str]:
+        """Form the last `wav_to_logmel` call took: 'fused' (min-max / log from the chunk's LDS tile), 'in_place' (one launch,
+        the workgroup finishes its rows of `out` in place: chunks too large for the tile), 'two_kernels'; None before the
+        first call or when neither min-max nor log was applied."""
+        form = C.c_int(-1)
+        N.check(N.lib().iris_plan_last_epilogue(self._handle, C.byref(form)), "iris_plan_last_epilogue")
+        return {N.IRIS_EPILOGUE_FUSED: "fused", N.IRIS_EPILOGUE_TWO_KERNELS: "two_kernels", N.IRIS_EPILOGUE_IN_PLACE: "in_place"}.get(form.value)
 
     def status(self) -> int:
         """0 = every bounded in-kernel wait of the fused epilogue completed so far; 1 = one gave up (clips written as

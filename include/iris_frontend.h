@@ -133,7 +133,13 @@ int iris_plan_set_mel_precision(iris_plan* plan, int precision);
  *                              good and returns IRIS_E_EPILOGUE_TIMEOUT: outputs of this plan since the last successful
  *                              iris_plan_status / since that call's predecessor are suspect.  Use TWO_KERNELS from the
  *                              start for pipelines that overlap plans.
+ *                              Shapes whose chunk does not fit the LDS tile (whole clips per workgroup: c2 geometry
+ *                              from batch 128 on) take the IN_PLACE form by themselves - still one launch.
  *   IRIS_EPILOGUE_TWO_KERNELS  fused kernel (raw mel + per-wave partials), then the min-max / log kernel.
+ *   IRIS_EPILOGUE_IN_PLACE     one launch like FUSED, without the LDS tile: the raw mel goes to `out` and the workgroup
+ *                              that wrote a chunk finishes its rows in place once the clip's range is known (same
+ *                              exchange, same co-residency rules, same bits).  What FUSED falls back to for large chunks;
+ *                              selectable for A/B runs.
  * A plan created while ROC_GLOBAL_CU_MASK or HSA_CU_MASK is set starts on TWO_KERNELS (a CU mask breaks the co-residency).
  * IRIS_EPILOGUE=1 in the environment at plan creation selects TWO_KERNELS (test / A-B hook; so do IRIS_CHUNK_FRAMES=n,
  * frames per chunk of the fused kernel, and IRIS_MAGMEL_GENERIC - test hooks read once per plan, never per launch).
@@ -144,7 +150,11 @@ int iris_plan_set_mel_precision(iris_plan* plan, int precision);
  */
 #define IRIS_EPILOGUE_FUSED 0
 #define IRIS_EPILOGUE_TWO_KERNELS 1
+#define IRIS_EPILOGUE_IN_PLACE 2
 int iris_plan_set_epilogue(iris_plan* plan, int mode);
+/* form the plan's last iris_wav_to_logmel call took: IRIS_EPILOGUE_* (a FUSED plan reports IN_PLACE or TWO_KERNELS where it
+ * fell back by itself), -1 before the first call or when neither min-max nor log was asked for */
+int iris_plan_last_epilogue(const iris_plan* plan, int* form_out);
 int iris_plan_status(iris_plan* plan, int* status_out);
 int iris_plan_set_epilogue_timeout(iris_plan* plan, unsigned long long microseconds);
 

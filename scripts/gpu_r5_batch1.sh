@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r5b1
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 1000 python3 -m pytest tests -x -q -m gpu -s > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -4 $OUT/pytest_gpu.log
+timeout -k 10 1100 python3 -m pytest tests -q -m gpu -s > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -4 $OUT/pytest_gpu.log
 grep -E "rccl world 1|rule ratio" $OUT/pytest_gpu.log | cut -c1-400 | tail -12
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-extras > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err; echo "bench rc $?"; python3 -c "
 import json; d = json.load(open('$OUT/bench_driver_cmd.json')); print({k: d[k] for k in ('value', 'ms_per_step', 'parity')}); print(d['roofline']['frac'], d['cpu_baseline']['value'])"
@@ -18,3 +18,4 @@ grep -i -E "nccl|rccl" $OUT/rccl_w1/*kernel_trace.csv | head -40 > $OUT/rccl_w1_
 find $OUT/rccl_w1 -name "*kernel_trace.csv" -delete
 IRIS_BENCH_SHARE_GPU=1 timeout -k 10 600 python3 bench.py --gpus 4 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_share4.json 2> $OUT/bench_share4.err; echo "share4 rc $?"; python3 -c "
 import json; d = json.load(open('$OUT/bench_share4.json')); print(d['n_gpus'], d['rccl_world'], d['backend'], len(d['ranks']), [r['rank'] for r in d['ranks']])"
+bash scripts/gpu_r5_sweep_ab.sh 2>&1 | tee $OUT/sweep_ab.log

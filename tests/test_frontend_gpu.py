@@ -636,11 +636,15 @@ def test_captured_step_replays_bit_exact(dev):
                                                           (2048, 512, 128, 2, 3, 33075, 0),   # table mel, 8 waves
                                                           (256, 128, 40, 1, 300, 4000, 0),    # one chunk per clip: no exchange
                                                           (1024, 256, 150, 1, 2, 600000, 0),  # table mel, 124 chunks per clip
-                                                          (256, 128, 40, 1, 260, 166400, 0)]) # chunk too long for the LDS tile: falls back
+                                                          (256, 128, 40, 1, 260, 166400, 0),  # chunk too long for the LDS tile: in place
+                                                          (1024, 256, 64, 1, 128, 160000, 0), # c2 geometry, B 128: 2 chunks per clip, in place
+                                                          (1024, 256, 64, 1, 256, 160000, 0), # c2 geometry, B 256: a whole clip per workgroup
+                                                          (1024, 256, 64, 1, 300, 160000, 0)])# ... and workgroups looping over whole clips
 def test_fused_epilogue_equals_two_kernels(dev, monkeypatch, n_fft, hop, m, c, b, length, chunk):
-    """min-max / log inside the fused kernel (LDS mel tile, clip-level (min, max) exchange between workgroups, one
-    launch) against the two-kernel form of the same step: identical bits for every flag combination, with SpecAugment
-    bands, with the normalize flag, when workgroups loop over several chunks; the bounded waits all completed."""
+    """min-max / log inside the fused kernel - from the chunk's LDS tile, or IN PLACE through `out` where the tile does not
+    fit (and on request) -, clip-level (min, max) exchange between workgroups, one launch, against the two-kernel form of
+    the same step: identical bits for every flag combination, with SpecAugment bands, with the normalize flag, when
+    workgroups loop over several chunks; the bounded waits all completed."""
     rng = np.random.default_rng(n_fft + b)
     wav = (rng.standard_normal((b, c, length)) * rng.uniform(0.02, 0.5, (b, 1, 1))).astype(np.float32)
     x = torch.from_numpy(wav).to(dev)
@@ -653,17 +657,30 @@ def test_fused_epilogue_equals_two_kernels(dev, monkeypatch, n_fft, hop, m, c, b
     two = FE().FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
     if chunk:
         monkeypatch.delenv("IRIS_CHUNK_FRAMES")
+    inplace = FE().FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
+    if chunk:
+        monkeypatch.setenv("IRIS_CHUNK_FRAMES", str(chunk))
+        inplace = FE().FrontendPlan(n_fft, hop, m, 16000, c, b, length, dev)
+        monkeypatch.delenv("IRIS_CHUNK_FRAMES")
     two.set_epilogue("two_kernels")
+    inplace.set_epilogue("in_place")
     for kw in ({}, {"t_bands": tb, "f_bands": fb}):
         for flags in ({}, {"minmax": False}, {"log": False}, {"normalize": True}):
             a = fused.wav_to_logmel(x, **kw, **flags)
+            assert fused.last_epilogue() in ("fused", "in_place"), fused.last_epilogue()   # ONE launch, whatever the chunk size
             bb = two.wav_to_logmel(x, **kw, **flags)
+            assert two.last_epilogue() == "two_kernels"
+            ip = inplace.wav_to_logmel(x, **kw, **flags)
+            assert inplace.last_epilogue() == "in_place"
             assert torch.isfinite(a).all()
             assert torch.equal(a, bb), (kw.keys(), flags)
+            assert torch.equal(ip, bb), ("in place", kw.keys(), flags)
     for _ in range(5):  # back to back: a new epoch every launch, slots of the previous launch never match
         a = fused.wav_to_logmel(x)
-    assert torch.equal(a, two.wav_to_logmel(x))
-    assert fused.status() == 0
+        ip = inplace.wav_to_logmel(x)
+    want = two.wav_to_logmel(x)
+    assert torch.equal(a, want) and torch.equal(ip, want)
+    assert fused.status() == 0 and inplace.status() == 0
     ref = R.wav_to_logmel(wav[:2], n_fft, hop, m, 16000)
     assert np.abs(np.exp(a[:2].cpu().numpy()) - np.exp(ref)).max() <= 5e-6
 
