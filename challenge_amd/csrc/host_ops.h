@@ -221,12 +221,13 @@ static int fused_config(iris_plan* p, fused_kernel_t kernel, int batch, int T, i
             *lds = g.lds;
             return g.lds == 0 ? IRIS_E_UNSUPPORTED : IRIS_OK;  // lds 0: this shape does not fit (remembered)
         }
-    fused_geometry(p, batch, T, 1, chunk_frames, chunks_per_clip);
+    const int per_cu = fuse ? 1 : IRIS_WGS_PER_CU;  // (the epilogue forms need every workgroup resident: one per CU)
+    fused_geometry(p, batch, T, per_cu, chunk_frames, chunks_per_clip);
     *lds = fused_lds_bytes(p, streams, bands, *chunk_frames, fuse);
     if (fuse) *lds = fused_tile_off(*lds) + fused_tile_bytes(p, streams, bands, *chunk_frames, fuse);
-    *grid = std::min(batch * *chunks_per_clip, p->num_cu);
+    *grid = std::min(batch * *chunks_per_clip, p->num_cu * per_cu);
     if (p->geom_cache.size() >= 64) p->geom_cache.clear();
-    if (*lds > 160 * 1024) {
+    if (*lds * per_cu > 160 * 1024) {
         p->geom_cache.push_back({(const void*)kernel, batch, T, *chunk_frames, *chunks_per_clip, *grid, 0});
         return fail(IRIS_E_UNSUPPORTED, "fused kernel needs %zu B of LDS", *lds);
     }
@@ -234,7 +235,7 @@ static int fused_config(iris_plan* p, fused_kernel_t kernel, int batch, int T, i
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void*)kernel,
                                                                 64 * fused_waves(p->log2n, streams, bands, p->need_hi != 0, fuse, p->mel_mode), *lds);
     if (e != hipSuccess) return fail((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
-    if (resident < 1) return fail(IRIS_E_UNSUPPORTED, "fused kernel does not fit one workgroup per CU (LDS %zu B)", *lds);
+    if (resident < per_cu) return fail(IRIS_E_UNSUPPORTED, "fused kernel does not fit %d workgroup(s) per CU (LDS %zu B)", per_cu, *lds);
     p->geom_cache.push_back({(const void*)kernel, batch, T, *chunk_frames, *chunks_per_clip, *grid, *lds});
     return IRIS_OK;
 }
@@ -295,8 +296,8 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
     // min-max / log inside the kernel (one launch) unless: nothing to apply, the MFMA variant, two frame streams
     // (diag), the plan says two kernels, the stream is being captured (the epoch is a host counter: it would be
     // frozen in the graph), or the chunk's mel tile does not fit the LDS
-    // fuse: 0 = two kernels, 1 = epilogue from the chunk's LDS tile, 2 = epilogue in place through `out` (chunks whose tile does
-    // not fit the LDS: whole clips per workgroup at large batches; or the plan asks for it, IRIS_EPILOGUE_IN_PLACE)
+    // fuse: 0 = two kernels, 1 = epilogue from the chunk's LDS tile, 2 = epilogue in place through `out` (only when the plan
+    // asks for it, IRIS_EPILOGUE_IN_PLACE: an A/B form - see below)
     int fuse = ((do_minmax || do_log) && !mfma && streams == 1 && p->epilogue != IRIS_EPILOGUE_TWO_KERNELS)
                    ? (p->epilogue == IRIS_EPILOGUE_IN_PLACE ? 2 : 1) : 0;
     if (fuse) {
@@ -315,19 +316,16 @@ extern "C" int iris_wav_to_logmel(iris_plan* p, const float* wav, float* out, in
         lds = mfma_lds_bytes(p);
         grid = std::min(batch * a.chunks_per_clip, p->num_cu);
     } else {
-        for (; fuse == 1 || fuse == 2; ++fuse) {
+        if (fuse) {
             kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams, fuse);
             rc = fused_config(p, kernel, batch, a.T, streams, bands, fuse, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds);
-            // no fused epilogue when a clip has more chunks than the grid has workgroups (a workgroup would then wait for a
-            // chunk it has yet to process itself); when the LDS tile does not fit, the in-place form is next
-            if ((size_t)batch * a.chunks_per_clip > p->n_slots || a.chunks_per_clip > grid) {
-                fuse = 0;
-                break;
-            }
-            if (rc == IRIS_OK) break;
-            if (rc != IRIS_E_UNSUPPORTED) return rc;
+            // no fused epilogue when the LDS tile does not fit, or when a clip has more chunks than the grid has workgroups (a
+            // workgroup would then wait for a chunk it has yet to process itself): the two-kernel form.  (Round 5 measured the
+            // in-place form as the fallback for tiles beyond the LDS: same bytes through the same fabric as the second kernel,
+            // moved by every CU at the same moment - 3-5 % slower at B = 128 and 512, equal at 256; it stays selectable.)
+            if (rc == IRIS_E_UNSUPPORTED || (size_t)batch * a.chunks_per_clip > p->n_slots || a.chunks_per_clip > grid) fuse = 0;
+            else if (rc) return rc;
         }
-        if (fuse > 2) fuse = 0;
         if (!fuse) {
             kernel = fused_kernel(p->log2n, p->mel_mode, p->need_hi != 0, bands, streams, 0);
             if ((rc = fused_config(p, kernel, batch, a.T, streams, bands, 0, &a.chunk_frames, &a.chunks_per_clip, &grid, &lds)))

@@ -403,10 +403,13 @@ extern "C" int iris_plan_create(iris_plan** out, int device, int n_fft, int hop,
     // (the full-spectrum untangle needs the registers too: need_hi -> table modes)
     int max_span = 0;  // widest band counted from the 4-bin boundary below its first bin
     for (int m = 0; m < n_mel; ++m) max_span = std::max(max_span, (lo[m] & 3) + len[m]);
-    if (log2n <= 10 && !p->need_hi && n_mel <= 64 && p->max_band_len + 3 <= kMelRegs && limit >= kMelRegs) {
+#ifndef IRIS_EXP_MELMODE1
+#define IRIS_EXP_MELMODE1 0  // experiment (k_fused.h): never the register band weights
+#endif
+    if (!IRIS_EXP_MELMODE1 && log2n <= 10 && !p->need_hi && n_mel <= 64 && p->max_band_len + 3 <= kMelRegs && limit >= kMelRegs) {
         p->mel_mode = 0;  // 16-byte aligned register window of kMelRegs bins per band
         p->rows = kMelRegs;
-    } else if (log2n <= 10 && !p->need_hi && n_mel > 64 && n_mel <= 128 && max_span <= 8 && limit >= 8) {
+    } else if (!IRIS_EXP_MELMODE1 && log2n <= 10 && !p->need_hi && n_mel > 64 && n_mel <= 128 && max_span <= 8 && limit >= 8) {
         p->mel_mode = 3;  // two bands per lane, 16-byte aligned register windows of 8 bins
         p->rows = 8;
     } else {

@@ -29,9 +29,10 @@
 //   S         = frames in flight per wave (1; 2 exists in diagnostic builds for n_fft 512 / 1024 and measured slower)
 //   FUSE      = min-max / log inside the kernel (clip-level granule exchange, see the epilogue) instead of per-wave
 //               partials for a second kernel: 1 = the chunk's mel values wait in an LDS tile and reach HBM once, finished;
-//               2 = chunks whose tile would not fit the LDS (whole clips per workgroup at large batches): the raw mel
-//               goes to `out` as in the unfused form and the SAME workgroup finishes its chunk's rows in place once the
-//               clip's range is known - its own stores, a barrier apart, read back through L2 / Infinity Cache
+//               2 = no tile (chunks of any size; round-5 experiment, selectable, never the default): the raw mel goes
+//               to `out` as in the unfused form and the SAME workgroup finishes its chunk's rows in place once the clip's
+//               range is known - its own stores, a barrier apart, read back through L2 / Infinity Cache.  Same bits; 3-5 %
+//               slower than the two-kernel form at the batch sizes whose tile does not fit (EXPERIMENTS.md)
 // ---------------------------------------------------------------------------
 // One workgroup per CU holding every wave of the CU: all waves are of one age class for the issue
 // arbiter (which favours older waves) and share one frame queue.
@@ -47,6 +48,17 @@
 #endif
 #ifndef IRIS_S2_WAVES
 #define IRIS_S2_WAVES 8
+#endif
+// Round-5 occupancy experiment (A/B builds only, the defaults are the product; EXPERIMENTS.md): IRIS_EXP_WIN_LDS reads the
+// window from the LDS staging area every frame instead of keeping it in 16 registers, IRIS_EXP_MELMODE1 (host_plan.h) takes
+// the LDS band table instead of 20 register weights - together the n_fft 1024 kernel without epilogue fits 96 VGPRs = five
+// waves per SIMD -, IRIS_WGS_PER_CU launches that many workgroups per CU (two of 10 waves: 1,024 threads cap one workgroup
+// at 16 waves) for the two-kernel form
+#ifndef IRIS_EXP_WIN_LDS
+#define IRIS_EXP_WIN_LDS 0
+#endif
+#ifndef IRIS_WGS_PER_CU
+#define IRIS_WGS_PER_CU 1
 #endif
 // frames go global -> registers up to this n_fft (log2); above it through LDS-DMA landing buffers.  Round 2: n_fft
 // 2048 too - the prefetch targets the sample registers themselves (dead during the mel phase), so it costs no
@@ -228,7 +240,7 @@ __device__ __forceinline__ LateEpilogueArgs late_epilogue_args() {
 constexpr unsigned long long kEpilogueTimeoutTicks = 200000000ull;  // s_memrealtime runs at 100 MHz: 2 s
 
 template <int LOG2N, int MELMODE, bool HI, bool BANDS, int S, int FUSE>
-__global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE), fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE) / 4) void k_wav_to_mel(const FusedArgs a) {
+__global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE), fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE) * (FUSE == 0 ? IRIS_WGS_PER_CU : 1) / 4) void k_wav_to_mel(const FusedArgs a) {
     constexpr int kFusedWaves = fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE);
     constexpr int N = 1 << LOG2N, NC = N / 2, P = FftCfg<LOG2N>::P, NTW = FftCfg<LOG2N>::NTW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -589,10 +601,23 @@ __global__ __launch_bounds__(64 * fused_waves(LOG2N, S, BANDS, HI, FUSE, MELMODE
             // (direct loads: the compiler waits for each sample register where it is first used; stores issued
             // from inline asm only make those counted waits more conservative, never less)
             PH_MARK(0);
+            if constexpr (IRIS_EXP_WIN_LDS && DIRECT && (P % 2 == 0)) {
+                // experiment: window pairs (win[2k], win[2k + 1]) = one float4 of the staged constant block per lane
+                const float4* w4 = reinterpret_cast<const float4*>(smem) + (ConstLayout<LOG2N>::OFF_WIN / 4) * kWave + lane;
 #pragma unroll
-            for (int st = 0; st < S; ++st)
+                for (int st = 0; st < S; ++st)
 #pragma unroll
-                for (int q = 0; q < P; ++q) x[st][q] *= win[q];
+                    for (int k = 0; k < P / 2; ++k) {
+                        const float4 w = w4[k * kWave];
+                        x[st][2 * k] *= mk(w.x, w.y);
+                        x[st][2 * k + 1] *= mk(w.z, w.w);
+                    }
+            } else {
+#pragma unroll
+                for (int st = 0; st < S; ++st)
+#pragma unroll
+                    for (int q = 0; q < P; ++q) x[st][q] *= win[q];
+            }
             if (!ABL(1)) fft_frames<LOG2N, S, LOG2N == IRIS_SINGLE_READS_LOG2N>(x, tw, lds, lane);
             PH_MARK(3);
             // |X| scaled by 2 (the 0.5 of the untangle lives in the band weights)

@@ -133,13 +133,12 @@ int iris_plan_set_mel_precision(iris_plan* plan, int precision);
  *                              good and returns IRIS_E_EPILOGUE_TIMEOUT: outputs of this plan since the last successful
  *                              iris_plan_status / since that call's predecessor are suspect.  Use TWO_KERNELS from the
  *                              start for pipelines that overlap plans.
- *                              Shapes whose chunk does not fit the LDS tile (whole clips per workgroup: c2 geometry
- *                              from batch 128 on) take the IN_PLACE form by themselves - still one launch.
  *   IRIS_EPILOGUE_TWO_KERNELS  fused kernel (raw mel + per-wave partials), then the min-max / log kernel.
  *   IRIS_EPILOGUE_IN_PLACE     one launch like FUSED, without the LDS tile: the raw mel goes to `out` and the workgroup
  *                              that wrote a chunk finishes its rows in place once the clip's range is known (same
- *                              exchange, same co-residency rules, same bits).  What FUSED falls back to for large chunks;
- *                              selectable for A/B runs.
+ *                              exchange, same co-residency rules, same bits), for chunks of any size.  Measured 3-5 %
+ *                              SLOWER than TWO_KERNELS where the tile does not fit (c2 geometry from batch 128 on: the same
+ *                              bytes move through the same fabric, all CUs at once) - an A/B form, never chosen by itself.
  * A plan created while ROC_GLOBAL_CU_MASK or HSA_CU_MASK is set starts on TWO_KERNELS (a CU mask breaks the co-residency).
  * IRIS_EPILOGUE=1 in the environment at plan creation selects TWO_KERNELS (test / A-B hook; so do IRIS_CHUNK_FRAMES=n,
  * frames per chunk of the fused kernel, and IRIS_MAGMEL_GENERIC - test hooks read once per plan, never per launch).

@@ -636,13 +636,13 @@ def test_captured_step_replays_bit_exact(dev):
                                                           (2048, 512, 128, 2, 3, 33075, 0),   # table mel, 8 waves
                                                           (256, 128, 40, 1, 300, 4000, 0),    # one chunk per clip: no exchange
                                                           (1024, 256, 150, 1, 2, 600000, 0),  # table mel, 124 chunks per clip
-                                                          (256, 128, 40, 1, 260, 166400, 0),  # chunk too long for the LDS tile: in place
-                                                          (1024, 256, 64, 1, 128, 160000, 0), # c2 geometry, B 128: 2 chunks per clip, in place
+                                                          (256, 128, 40, 1, 260, 166400, 0),  # chunk too long for the LDS tile: falls back
+                                                          (1024, 256, 64, 1, 128, 160000, 0), # c2 geometry, B 128: 2 chunks per clip, tile beyond the LDS
                                                           (1024, 256, 64, 1, 256, 160000, 0), # c2 geometry, B 256: a whole clip per workgroup
                                                           (1024, 256, 64, 1, 300, 160000, 0)])# ... and workgroups looping over whole clips
 def test_fused_epilogue_equals_two_kernels(dev, monkeypatch, n_fft, hop, m, c, b, length, chunk):
-    """min-max / log inside the fused kernel - from the chunk's LDS tile, or IN PLACE through `out` where the tile does not
-    fit (and on request) -, clip-level (min, max) exchange between workgroups, one launch, against the two-kernel form of
+    """min-max / log inside the fused kernel - from the chunk's LDS tile (default) or IN PLACE through `out` (on request:
+    no tile, chunks of any size) -, clip-level (min, max) exchange between workgroups, one launch, against the two-kernel form of
     the same step: identical bits for every flag combination, with SpecAugment bands, with the normalize flag, when
     workgroups loop over several chunks; the bounded waits all completed."""
     rng = np.random.default_rng(n_fft + b)
@@ -667,7 +667,7 @@ def test_fused_epilogue_equals_two_kernels(dev, monkeypatch, n_fft, hop, m, c, b
     for kw in ({}, {"t_bands": tb, "f_bands": fb}):
         for flags in ({}, {"minmax": False}, {"log": False}, {"normalize": True}):
             a = fused.wav_to_logmel(x, **kw, **flags)
-            assert fused.last_epilogue() in ("fused", "in_place"), fused.last_epilogue()   # ONE launch, whatever the chunk size
+            assert fused.last_epilogue() in ("fused", "two_kernels"), fused.last_epilogue()   # (falls back by itself for large chunks)
             bb = two.wav_to_logmel(x, **kw, **flags)
             assert two.last_epilogue() == "two_kernels"
             ip = inplace.wav_to_logmel(x, **kw, **flags)
@@ -763,8 +763,8 @@ def test_cu_mask_environment_starts_on_two_kernels(dev, monkeypatch):
     want = ref_plan.wav_to_logmel(x).clone()
     monkeypatch.setenv("HSA_CU_MASK", "0:0-255")   # read by this library at plan creation only (the runtime is already up)
     masked = FE().FrontendPlan(1024, 256, 64, 16000, 1, 4, 40000, dev)
-    assert masked.epilogue == "two_kernels" and masked.fused_kernel_name().endswith("false>")
+    assert masked.epilogue == "two_kernels" and masked.fused_kernel_name().endswith(",0>")
     assert torch.equal(masked.wav_to_logmel(x), want)
     monkeypatch.setenv("IRIS_EPILOGUE", "0")
     forced = FE().FrontendPlan(1024, 256, 64, 16000, 1, 4, 40000, dev)
-    assert forced.epilogue == "fused" and forced.fused_kernel_name().endswith("true>")
+    assert forced.epilogue == "fused" and forced.fused_kernel_name().endswith(",1>")
