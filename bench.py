@@ -612,10 +612,22 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL
+        # RCCL prints a version banner to STDOUT when its first communicator comes up; this script's stdout is ONE JSON line:
+        # the banner goes to stderr (fd-level redirect around the group's creation and first collective)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if share:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         backend = dist.get_backend()
         if not share and backend != "nccl":  # the N > 1 line is about RCCL over xGMI; anything else is a mis-launch
             print(f"bench.py: world {world} runs on backend '{backend}', expected 'nccl' (RCCL)", file=sys.stderr)
@@ -793,6 +805,18 @@ def main():
                 else:
                     roof["frac_withheld"] = (f"kernel_ms {kernel_ms:.5f} + second_kernel_ms {k2_ms:.5f} exceed ms_per_step "
                                              f"{ms_per_step:.5f} x 1.05: inconsistent, no fraction reported")
+            # the OTHER bound of this kernel: it is bound by vector-instruction issue, not by bytes.
+            # 235 vector instructions per frame (PMC, profiles/r4/pmc_traffic.json) x 4.3 cycles per packed-fp32 instruction and
+            # SIMD (scripts/microbench/valu_rate.hip) over 1,024 SIMDs at 2.4 GHz, plus the launch's fixed cost that no frame
+            # work can hide (dispatch + drain 2.4 us, first HBM fetch of the prologue 2.5 us: in-kernel stamps, round 3 / 4)
+            frames = batch * plan.channels * plan.num_frames(length)
+            issue_us = frames * 235 * 4.3 / (1024 * 2.4e3)
+            roof["issue_floor_us"] = round(issue_us + 4.9, 2)
+            roof["issue_floor_frac"] = round(algo_bytes / ((issue_us + 4.9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            roof["issue_floor_how"] = ("frames x 235 vector instructions x 4.3 cycles / (1,024 SIMDs x 2.4 GHz) + 4.9 us of launch, drain "
+                                       "and first fetch: what THIS decomposition (one wave per frame, fp32 Stockham 8x8x8 on packed "
+                                       "math) could reach with every LDS / memory wait hidden; round 5's A/B of five waves per SIMD "
+                                       "against four on one instruction stream lost 19 % (profiles/r5/ab_occupancy.log)")
             roof["two_kernel_form"] = two
             result["roofline"] = roof
             if cpu_input is not None:
