@@ -1,0 +1,351 @@
+// k_conv_wino.h -- Conv2D(3x3 'same', Cin -> Cout) + bias + ReLU (+ MaxPool 2x2 'same') as a Winograd F(2x2, 3x3) transform on
+// the fp32 matrix cores: blocks 2-5 of the CRNN (sj_train.py:191-201, 222-242: 64 ... 512 channels), for inference.
+// Part of the single translation unit iris_frontend.hip (and of scripts/microbench/wino_conv.hip, which builds it alone).
+#pragma once
+// ---------------------------------------------------------------------------
+// MIOpen runs these layers as implicit GEMMs at the fp32 MFMA rate (232-249 us for 38.7 GFLOP = the ceiling of
+// v_mfma_f32_32x32x2_f32 at the clock the chip sustains), so only fewer multiplies can be faster: F(2x2, 3x3) needs 16 instead
+// of 36 per 2 x 2 output tile and channel pair (2.25x).   Y = A^T [ (G g G^T) (.) (B^T d B) ] A   per tile, summed over the
+// input channels BEFORE the output transform:
+//   U[p][cin][cout] = G g G^T                     once per layer, on the host side of the ABI (iris_wino_pack_weights)
+//   V[p][tile][cin] = B^T d B                     4 x 4 input patch d of a tile -> 16 positions p, computed on the fly
+//   M[p][tile][cout] = sum_cin V U                16 GEMMs - the matrix cores
+//   Y[tile][2 x 2][cout] = A^T M A, + bias, ReLU (a 2 x 2 output tile IS a pooling window: MaxPool = an in-lane max)
+// Decomposition: a wave owns 32 tiles x 32 output channels x all 16 positions = 16 accumulators of v_mfma_f32_32x32x2_f32
+// (256 AGPRs: one wave per SIMD, 512-register budget); a workgroup of 4 waves = 64 tiles (TR tile rows x TC tile columns)
+// x 64 output channels.  K runs over the input channels in chunks of 8, everything double-buffered in LDS.
+// Activations are CHANNEL-CHUNKED: x [B][Cin / 8][H][W][8] - a chunk of 8 channels of a row of pixels is contiguous, so
+// the input of a chunk arrives by LDS-DMA (global_load_lds_dwordx4: no registers, no wait counters shared with the
+// compiler's own loads) in whole cache lines; out-of-image pixels are fetched from a block of zeros.  Each wave stages,
+// privately, exactly the pixels ITS transform items read (3 patch rows x one 16-byte channel group), so the hand-over raw ->
+// patch registers -> next DMA needs no workgroup barrier.  U comes by LDS-DMA too (the host packs it in LDS order).
+// One wave per SIMD means nothing else hides latency: the K loop is written as 64 SLOTS per chunk - one MFMA each, fenced
+// by scheduling barriers - and every other instruction of the chunk (the LDS reads of the next operand group, the transform
+// of the NEXT chunk and its LDS writes, the DMA requests of the chunk after that) sits in the shadow of one of those MFMAs.
+// The transformed input (4x the activation) and M (4x the output) never exist in memory.
+// y: [B][Cout / 8][Ho][Wo][8] (the next layer's input) or channels-last [B][Ho][Wo][Cout] (`out_nhwc`); Cin % 8 == 0,
+// Cout % 64 == 0.
+// ---------------------------------------------------------------------------
+#ifdef IRIS_WINO_STANDALONE
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// timing experiments only (results wrong when non-zero): 1 no per-chunk barrier, 2 no LDS-DMA of U, 4 no transform of the next
+// chunk (patch reads, row / column stage, V writes), 8 no operand reads after a chunk's first group, 16 no LDS-DMA of the input
+#ifndef IRIS_WINO_ABLATE
+#define IRIS_WINO_ABLATE 0
+#endif
+#define WINO_ABL(bit) ((IRIS_WINO_ABLATE & (bit)) != 0)
+constexpr int kWinoTM = 64, kWinoTN = 64, kWinoKC = 8;
+constexpr int kWinoVFloats = 16 * 4 * kWinoTM * 2;   // [pos 16][pair 2][hl 2][tile 64][2]
+constexpr int kWinoUFloats = 16 * 4 * kWinoTN * 2;   // [pos 16][pair 2][hl 2][cout 64][2]
+constexpr int kWinoBuf = kWinoVFloats + kWinoUFloats;
+constexpr int kWinoRawPieces = 448;                  // per wave: 7 LDS-DMA rows of 64 pieces of 16 bytes (>= TR 3 (2 TC + 2))
+constexpr size_t kWinoLdsBytes = 2 * (size_t)kWinoBuf * sizeof(float) + 4 * (size_t)kWinoRawPieces * 16;  // 128 KiB + 28 KiB
+
+// floats of the packed weights: [cout block][chunk][pos][pair][hl][cout 64][2]
+static size_t wino_packed_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
+
+typedef __attribute__((address_space(3))) float wino_lds_float;
+__device__ __forceinline__ unsigned wino_lds_addr(const float* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(wino_lds_float*)p);
+}
+// 1 KiB global -> LDS without registers: lane l moves 16 bytes to LDS byte address lds + 16 l (M0 = lds) - from src + 16 l
+// (uniform source: a contiguous row) or from its own address (gathered pieces).
+// Inline asm: the compiler would drain an LDS-DMA it knows about before the next LDS access.
+__device__ __forceinline__ void wino_dma16(const float* src /*uniform*/, unsigned lds /*uniform*/, unsigned lane16) {
+    const uint64_t a = reinterpret_cast<uint64_t>(src);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const float* s = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(s), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void wino_dma16_gather(const float* src /*per lane*/, unsigned lds /*uniform*/) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+}
+__device__ __forceinline__ float4 wino_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 wino_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+struct WinoWave {
+    f32x16 acc[16];
+    f32x2 ops[2][8];      // operand pairs of a group of 4 positions: [0..3] = V (A operand), [4..7] = U (B operand); double-buffered
+    float4 d[3][4];       // this thread's patch rows (three of the four) x columns, one channel group of 4
+    float4 w[2][4];       // B^T d, two rows xi of this thread's half
+};
+
+// TC: tile columns of a workgroup's block (64 / TC tile rows): min(ceil(W / 2), 64) rounded up to a power of two
+template <bool POOL, int TC>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict__ x, const float* __restrict__ u,
+                                                         const float* __restrict__ bias, const float* __restrict__ zeros,
+                                                         float* __restrict__ y, int B, int H, int W, int Cin, int Cout, int out_nhwc) {
+    extern __shared__ __attribute__((aligned(16))) float wino_lds[];
+    constexpr int TR = kWinoTM / TC, PW = 2 * TC + 2, kPieces = TR * 3 * PW, kDmaRows = (kPieces + 63) / 64;
+    static_assert(kPieces <= kWinoRawPieces, "raw region too small");
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave index is uniform
+    const int hl = lane >> 5, li = lane & 31;
+    const int wm = wv & 1, wn = wv >> 1;  // the wave's tile half / output-channel half of the workgroup's 64 x 64 block
+    const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
+    const int n_rows = B * TH;                                    // tile rows of the whole batch
+    const int row_blocks = (n_rows + TR - 1) / TR, col_blocks = (TW + TC - 1) / TC;
+    const int cout_blocks = Cout / kWinoTN, n_chunks = Cin / kWinoKC;
+    const int n_work = row_blocks * col_blocks * cout_blocks;
+    const size_t plane = (size_t)H * W * 8;                       // floats of one channel chunk of one image
+    // transform role of this wave: channel group (4 of the chunk's 8 channels) and half of the 16 positions; lane = tile
+    const int p_cg = wv & 1, p_half = wv >> 1;
+    float* const raw = wino_lds + 2 * kWinoBuf + wv * (kWinoRawPieces * 4);   // this wave's private staging area
+    const unsigned raw_l = wino_lds_addr(raw);
+    WinoWave s;
+
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+        // consecutive work items share a tile block (its input stays in L2) and walk the output-channel blocks
+        const int cb = work % cout_blocks, blk = work / cout_blocks;
+        const int cbk = blk % col_blocks, rb = blk / col_blocks;
+        const int R0 = rb * TR, tc0 = cbk * TC;
+        const float* const ubase = u + ((size_t)cb * n_chunks) * (kWinoUFloats);
+        // ---- the input pieces this lane requests per chunk: piece i = lane + 64 k of the wave's staging order
+        //      [strip (tile row of the block)][patch row r of this half][pixel px of the strip], 16 bytes = channel group p_cg
+        unsigned poff[kDmaRows];  // element offset inside a chunk plane of image 0 (32 bit), or ~0u: out of the image -> zeros
+#pragma unroll
+        for (int k = 0; k < kDmaRows; ++k) {
+            const int i = lane + 64 * k;
+            const int strip = i / (3 * PW), r = (i / PW) % 3, px = i % PW;
+            const int R = R0 + strip, b_ = R / TH, th = R - b_ * TH;
+            const int hh = 2 * th - 1 + p_half + r, ww = 2 * tc0 - 1 + px;
+            const bool ok = i < kPieces && R < n_rows && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            poff[k] = ok ? (unsigned)((((size_t)b_ * (Cin / 8)) * H + hh) * W + ww) * 8u + 4u * p_cg : ~0u;
+        }
+        auto dma_x = [&](int chunk, int k0, int k1) {  // rows k0 .. k1 - 1 of the wave's staging area for `chunk`
+            const float* xc = x + (size_t)chunk * plane;  // uniform
+#pragma unroll
+            for (int k = 0; k < kDmaRows; ++k)
+                if (k >= k0 && k < k1) wino_dma16_gather(poff[k] != ~0u ? xc + poff[k] : zeros + 4 * (lane & 3), raw_l + 1024u * k);
+        };
+        auto dma_u = [&](int chunk, int buf, int j0, int j1) {  // the chunk of U: one contiguous 32 KiB block in LDS order, 8 rows of
+            const float* us_g = ubase + (size_t)chunk * kWinoUFloats;  // 1 KiB per wave (rows j0 .. j1 - 1 of them)
+            const unsigned us_l = wino_lds_addr(wino_lds + buf * kWinoBuf + kWinoVFloats);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j >= j0 && j < j1) wino_dma16(us_g + (wv + 4 * j) * 256, us_l + (wv + 4 * j) * 1024u, (unsigned)lane * 16u);
+        };
+        // this lane's tile inside the block and its patch in the staging area
+        const int trow = lane / TC, tcol = lane % TC;
+        const float4* const patch = reinterpret_cast<const float4*>(raw) + (trow * 3) * PW + 2 * tcol;
+        auto read_patch = [&](int i) { s.d[i >> 2][i & 3] = patch[(i >> 2) * PW + (i & 3)]; };  // i = 4 r + c
+        auto row_stage = [&](int e, int c) {
+            // rows of B^T d: half 0 holds patch rows 0, 1, 2 -> xi 0 = d0 - d2, xi 1 = d1 + d2; half 1 holds rows 1, 2, 3 ->
+            // xi 2 = d2 - d1, xi 3 = d1 - d3
+            const float4 a = s.d[0][c], b = s.d[1][c], dd = s.d[2][c];
+            if (p_half == 0) s.w[e][c] = e == 0 ? wino_sub(a, dd) : wino_add(b, dd);
+            else s.w[e][c] = e == 0 ? wino_sub(b, a) : wino_sub(a, dd);
+        };
+        auto col_stage = [&](int buf, int e, int nu) {
+            const float4 (&w)[4] = s.w[e];
+            const float4 v = nu == 0 ? wino_sub(w[0], w[2]) : nu == 1 ? wino_add(w[1], w[2]) : nu == 2 ? wino_sub(w[2], w[1]) : wino_sub(w[1], w[3]);
+            const int pos = 4 * (2 * p_half + e) + nu;
+            // channels k = 4 p_cg + {0, 1, 2, 3}: pair p_cg; hl 0 holds (k, k + 2) = (.x, .z), hl 1 holds (.y, .w)
+            f32x2* dst = reinterpret_cast<f32x2*>(wino_lds + buf * kWinoBuf) + ((pos * 2 + p_cg) * 2) * kWinoTM + lane;
+            const f32x2 lo = {v.x, v.z}, hi = {v.y, v.w};
+            dst[0] = lo;
+            dst[kWinoTM] = hi;
+        };
+        auto read_op = [&](f32x2 (&ops)[8], int buf, int gi, int j) {  // operand j of group gi = (pr, g): positions 4 g + (j & 3)
+            const int pr = gi >> 2, p = 4 * (gi & 3) + (j & 3);
+            const f32x2* base = reinterpret_cast<const f32x2*>(wino_lds + buf * kWinoBuf);
+            ops[j] = j < 4 ? base[((p * 2 + pr) * 2 + hl) * kWinoTM + 32 * wm + li]
+                           : base[kWinoVFloats / 2 + ((p * 2 + pr) * 2 + hl) * kWinoTN + 32 * wn + li];
+        };
+
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s.acc[p][r] = 0.f;
+
+        // ---- prologue (not overlapped): V(0), U(0) into buffer 0; the patches of chunk 1 in registers; the input of chunk 2 requested
+        __syncthreads();  // the previous work item's last buffer is consumed
+        dma_u(0, 0, 0, 8);
+        dma_x(0, 0, kDmaRows);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 12; ++i) read_patch(i);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area is free again
+        if (n_chunks > 1) dma_x(1, 0, kDmaRows);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) row_stage(e, c);
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) col_stage(0, e, nu);
+        }
+        if (n_chunks > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 12; ++i) read_patch(i);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+
+        // One chunk: 8 groups (4 positions x the two MFMA steps of an operand pair) of 8 slots.  NEXT: another chunk follows
+        // (its transform rides in this chunk's slots); the last chunk of a work item runs the bare MFMA sequence.
+        // Timeline of the wave's own memory traffic in chunk c (a wave's vector-memory operations return in order):
+        //   slots  0 ..  6  request the input of chunk c + 2 into the staging area (its previous content, chunk c + 1, went to
+        //                   registers at the end of chunk c - 1)
+        //   slots  8 .. 15  request U(c + 1) into buffer buf ^ 1
+        //   slots 20 .. 27  row stage, 32 .. 39 column stage + V(c + 1) writes into buffer buf ^ 1
+        //   slot  52        wait until at most the 8 U requests are outstanding: the staging area holds chunk c + 2
+        //   slots 52 .. 63  patches of chunk c + 2 -> registers (consumed during chunk c + 1)
+        //   top of c + 1    wait for everything (U(c + 1) has landed), barrier
+        auto chunk_body = [&](auto next_tag, int chunk) {
+            constexpr bool next = decltype(next_tag)::value;
+            const int buf = chunk & 1;
+            const bool next2 = chunk + 2 < n_chunks;  // uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!WINO_ABL(1)) __syncthreads();  // buffer `buf` is complete; buffer buf ^ 1 is free (its readers passed this barrier)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) read_op(s.ops[0], buf, 0, j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gi = 0; gi < 8; ++gi) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = j & 3, p = 4 * (gi & 3) + q, sl = 8 * gi + j;
+                    const f32x2 a = s.ops[gi & 1][q], b = s.ops[gi & 1][4 + q];
+                    s.acc[p] = (j < 4) ? __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, s.acc[p], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, s.acc[p], 0, 0, 0);
+                    if (gi < 7 && !WINO_ABL(8)) read_op(s.ops[(gi + 1) & 1], buf, gi + 1, j);   // next group's operand j
+                    if constexpr (next) {
+                        if (sl < kDmaRows && next2 && !WINO_ABL(16)) dma_x(chunk + 2, sl, sl + 1);
+                        if (sl >= 8 && sl < 16 && !WINO_ABL(2)) dma_u(chunk + 1, buf ^ 1, sl - 8, sl - 7);
+                        if (sl >= 20 && sl < 28 && !WINO_ABL(4)) row_stage((sl - 20) >> 2, (sl - 20) & 3);
+                        if (sl >= 32 && sl < 40 && !WINO_ABL(4)) col_stage(buf ^ 1, (sl - 32) >> 2, (sl - 32) & 3);
+                        if (sl == 52 && !WINO_ABL(4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        if (sl >= 52 && next2 && !WINO_ABL(4)) read_patch(sl - 52);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) chunk_body(std::true_type{}, chunk);
+        chunk_body(std::false_type{}, n_chunks - 1);
+
+        // ---- output transform, bias, ReLU (, MaxPool) and store: lane = output channel, register r = tile
+        const int co = cb * kWinoTN + 32 * wn + li;
+        const float bj = bias[co];
+        const int Ho = POOL ? TH : H, Wo = POOL ? TW : W;
+        // element offset of (b, oh, ow, co) = base(b) + (oh Wo + ow) pstride: chunked [B][Cout / 8][Ho][Wo][8] or channels-last
+        const size_t img = (size_t)Ho * Wo * Cout;
+        const size_t cbase = out_nhwc ? (size_t)co : ((size_t)(co >> 3) * Ho * Wo) * 8 + (co & 7);
+        const int pstride = out_nhwc ? Cout : 8;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hl;
+            const int t = 32 * wm + row;  // tile of the block
+            const int R = R0 + t / TC, tw_ = tc0 + t % TC;
+            const int b_ = R / TH, th_ = R - b_ * TH;
+            float sr[2][4];  // A^T M: rows (m0 + m1 + m2), (m1 - m2 - m3) per column nu
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                const float m0 = s.acc[nu][r], m1 = s.acc[4 + nu][r], m2 = s.acc[8 + nu][r], m3 = s.acc[12 + nu][r];
+                sr[0][nu] = m0 + m1 + m2;
+                sr[1][nu] = m1 - m2 - m3;
+            }
+            float o[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                o[i][0] = sr[i][0] + sr[i][1] + sr[i][2];
+                o[i][1] = sr[i][1] - sr[i][2] - sr[i][3];
+            }
+            if (R < n_rows && tw_ < TW) {
+                const int oh = 2 * th_, ow = 2 * tw_;
+                float* const yb = y + (size_t)b_ * img + cbase;
+                if constexpr (POOL) {
+                    float m = o[0][0];  // (oh, ow) is inside whenever the tile exists
+                    if (ow + 1 < W) m = fmaxf(m, o[0][1]);
+                    if (oh + 1 < H) {
+                        m = fmaxf(m, o[1][0]);
+                        if (ow + 1 < W) m = fmaxf(m, o[1][1]);
+                    }
+                    yb[((size_t)th_ * Wo + tw_) * pstride] = fmaxf(m + bj, 0.f);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            if (oh + i < H && ow + j < W) yb[((size_t)(oh + i) * Wo + ow + j) * pstride] = fmaxf(o[i][j] + bj, 0.f);
+                }
+            }
+        }
+    }
+}
+
+// Host side of the packing: weight [Cout][Cin][3][3] (OIHW, contiguous) -> U = G g G^T in the kernel's LDS order
+// [cout block][chunk of 8 cin][pos 16][pair 2][hl 2][cout 64][2], where (pair, hl, j) <-> k = 4 pair + hl + 2 j of the chunk.
+extern "C" size_t iris_wino_packed_len(int cin, int cout) { return (cin > 0 && cout > 0) ? wino_packed_floats(cin, cout) : 0; }
+
+extern "C" int iris_wino_pack_weights(const float* weight_host, int cin, int cout, float* packed_host) {
+    if (!weight_host || !packed_host) return fail(IRIS_E_INVALID, "iris_wino_pack_weights: NULL argument");
+    if (cin <= 0 || cout <= 0 || (cin % kWinoKC) || (cout % kWinoTN))
+        return fail(IRIS_E_UNSUPPORTED, "iris_wino_pack_weights: cin %d must be a multiple of %d, cout %d of %d", cin, kWinoKC, cout, kWinoTN);
+    static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    const int n_chunks = cin / kWinoKC;
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c) {
+            const float* g = weight_host + ((size_t)o * cin + c) * 9;
+            double t[4][3];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+            const int cb = o / kWinoTN, oc = o % kWinoTN, chunk = c / kWinoKC, k = c % kWinoKC;
+            const int pair = k >> 2, hl = k & 1, j2 = (k >> 1) & 1;
+            for (int xi = 0; xi < 4; ++xi)
+                for (int nu = 0; nu < 4; ++nu) {
+                    const double v = t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2];
+                    const int pos = 4 * xi + nu;
+                    packed_host[((size_t)cb * n_chunks + chunk) * kWinoUFloats + ((((size_t)pos * 2 + pair) * 2 + hl) * kWinoTN + oc) * 2 + j2] = (float)v;
+                }
+        }
+    return IRIS_OK;
+}
+
+template <bool POOL>
+static hipError_t wino_launch(int tc, unsigned grid, hipStream_t s, const float* x, const float* packed, const float* bias,
+                              const float* zeros, float* y, int batch, int height, int width, int cin, int cout, int out_nhwc) {
+    if (tc >= 64) k_conv3x3_wino<POOL, 64><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, zeros, y, batch, height, width, cin, cout, out_nhwc);
+    else if (tc >= 32) k_conv3x3_wino<POOL, 32><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, zeros, y, batch, height, width, cin, cout, out_nhwc);
+    else k_conv3x3_wino<POOL, 16><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, zeros, y, batch, height, width, cin, cout, out_nhwc);
+    return hipGetLastError();
+}
+
+// x: channel-chunked [B][cin / 8][H][W][8]; packed: iris_wino_pack_weights; zeros: >= 16 floats of zeros (DEVICE; the source
+// of every out-of-image pixel); y: chunked [B][cout / 8][Ho][Wo][8], or channels-last [B][Ho][Wo][cout] with out_nhwc
+extern "C" int iris_conv3x3_wino_bias_relu(const float* x, const float* packed, const float* bias, const float* zeros, float* y,
+                                           int batch, int height, int width, int cin, int cout, int pool, int out_nhwc, void* stream) {
+    if (!x || !packed || !bias || !zeros || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: NULL argument");
+    if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: empty tensor");
+    if (cin <= 0 || cout <= 0 || (cin % kWinoKC) || (cout % kWinoTN))
+        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_bias_relu: cin %d must be a multiple of %d, cout %d of %d", cin, kWinoKC, cout, kWinoTN);
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(zeros)) & 15)
+        return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: x, the packed weights and the zero block must be 16-byte aligned");
+    if ((long long)batch * height * width * cin >= 4294967295LL / 2)
+        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_bias_relu: tensor too large for 32-bit element offsets");
+    int dev = 0, n_cu = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    static std::atomic<unsigned> attr_set[64];
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+        const void* ks[6] = {(const void*)k_conv3x3_wino<false, 64>, (const void*)k_conv3x3_wino<false, 32>, (const void*)k_conv3x3_wino<false, 16>,
+                             (const void*)k_conv3x3_wino<true, 64>,  (const void*)k_conv3x3_wino<true, 32>,  (const void*)k_conv3x3_wino<true, 16>};
+        for (const void* k : ks) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsBytes));
+        if (dev >= 0 && dev < 64) attr_set[dev].store(1u, std::memory_order_release);
+    }
+    const int th = (height + 1) / 2, tw = (width + 1) / 2;
+    const int tc = tw > 32 ? 64 : (tw > 16 ? 32 : 16), tr = kWinoTM / tc;
+    const long long n_work = (((long long)batch * th + tr - 1) / tr) * ((tw + tc - 1) / tc) * (cout / kWinoTN);
+    if (n_work >= 2147483647LL) return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_bias_relu: too many tiles");
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+    const unsigned grid = (unsigned)std::min<long long>(n_work, n_cu);  // persistent: one workgroup (4 waves, 156 KiB of LDS) per CU
+    hipError_t e = pool ? wino_launch<true>(tc, grid, (hipStream_t)stream, x, packed, bias, zeros, y, batch, height, width, cin, cout, out_nhwc)
+                        : wino_launch<false>(tc, grid, (hipStream_t)stream, x, packed, bias, zeros, y, batch, height, width, cin, cout, out_nhwc);
+    HIP_TRY(e);
+    return IRIS_OK;
+}

@@ -479,6 +479,44 @@ def conv3x3_c32_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Ten
     return y
 
 
+def wino_pack_weights(weight: torch.Tensor) -> torch.Tensor:
+    """U = G g G^T of a [Cout, Cin, 3, 3] convolution weight in the Winograd kernel's LDS order (iris_wino_pack_weights, on the
+    host, once per layer); returns a device tensor of 16 Cin Cout floats on the weight's device."""
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    if tuple(weight.shape[2:]) != (3, 3):
+        raise ValueError("wino_pack_weights: a [Cout, Cin, 3, 3] weight is expected")
+    host = np.ascontiguousarray(weight.detach().to(torch.float32).cpu().contiguous().numpy())
+    out = np.empty(int(N.lib().iris_wino_packed_len(cin, cout)), np.float32)
+    N.check(N.lib().iris_wino_pack_weights(host.ctypes.data, cin, cout, out.ctypes.data), "iris_wino_pack_weights")
+    return torch.from_numpy(out).to(weight.device)
+
+
+def to_chunked(x: torch.Tensor) -> torch.Tensor:
+    """channels_last [B, C, H, W] (or any layout) -> the channel-chunked activation [B, C / 8, H, W, 8] of the Winograd layers."""
+    b, c, h, w = (int(v) for v in x.shape)
+    return x.permute(0, 2, 3, 1).reshape(b, h, w, c // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
+
+
+def conv3x3_wino_bias_relu(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, zeros: torch.Tensor, cout: int,
+                           pool: bool = False, out_nhwc: bool = False) -> torch.Tensor:
+    """relu(conv2d(x, weight, padding=1) + bias), with `pool` max-pooled 2x2 'same' behind it, as Winograd F(2x2, 3x3) on the
+    fp32 matrix cores (iris_conv3x3_wino_bias_relu).  x: channel-chunked [B, Cin / 8, H, W, 8]; packed: `wino_pack_weights`;
+    returns the chunked [B, cout / 8, Ho, Wo, 8] or, with `out_nhwc`, a channels_last [B, cout, Ho, Wo] tensor."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[4] == 8 and x.is_contiguous()):
+        raise ValueError("conv3x3_wino_bias_relu: x must be a contiguous float32 device tensor [B, Cin / 8, H, W, 8] (no CPU fallback)")
+    b, cbk, h, w, _ = (int(v) for v in x.shape)
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
+    if out_nhwc:
+        y = torch.empty((b, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    else:
+        y = torch.empty((b, cout // 8, ho, wo, 8), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = N.lib().iris_conv3x3_wino_bias_relu(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), zeros.data_ptr(), y.data_ptr(), b, h, w,
+                                                 8 * cbk, int(cout), 1 if pool else 0, 1 if out_nhwc else 0, _stream_ptr(x.device))
+    N.check(rc, "iris_conv3x3_wino_bias_relu")
+    return y
+
+
 def _check_bilstm(gx, w_hh, who):
     if (gx.dim() != 4 or tuple(gx.shape[2:]) != (2, 512) or tuple(w_hh.shape) != (2, 512, 128) or not gx.is_cuda
             or gx.dtype != torch.float32 or w_hh.dtype != torch.float32 or w_hh.device != gx.device):

@@ -1071,6 +1071,60 @@ class _ConvBiasReLU(nn.Module):
         return _fe.bias_relu_maxpool(y, self.bias) if self.pool else _fe.bias_relu_(y, self.bias)
 
 
+WINO_CONVS = os.environ.get("IRIS_WINO", "1") != "0"   # blocks 2-5 of the InferenceEngine as Winograd F(2x2, 3x3) on the fp32 MFMA
+
+
+class _WinoStack(nn.Module):
+    """Inference form of a run of ConvMPBlocks with 8 | Cin and 64 | Cout (blocks 2-5 of the CRNN, sj_train.py:222-242): every
+    Conv2D 3x3 + folded bias + ReLU (+ the block's MaxPool) as ONE launch of the Winograd F(2x2, 3x3) kernel on the fp32
+    matrix cores (iris_conv3x3_wino_bias_relu: 16 instead of 36 multiplies per output tile; MIOpen's implicit GEMMs already
+    sit at the fp32 MFMA rate).  The layers hand each other the channel-chunked activation [B, C / 8, H, W, 8]; the first one
+    converts from channels_last, the last one writes channels_last again."""
+
+    def __init__(self, blocks):
+        super().__init__()
+        self.layers = []  # (index, cout, pool)
+        dev = None
+        for blk in blocks:
+            convs = list(blk.convs)
+            has_pool = isinstance(blk.pool, nn.MaxPool2d) or getattr(blk, '_pool_fused', False)
+            for i, m in enumerate(convs):
+                conv = m[0] if isinstance(m, nn.Sequential) else m
+                w, b = conv.weight.detach(), conv.bias.detach()
+                dev = w.device
+                k = len(self.layers)
+                self.register_buffer(f"packed{k}", _fe.wino_pack_weights(w), persistent=False)
+                self.register_buffer(f"bias{k}", b.to(torch.float32).contiguous().clone(), persistent=False)
+                self.layers.append((k, int(w.shape[0]), has_pool and i == len(convs) - 1))
+        self.register_buffer("zeros", torch.zeros(64, dtype=torch.float32, device=dev), persistent=False)
+
+    @staticmethod
+    def eligible(blk) -> bool:
+        def pair(v):
+            return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+        if not isinstance(blk, ConvMPBlock):
+            return False
+        if not (isinstance(blk.pool, nn.Identity) or _is_pool_2x2_same(blk.pool)):
+            return False
+        for m in blk.convs:
+            conv = m[0] if isinstance(m, nn.Sequential) else m
+            if not (isinstance(conv, nn.Conv2d) and (not isinstance(m, nn.Sequential) or (len(m) == 3 and isinstance(m[1], nn.Identity)))):
+                return False
+            if not (pair(conv.kernel_size) == (3, 3) and pair(conv.padding) == (1, 1) and pair(conv.stride) == (1, 1)
+                    and pair(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is not None
+                    and conv.weight.dtype == torch.float32 and conv.in_channels % 8 == 0 and conv.out_channels % 64 == 0):
+                return False
+        return True
+
+    def forward(self, x):
+        x = _fe.to_chunked(x)
+        last = len(self.layers) - 1
+        for k, cout, pool in self.layers:
+            x = _fe.conv3x3_wino_bias_relu(x, getattr(self, f"packed{k}"), getattr(self, f"bias{k}"), self.zeros, cout, pool=pool,
+                                           out_nhwc=(k == last))
+        return x
+
+
 class _BiLSTM128(torch.autograd.Function):
     """out = recurrence(gx, w_hh) of a bidirectional LSTM(128) with both passes through time inside ONE HIP launch each
     (iris_bilstm128_forward / _backward).  backward returns dgx (autograd carries it on into W_ih, the biases and x through
@@ -1164,6 +1218,17 @@ class InferenceEngine:
         self.hip_convs = 0
         self.fused_lstm = False
         dev = next(self.model.parameters()).device
+        self.wino_convs = 0
+        if fuse_epilogues and hip_convs and WINO_CONVS and dev.type == 'cuda':
+            # the trailing run of plain ConvMPBlocks whose convolutions the Winograd kernel takes (blocks 2-5 of v9): one module
+            feats = list(self.model.features)
+            k = len(feats)
+            while k > 1 and _WinoStack.eligible(feats[k - 1]):
+                k -= 1
+            if k < len(feats):
+                stack = _WinoStack(feats[k:])
+                self.wino_convs = len(stack.layers)
+                self.model.features = nn.Sequential(*feats[:k], stack)
         if fuse_epilogues and dev.type == 'cuda':
             first = True
             for blk in self.model.features:
@@ -1186,6 +1251,8 @@ class InferenceEngine:
                 if has_pool:
                     blk.pool = nn.Identity()
                 self.fused_convs += len(convs)
+        self.fused_convs += self.wino_convs
+        self.hip_convs += self.wino_convs
         if fuse_lstm and dev.type == 'cuda' and _HipBiLSTM.supports(getattr(self.model, 'lstm', None)):
             self.model.lstm = _HipBiLSTM(self.model.lstm)
             self.fused_lstm = True

@@ -348,6 +348,25 @@ int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, const float*
                                int pool, void* stream);
 
 /*
+ * Blocks 2-5 of the CRNN for inference: Conv2D(cin -> cout, 3x3 'same') + (BatchNorm-folded) bias + ReLU, with pool != 0 the
+ * block's MaxPool2D(2, 2, 'same') behind it (sj_train.py:191-201, 222-242), as a Winograd F(2x2, 3x3) transform on the fp32
+ * matrix cores: 16 instead of 36 multiplies per 2 x 2 output tile and channel pair - MIOpen's implicit GEMMs already run these
+ * layers at the fp32 MFMA rate.  fp32 throughout; against an fp64 convolution the error is that of a direct fp32 convolution
+ * (<= 1e-6 of the output's peak).  cin % 8 == 0, cout % 64 == 0.
+ *   x      channel-chunked activation [batch][cin / 8][height][width][8] (8 channels of a pixel contiguous), DEVICE, 16-byte
+ *          aligned, fewer than 2^31 elements
+ *   packed iris_wino_pack_weights(weight [cout][cin][3][3] contiguous, HOST) -> U = G g G^T in the kernel's LDS order,
+ *          iris_wino_packed_len(cin, cout) = 16 cin cout floats (HOST buffers; upload the result once per layer)
+ *   zeros  >= 16 floats of zeros, DEVICE, 16-byte aligned: where every out-of-image pixel is fetched from
+ *   y      [batch][cout / 8][Ho][Wo][8] - the next layer's x - or, with out_nhwc != 0, channels-last [batch][Ho][Wo][cout];
+ *          Ho x Wo = height x width, or ceil(height / 2) x ceil(width / 2) when pooled
+ */
+size_t iris_wino_packed_len(int cin, int cout);
+int iris_wino_pack_weights(const float* weight_host, int cin, int cout, float* packed_host);
+int iris_conv3x3_wino_bias_relu(const float* x, const float* packed, const float* bias, const float* zeros, float* y, int batch,
+                                int height, int width, int cin, int cout, int pool, int out_nhwc, void* stream);
+
+/*
  * The CRNN's first layer in TRAINING mode - Conv2D(3x3 'same', 1 or 2 input channels) + BatchNormalization + ReLU
  * (sj_train.py:191-201, 244) - with the convolution recomputed from x wherever its output is needed (9-18 FMAs per value
  * against 4 bytes of traffic): z is never stored.  x [batch, in_channels, height, width] contiguous; weight

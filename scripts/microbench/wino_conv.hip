@@ -1,0 +1,29 @@
+// Standalone build of the Winograd convolution kernel (challenge_amd/csrc/k_conv_wino.h) for the round-5 microbenchmark:
+//   hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared -o scripts/microbench/libwino.so scripts/microbench/wino_conv.hip
+// driven by scripts/gpu_wino_bench.py (ctypes) against torch / MIOpen on the same shapes.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <type_traits>
+
+enum { IRIS_OK = 0, IRIS_E_INVALID = -1, IRIS_E_UNSUPPORTED = -2 };
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* wino_last_error(void) { return g_err; }
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail((int)e_, "%s failed: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+#define IRIS_WINO_STANDALONE 1
+#include "../../challenge_amd/csrc/k_conv_wino.h"

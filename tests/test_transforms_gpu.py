@@ -1103,13 +1103,50 @@ def test_model_predict_uses_a_cached_engine(dev):
 
     p1 = model.predict(x, batch_size=4)
     eng1 = model._predict_engine[1]
-    assert eng1.hip_convs == 2 and eng1.fused_lstm and float((p1 - reference()).abs().max()) <= 1e-4
+    assert eng1.hip_convs == 14 and eng1.wino_convs == 12 and eng1.fused_lstm and float((p1 - reference()).abs().max()) <= 1e-4
     model.predict(x)
     assert model._predict_engine[1] is eng1                       # unchanged weights: the same engine
     model.train_step((x[:4], y[:4]))
     p2 = model.predict(x)
     assert model._predict_engine[1] is not eng1 and model.training   # rebuilt; the training flag is left alone
     assert float((p2 - reference()).abs().max()) <= 1e-4 and float((p2 - p1).abs().max()) > 0
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout", [(2, 32, 256, 32, 64), (2, 32, 256, 64, 64), (3, 16, 128, 64, 128), (2, 16, 128, 128, 128),
+                                            (5, 8, 64, 256, 256), (3, 4, 32, 512, 512), (7, 2, 16, 512, 512),     # the CRNN's own shapes
+                                            (2, 40, 256, 32, 64), (3, 5, 32, 256, 512), (1, 7, 9, 16, 64), (2, 3, 70, 8, 128),
+                                            (1, 1, 1, 8, 64), (130, 2, 2, 24, 64)])                                   # odd sizes, edges
+def test_winograd_convolution_matches_fp64(dev, b, h, w, cin, cout):
+    """Blocks 2-5 of the inference engine: Conv2D 3x3 'same' + bias + ReLU (+ MaxPool 2x2 'same') as Winograd F(2x2, 3x3) on
+    the fp32 matrix cores (iris_conv3x3_wino_bias_relu) against an fp64 convolution: as close as MIOpen's direct fp32
+    convolution is (stated bound 2e-6 of the output's peak, i.e. 10x the typical error); pooled and unpooled, chunked and
+    channels-last outputs identical; every tile-block geometry (64, 32, 16 tile columns), odd heights / widths, tile rows that
+    straddle images, batches that do not fill a block."""
+    from challenge_amd import frontend as FE
+    g = torch.Generator(device=dev).manual_seed(b * 1000 + h)
+    x = torch.randn(b, cin, h, w, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(cout, cin, 3, 3, generator=g, device=dev) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g, device=dev) * 0.1
+    zeros = torch.zeros(64, device=dev)
+    packed = FE.wino_pack_weights(wt)
+    xc = FE.to_chunked(x)
+    assert tuple(xc.shape) == (b, cin // 8, h, w, 8)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1).relu()
+    for pool in (False, True):
+        want = torch.nn.functional.max_pool2d(ref, 2, 2, ceil_mode=True) if pool else ref
+        y_cl = FE.conv3x3_wino_bias_relu(xc, packed, bias, zeros, cout, pool=pool, out_nhwc=True)
+        assert tuple(y_cl.shape) == tuple(want.shape) and y_cl.is_contiguous(memory_format=torch.channels_last)
+        err = float((y_cl.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+        assert err <= 2e-6, (pool, err)
+        y_ch = FE.conv3x3_wino_bias_relu(xc, packed, bias, zeros, cout, pool=pool)
+        ho, wo = want.shape[2], want.shape[3]
+        assert tuple(y_ch.shape) == (b, cout // 8, ho, wo, 8)
+        assert torch.equal(y_ch.permute(0, 1, 4, 2, 3).reshape(b, cout, ho, wo), y_cl)
+        assert torch.equal(FE.to_chunked(y_cl), y_ch)      # the next layer's input, either way
+    with pytest.raises(ValueError):
+        FE.conv3x3_wino_bias_relu(xc, packed, bias, zeros, cout + 8)       # cout must be a multiple of 64
+    with pytest.raises(ValueError):
+        FE.conv3x3_wino_bias_relu(x, packed, bias, zeros, cout)            # not the chunked layout
 
 
 def test_hip_bilstm_matches_torch(dev):
@@ -1256,7 +1293,7 @@ def test_inference_engine_matches_module(dev):
     fe = S.WaveFrontend(1024, 256, 64, 16000, 1, 4, length, dev, training=False)
     wav = torch.randn(4, 1, length, device=dev) * 0.1
     eng = S.InferenceEngine(model, fe, wav)
-    assert eng.fused_convs == 14 and eng.fused_lstm and eng.hip_convs == 2
+    assert eng.fused_convs == 14 and eng.fused_lstm and eng.hip_convs == 14 and eng.wino_convs == 12  # every convolution is a HIP kernel
     model.eval()
     with torch.no_grad():
         want = model(fe(wav))
