@@ -57,10 +57,10 @@ SIGNATURES = {
     "iris_bn_relu_pool_apply": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_pool_bwd_reduce": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_pool_bwd_dx": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "iris_conv3x3_c32_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "iris_conv3x3_c32_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "iris_wino_packed_len": (_sz, [_i, _i]),
     "iris_wino_pack_weights": (_i, [_vp, _i, _i, _vp]),
-    "iris_conv3x3_wino_bias_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "iris_conv3x3_wino_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "iris_conv0_dweight_len": (_sz, [_i, _i]),
     "iris_conv0_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "iris_conv0_bn_relu": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),

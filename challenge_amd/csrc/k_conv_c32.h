@@ -63,7 +63,8 @@ __device__ __forceinline__ void c32_groups(float (&abuf)[2][8], const float (&br
     }
 }
 
-template <bool POOL>
+// CHUNKED: y in the channel-chunked layout [B][4][Ho][Wo][8] the Winograd layers read (k_conv_wino.h) instead of channels-last
+template <bool POOL, bool CHUNKED = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int H,
                                                         int W) {
@@ -127,7 +128,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
                 for (int r = 0; r < 16; ++r) {
                     const int row_i = (r & 3) + 8 * (r >> 2) + 4 * hl;
                     const int orow = h0 + 2 * t + ((row_i >> 1) & 1), ocol = w0 + 16 * wv + 2 * (row_i >> 2) + (row_i & 1);
-                    if (orow < H && ocol < W) y[(((size_t)b * H + orow) * W + ocol) * kC32 + i] = fmaxf(acc[r] + bj, 0.f);
+                    if (orow < H && ocol < W)
+                        y[CHUNKED ? ((((size_t)b * 4 + (i >> 3)) * H + orow) * W + ocol) * 8 + (i & 7)
+                                  : (((size_t)b * H + orow) * W + ocol) * kC32 + i] = fmaxf(acc[r] + bj, 0.f);
                 }
             } else {
                 const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
                     }
                     const int pcol = (w0 >> 1) + 8 * wv + q;
                     if (prow < Ho && pcol < Wo && or0 < H && oc0 < W)
-                        y[(((size_t)b * Ho + prow) * Wo + pcol) * kC32 + i] = fmaxf(m + bj, 0.f);
+                        y[CHUNKED ? ((((size_t)b * 4 + (i >> 3)) * Ho + prow) * Wo + pcol) * 8 + (i & 7)
+                                  : (((size_t)b * Ho + prow) * Wo + pcol) * kC32 + i] = fmaxf(m + bj, 0.f);
                 }
             }
         }
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
 }
 
 extern "C" int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, const float* bias, float* y, int batch, int height,
-                                          int width, int pool, void* stream) {
+                                          int width, int pool, int out_chunked, void* stream) {
     if (!x || !weight || !bias || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_c32_bias_relu: NULL argument");
     if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_c32_bias_relu: empty tensor");
     if ((reinterpret_cast<uintptr_t>(x) & 15)) return fail(IRIS_E_INVALID, "iris_conv3x3_c32_bias_relu: x must be 16-byte aligned");
@@ -168,14 +172,21 @@ extern "C" int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, c
                                     (int)kC32LdsBytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c32<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kC32LdsBytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c32<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kC32LdsBytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c32<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kC32LdsBytes));
         if (dev >= 0 && dev < 64) attr_set[dev].store(1u, std::memory_order_release);
     }
     const long long n_tiles = (long long)((width + kC32TileW - 1) / kC32TileW) * ((height + kC32TileH - 1) / kC32TileH) * batch;
     if (n_tiles >= 2147483647LL) return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_c32_bias_relu: too many tiles");
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const unsigned grid = (unsigned)std::min<long long>(n_tiles, 2LL * n_cu);  // persistent: two workgroups per CU walk the tiles
-    if (pool) k_conv3x3_c32<true><<<grid, 256, kC32LdsBytes, (hipStream_t)stream>>>(x, weight, bias, y, batch, height, width);
-    else k_conv3x3_c32<false><<<grid, 256, kC32LdsBytes, (hipStream_t)stream>>>(x, weight, bias, y, batch, height, width);
+    hipStream_t s = (hipStream_t)stream;
+    if (pool && out_chunked) k_conv3x3_c32<true, true><<<grid, 256, kC32LdsBytes, s>>>(x, weight, bias, y, batch, height, width);
+    else if (pool) k_conv3x3_c32<true><<<grid, 256, kC32LdsBytes, s>>>(x, weight, bias, y, batch, height, width);
+    else if (out_chunked) k_conv3x3_c32<false, true><<<grid, 256, kC32LdsBytes, s>>>(x, weight, bias, y, batch, height, width);
+    else k_conv3x3_c32<false><<<grid, 256, kC32LdsBytes, s>>>(x, weight, bias, y, batch, height, width);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }

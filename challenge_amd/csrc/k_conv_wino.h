@@ -16,7 +16,7 @@
 // x 64 output channels.  K runs over the input channels in chunks of 8, everything double-buffered in LDS.
 // Activations are CHANNEL-CHUNKED: x [B][Cin / 8][H][W][8] - a chunk of 8 channels of a row of pixels is contiguous, so
 // the input of a chunk arrives by LDS-DMA (global_load_lds_dwordx4: no registers, no wait counters shared with the
-// compiler's own loads) in whole cache lines; out-of-image pixels are fetched from a block of zeros.  Each wave stages,
+// compiler's own loads) in whole cache lines; out-of-image pixels are LDS slots zeroed once per block and masked out of the DMA.  Each wave stages,
 // privately, exactly the pixels ITS transform items read (3 patch rows x one 16-byte channel group), so the hand-over raw ->
 // patch registers -> next DMA needs no workgroup barrier.  U comes by LDS-DMA too (the host packs it in LDS order).
 // One wave per SIMD means nothing else hides latency: the K loop is written as 64 SLOTS per chunk - one MFMA each, fenced
@@ -62,26 +62,40 @@ __device__ __forceinline__ void wino_dma16(const float* src /*uniform*/, unsigne
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane16), "s"(s), "s"(lds) : "memory");
 }
-__device__ __forceinline__ void wino_dma16_gather(const float* src /*per lane*/, unsigned lds /*uniform*/) {
+// the same for gathered pieces: lane l moves 16 bytes from base + off[l] (base uniform, off a 32-bit byte offset) - the lanes of
+// `mask` only: the others touch neither memory nor their LDS slot (which the caller has zeroed: out-of-image pixels)
+__device__ __forceinline__ void wino_dma16_gather(const float* base /*uniform*/, unsigned off, unsigned long long mask /*uniform*/,
+                                                  unsigned lds /*uniform*/) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const float* s = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+    unsigned long long keep_exec;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(keep_exec) : "v"(off), "s"(s), "s"(mask), "s"(lds) : "memory");
 }
-__device__ __forceinline__ float4 wino_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 wino_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+typedef struct { f32x2 lo, hi; } wino_v4;  // four channels as two register pairs: sums and differences are v_pk_add_f32
+__device__ __forceinline__ wino_v4 operator+(wino_v4 a, wino_v4 b) { return {a.lo + b.lo, a.hi + b.hi}; }
+// (a - b as a packed FMA with a (-1, -1) constant: exact, and ONE v_pk_fma_f32 - the compiler scalarises a vector fsub)
+__device__ __forceinline__ f32x2 wino_sub2(f32x2 a, f32x2 b) {
+    const f32x2 m1 = {-1.0f, -1.0f};
+    return __builtin_elementwise_fma(b, m1, a);
+}
+__device__ __forceinline__ wino_v4 operator-(wino_v4 a, wino_v4 b) { return {wino_sub2(a.lo, b.lo), wino_sub2(a.hi, b.hi)}; }
 
 struct WinoWave {
     f32x16 acc[16];
     f32x2 ops[2][8];      // operand pairs of a group of 4 positions: [0..3] = V (A operand), [4..7] = U (B operand); double-buffered
-    float4 d[3][4];       // this thread's patch rows (three of the four) x columns, one channel group of 4
-    float4 w[2][4];       // B^T d, two rows xi of this thread's half
+    wino_v4 d[3][4];      // this thread's patch rows (three of the four) x columns, one channel group of 4
+    wino_v4 w[2][4];      // B^T d, two rows xi of this thread's half
 };
 
 // TC: tile columns of a workgroup's block (64 / TC tile rows): min(ceil(W / 2), 64) rounded up to a power of two
 template <bool POOL, int TC>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict__ x, const float* __restrict__ u,
-                                                         const float* __restrict__ bias, const float* __restrict__ zeros,
-                                                         float* __restrict__ y, int B, int H, int W, int Cin, int Cout, int out_nhwc) {
+                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
+                                                         int Cin, int Cout, int out_nhwc) {
     extern __shared__ __attribute__((aligned(16))) float wino_lds[];
     constexpr int TR = kWinoTM / TC, PW = 2 * TC + 2, kPieces = TR * 3 * PW, kDmaRows = (kPieces + 63) / 64;
     static_assert(kPieces <= kWinoRawPieces, "raw region too small");
@@ -108,7 +122,12 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
         const float* const ubase = u + ((size_t)cb * n_chunks) * (kWinoUFloats);
         // ---- the input pieces this lane requests per chunk: piece i = lane + 64 k of the wave's staging order
         //      [strip (tile row of the block)][patch row r of this half][pixel px of the strip], 16 bytes = channel group p_cg
-        unsigned poff[kDmaRows];  // element offset inside a chunk plane of image 0 (32 bit), or ~0u: out of the image -> zeros
+        // A piece's LDS slot, its offset and whether it lies inside the image are the same for every chunk of the work item:
+        // byte offset inside a chunk plane (32 bit) + a lane mask per DMA row; the slots of out-of-image pieces are zeroed HERE,
+        // once, and never requested (EXEC-masked DMA), so no zero source and no per-chunk address arithmetic is needed.
+        unsigned poff[kDmaRows];
+        unsigned long long pmask[kDmaRows];
+        __syncthreads();  // the previous work item's last buffers - and every wave's last read of its staging area - are done
 #pragma unroll
         for (int k = 0; k < kDmaRows; ++k) {
             const int i = lane + 64 * k;
@@ -116,13 +135,15 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
             const int R = R0 + strip, b_ = R / TH, th = R - b_ * TH;
             const int hh = 2 * th - 1 + p_half + r, ww = 2 * tc0 - 1 + px;
             const bool ok = i < kPieces && R < n_rows && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            poff[k] = ok ? (unsigned)((((size_t)b_ * (Cin / 8)) * H + hh) * W + ww) * 8u + 4u * p_cg : ~0u;
+            poff[k] = ok ? ((unsigned)((((size_t)b_ * (Cin / 8)) * H + hh) * W + ww) * 8u + 4u * p_cg) * 4u : 0u;
+            pmask[k] = __ballot(ok);
+            if (!ok && i < kWinoRawPieces) reinterpret_cast<float4*>(raw)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         auto dma_x = [&](int chunk, int k0, int k1) {  // rows k0 .. k1 - 1 of the wave's staging area for `chunk`
             const float* xc = x + (size_t)chunk * plane;  // uniform
 #pragma unroll
             for (int k = 0; k < kDmaRows; ++k)
-                if (k >= k0 && k < k1) wino_dma16_gather(poff[k] != ~0u ? xc + poff[k] : zeros + 4 * (lane & 3), raw_l + 1024u * k);
+                if (k >= k0 && k < k1) wino_dma16_gather(xc, poff[k], pmask[k], raw_l + 1024u * k);
         };
         auto dma_u = [&](int chunk, int buf, int j0, int j1) {  // the chunk of U: one contiguous 32 KiB block in LDS order, 8 rows of
             const float* us_g = ubase + (size_t)chunk * kWinoUFloats;  // 1 KiB per wave (rows j0 .. j1 - 1 of them)
@@ -133,24 +154,25 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
         };
         // this lane's tile inside the block and its patch in the staging area
         const int trow = lane / TC, tcol = lane % TC;
-        const float4* const patch = reinterpret_cast<const float4*>(raw) + (trow * 3) * PW + 2 * tcol;
+        const wino_v4* const patch = reinterpret_cast<const wino_v4*>(raw) + (trow * 3) * PW + 2 * tcol;
         auto read_patch = [&](int i) { s.d[i >> 2][i & 3] = patch[(i >> 2) * PW + (i & 3)]; };  // i = 4 r + c
-        auto row_stage = [&](int e, int c) {
+        auto row_stage = [&](auto half_tag, int e, int c) {
             // rows of B^T d: half 0 holds patch rows 0, 1, 2 -> xi 0 = d0 - d2, xi 1 = d1 + d2; half 1 holds rows 1, 2, 3 ->
             // xi 2 = d2 - d1, xi 3 = d1 - d3
-            const float4 a = s.d[0][c], b = s.d[1][c], dd = s.d[2][c];
-            if (p_half == 0) s.w[e][c] = e == 0 ? wino_sub(a, dd) : wino_add(b, dd);
-            else s.w[e][c] = e == 0 ? wino_sub(b, a) : wino_sub(a, dd);
+            constexpr int half = decltype(half_tag)::value;
+            const wino_v4 a = s.d[0][c], b = s.d[1][c], dd = s.d[2][c];
+            if constexpr (half == 0) s.w[e][c] = e == 0 ? a - dd : b + dd;
+            else s.w[e][c] = e == 0 ? b - a : a - dd;
         };
         auto col_stage = [&](int buf, int e, int nu) {
-            const float4 (&w)[4] = s.w[e];
-            const float4 v = nu == 0 ? wino_sub(w[0], w[2]) : nu == 1 ? wino_add(w[1], w[2]) : nu == 2 ? wino_sub(w[2], w[1]) : wino_sub(w[1], w[3]);
+            const wino_v4 (&w)[4] = s.w[e];
+            const wino_v4 v = nu == 0 ? w[0] - w[2] : nu == 1 ? w[1] + w[2] : nu == 2 ? w[2] - w[1] : w[1] - w[3];
             const int pos = 4 * (2 * p_half + e) + nu;
-            // channels k = 4 p_cg + {0, 1, 2, 3}: pair p_cg; hl 0 holds (k, k + 2) = (.x, .z), hl 1 holds (.y, .w)
+            // the chunk's channels 4 p_cg + {0, 1, 2, 3} are operand pair p_cg: lanes hl 0 take (.x, .y) for their two MFMA
+            // steps, lanes hl 1 take (.z, .w) - register pairs as they are (iris_wino_pack_weights orders U the same way)
             f32x2* dst = reinterpret_cast<f32x2*>(wino_lds + buf * kWinoBuf) + ((pos * 2 + p_cg) * 2) * kWinoTM + lane;
-            const f32x2 lo = {v.x, v.z}, hi = {v.y, v.w};
-            dst[0] = lo;
-            dst[kWinoTM] = hi;
+            dst[0] = v.lo;
+            dst[kWinoTM] = v.hi;
         };
         auto read_op = [&](f32x2 (&ops)[8], int buf, int gi, int j) {  // operand j of group gi = (pr, g): positions 4 g + (j & 3)
             const int pr = gi >> 2, p = 4 * (gi & 3) + (j & 3);
@@ -165,8 +187,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
             for (int r = 0; r < 16; ++r) s.acc[p][r] = 0.f;
 
         // ---- prologue (not overlapped): V(0), U(0) into buffer 0; the patches of chunk 1 in registers; the input of chunk 2 requested
-        __syncthreads();  // the previous work item's last buffer is consumed
         dma_u(0, 0, 0, 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zeros above are in place before any request can land beside them
         dma_x(0, 0, kDmaRows);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -176,7 +198,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) row_stage(e, c);
+            for (int c = 0; c < 4; ++c) {
+                if (p_half == 0) row_stage(std::integral_constant<int, 0>{}, e, c);
+                else row_stage(std::integral_constant<int, 1>{}, e, c);
+            }
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) col_stage(0, e, nu);
         }
@@ -197,10 +222,11 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
         //   slot  52        wait until at most the 8 U requests are outstanding: the staging area holds chunk c + 2
         //   slots 52 .. 63  patches of chunk c + 2 -> registers (consumed during chunk c + 1)
         //   top of c + 1    wait for everything (U(c + 1) has landed), barrier
-        auto chunk_body = [&](auto next_tag, int chunk) {
+        auto chunk_body = [&](auto next_tag, auto half_tag, int chunk) {
             constexpr bool next = decltype(next_tag)::value;
             const int buf = chunk & 1;
-            const bool next2 = chunk + 2 < n_chunks;  // uniform
+            // (the last two chunks of a work item request / read a chunk that exists instead of chunk + 2: valid memory, never used)
+            const int chunk2 = min(chunk + 2, n_chunks - 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!WINO_ABL(1)) __syncthreads();  // buffer `buf` is complete; buffer buf ^ 1 is free (its readers passed this barrier)
 #pragma unroll
@@ -216,34 +242,41 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
                                        : __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, s.acc[p], 0, 0, 0);
                     if (gi < 7 && !WINO_ABL(8)) read_op(s.ops[(gi + 1) & 1], buf, gi + 1, j);   // next group's operand j
                     if constexpr (next) {
-                        if (sl < kDmaRows && next2 && !WINO_ABL(16)) dma_x(chunk + 2, sl, sl + 1);
+                        if (sl < kDmaRows && !WINO_ABL(16)) dma_x(chunk2, sl, sl + 1);
                         if (sl >= 8 && sl < 16 && !WINO_ABL(2)) dma_u(chunk + 1, buf ^ 1, sl - 8, sl - 7);
-                        if (sl >= 20 && sl < 28 && !WINO_ABL(4)) row_stage((sl - 20) >> 2, (sl - 20) & 3);
+                        if (sl >= 20 && sl < 28 && !WINO_ABL(4)) row_stage(half_tag, (sl - 20) >> 2, (sl - 20) & 3);
                         if (sl >= 32 && sl < 40 && !WINO_ABL(4)) col_stage(buf ^ 1, (sl - 32) >> 2, (sl - 32) & 3);
                         if (sl == 52 && !WINO_ABL(4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                        if (sl >= 52 && next2 && !WINO_ABL(4)) read_patch(sl - 52);
+                        if (sl >= 52 && !WINO_ABL(4)) read_patch(sl - 52);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         };
-        for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) chunk_body(std::true_type{}, chunk);
-        chunk_body(std::false_type{}, n_chunks - 1);
+        if (p_half == 0) {  // wave-uniform: two copies of the loop, no per-lane select in the row stage
+            for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) chunk_body(std::true_type{}, std::integral_constant<int, 0>{}, chunk);
+        } else {
+            for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) chunk_body(std::true_type{}, std::integral_constant<int, 1>{}, chunk);
+        }
+        chunk_body(std::false_type{}, std::integral_constant<int, 0>{}, n_chunks - 1);
 
         // ---- output transform, bias, ReLU (, MaxPool) and store: lane = output channel, register r = tile
         const int co = cb * kWinoTN + 32 * wn + li;
         const float bj = bias[co];
         const int Ho = POOL ? TH : H, Wo = POOL ? TW : W;
-        // element offset of (b, oh, ow, co) = base(b) + (oh Wo + ow) pstride: chunked [B][Cout / 8][Ho][Wo][8] or channels-last
-        const size_t img = (size_t)Ho * Wo * Cout;
-        const size_t cbase = out_nhwc ? (size_t)co : ((size_t)(co >> 3) * Ho * Wo) * 8 + (co & 7);
-        const int pstride = out_nhwc ? Cout : 8;
+        constexpr int kPix = POOL ? 1 : 4;                       // output pixels per tile
+        constexpr int kCcStride = 32 * kPix * 8 + 8;             // floats between channel chunks in the staging area (+ 8: banks)
+        // Chunked output: the values go through LDS (the operand buffers are free once every wave has left the K loop), so
+        // that a wave stores whole runs - 32 tiles of a tile row are 64 (pooled: 32) consecutive pixels x 8 channels = 2 KiB
+        // contiguous per channel chunk and output row - with 16 bytes per lane instead of 4-byte stores 32 bytes at a time.
+        float* const stage = wino_lds + wv * (4 * kCcStride);    // [chunk 4][i 2][tile 32][j 2][8] (pooled: [chunk 4][tile 32][8])
+        // (measured, round 5: the staged form gains 7-10 us per POOLED layer; for the unpooled ones - four times the values -
+        // the extra LDS pass and its registers cost 15 us more than the scattered stores: they keep storing from registers)
+        const bool direct = out_nhwc || !POOL;
+        if (!direct) __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hl;
-            const int t = 32 * wm + row;  // tile of the block
-            const int R = R0 + t / TC, tw_ = tc0 + t % TC;
-            const int b_ = R / TH, th_ = R - b_ * TH;
             float sr[2][4];  // A^T M: rows (m0 + m1 + m2), (m1 - m2 - m3) per column nu
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
@@ -257,31 +290,85 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
                 o[i][0] = sr[i][0] + sr[i][1] + sr[i][2];
                 o[i][1] = sr[i][1] - sr[i][2] - sr[i][3];
             }
-            if (R < n_rows && tw_ < TW) {
-                const int oh = 2 * th_, ow = 2 * tw_;
-                float* const yb = y + (size_t)b_ * img + cbase;
-                if constexpr (POOL) {
-                    float m = o[0][0];  // (oh, ow) is inside whenever the tile exists
-                    if (ow + 1 < W) m = fmaxf(m, o[0][1]);
-                    if (oh + 1 < H) {
-                        m = fmaxf(m, o[1][0]);
-                        if (ow + 1 < W) m = fmaxf(m, o[1][1]);
+            const int t = 32 * wm + row;  // tile of the block
+            const int R = R0 + t / TC, tw_ = tc0 + t % TC;
+            const int b_ = R / TH, th_ = R - b_ * TH;
+            const int oh = 2 * th_, ow = 2 * tw_;
+            float pooled = 0.f;
+            if constexpr (POOL) {
+                pooled = o[0][0];  // (oh, ow) is inside whenever the tile exists; values outside the image never win
+                if (ow + 1 < W) pooled = fmaxf(pooled, o[0][1]);
+                if (oh + 1 < H) {
+                    pooled = fmaxf(pooled, o[1][0]);
+                    if (ow + 1 < W) pooled = fmaxf(pooled, o[1][1]);
+                }
+                pooled = fmaxf(pooled + bj, 0.f);
+            }
+            if (direct) {  // channels-last (the stack's last layer) or unpooled: straight from the registers
+                if (R < n_rows && tw_ < TW) {
+                    // element (b, oh, ow, co): chunked [B][Cout / 8][Ho][Wo][8] or channels-last [B][Ho][Wo][Cout]
+                    float* const yb = y + (size_t)b_ * Ho * Wo * Cout + (out_nhwc ? (size_t)co : ((size_t)(co >> 3) * Ho * Wo) * 8 + (co & 7));
+                    const int ps = out_nhwc ? Cout : 8;
+                    if constexpr (POOL) {
+                        yb[((size_t)th_ * Wo + tw_) * ps] = pooled;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                if (oh + i < H && ow + j < W) yb[((size_t)(oh + i) * Wo + ow + j) * ps] = fmaxf(o[i][j] + bj, 0.f);
                     }
-                    yb[((size_t)th_ * Wo + tw_) * pstride] = fmaxf(m + bj, 0.f);
+                }
+            } else {
+                float* const sp = stage + (li >> 3) * kCcStride + (li & 7);
+                if constexpr (POOL) {
+                    sp[row * 8] = pooled;
                 } else {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            if (oh + i < H && ow + j < W) yb[((size_t)(oh + i) * Wo + ow + j) * pstride] = fmaxf(o[i][j] + bj, 0.f);
+                        for (int j = 0; j < 2; ++j) sp[((i * 32 + row) * 2 + j) * 8] = fmaxf(o[i][j] + bj, 0.f);
                 }
             }
+        }
+        if (!direct) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave reads back what its own lanes wrote: LDS operations
+            __builtin_amdgcn_wave_barrier();                         // of a wave execute in order, this only pins the compiler
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // float4 q = 64 n + lane of a chunk's [i][tile][j][half] (pooled: [tile][half]) block: lane -> (tile, j, half), n -> i and
+            // the upper tile bit.  The lane's two tiles (n even / odd) and where they land in y:
+            constexpr int kPerChunk = 32 * kPix * 2;  // float4 per channel chunk
+            constexpr int kN = kPerChunk / 64;        // store instructions per channel chunk (unpooled 4, pooled 1)
+            const int half8 = lane & 1, jj = POOL ? 0 : (lane >> 1) & 1;
+            size_t goff[POOL ? 1 : 2];
+            bool gok[POOL ? 1 : 2][2];  // [tile slot][i]
+#pragma unroll
+            for (int ts = 0; ts < (POOL ? 1 : 2); ++ts) {
+                const int tl = POOL ? (lane >> 1) : ((lane >> 2) + 16 * ts);
+                const int t = 32 * wm + tl;
+                const int R = R0 + t / TC, tw_ = tc0 + t % TC;
+                const int b_ = R / TH, th_ = R - b_ * TH;
+                const int oh = POOL ? th_ : 2 * th_, ow = (POOL ? tw_ : 2 * tw_) + jj;
+                const bool tile_ok = R < n_rows && tw_ < TW && ow < Wo;
+                goff[ts] = ((((size_t)b_ * (Cout / 8) + (cb * kWinoTN + 32 * wn) / 8) * Ho + oh) * Wo + ow) * 8 + 4 * half8;
+                gok[ts][0] = tile_ok && oh < Ho;
+                gok[ts][1] = tile_ok && oh + 1 < Ho;
+            }
+            const size_t cstride = (size_t)Ho * Wo * 8;  // floats between channel chunks of y
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int n = 0; n < kN; ++n) {
+                    const int i = POOL ? 0 : (n >> 1), ts = POOL ? 0 : (n & 1);
+                    const float4 v = *reinterpret_cast<const float4*>(stage + cc * kCcStride + (n * 64 + lane) * 4);
+                    if (gok[ts][i]) *reinterpret_cast<float4*>(y + goff[ts] + cc * cstride + (size_t)i * Wo * 8) = v;
+                }
         }
     }
 }
 
 // Host side of the packing: weight [Cout][Cin][3][3] (OIHW, contiguous) -> U = G g G^T in the kernel's LDS order
-// [cout block][chunk of 8 cin][pos 16][pair 2][hl 2][cout 64][2], where (pair, hl, j) <-> k = 4 pair + hl + 2 j of the chunk.
+// [cout block][chunk of 8 cin][pos 16][pair 2][hl 2][cout 64][2], where (pair, hl, j) <-> channel 4 pair + 2 hl + j of the chunk.
 extern "C" size_t iris_wino_packed_len(int cin, int cout) { return (cin > 0 && cout > 0) ? wino_packed_floats(cin, cout) : 0; }
 
 extern "C" int iris_wino_pack_weights(const float* weight_host, int cin, int cout, float* packed_host) {
@@ -297,7 +384,7 @@ extern "C" int iris_wino_pack_weights(const float* weight_host, int cin, int cou
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
             const int cb = o / kWinoTN, oc = o % kWinoTN, chunk = c / kWinoKC, k = c % kWinoKC;
-            const int pair = k >> 2, hl = k & 1, j2 = (k >> 1) & 1;
+            const int pair = k >> 2, hl = (k >> 1) & 1, j2 = k & 1;  // channel 4 pair + 2 hl + j2: step j2 of the pair, lanes hl
             for (int xi = 0; xi < 4; ++xi)
                 for (int nu = 0; nu < 4; ++nu) {
                     const double v = t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2];
@@ -310,25 +397,25 @@ extern "C" int iris_wino_pack_weights(const float* weight_host, int cin, int cou
 
 template <bool POOL>
 static hipError_t wino_launch(int tc, unsigned grid, hipStream_t s, const float* x, const float* packed, const float* bias,
-                              const float* zeros, float* y, int batch, int height, int width, int cin, int cout, int out_nhwc) {
-    if (tc >= 64) k_conv3x3_wino<POOL, 64><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, zeros, y, batch, height, width, cin, cout, out_nhwc);
-    else if (tc >= 32) k_conv3x3_wino<POOL, 32><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, zeros, y, batch, height, width, cin, cout, out_nhwc);
-    else k_conv3x3_wino<POOL, 16><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, zeros, y, batch, height, width, cin, cout, out_nhwc);
+                              float* y, int batch, int height, int width, int cin, int cout, int out_nhwc) {
+    if (tc >= 64) k_conv3x3_wino<POOL, 64><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc);
+    else if (tc >= 32) k_conv3x3_wino<POOL, 32><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc);
+    else k_conv3x3_wino<POOL, 16><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc);
     return hipGetLastError();
 }
 
-// x: channel-chunked [B][cin / 8][H][W][8]; packed: iris_wino_pack_weights; zeros: >= 16 floats of zeros (DEVICE; the source
-// of every out-of-image pixel); y: chunked [B][cout / 8][Ho][Wo][8], or channels-last [B][Ho][Wo][cout] with out_nhwc
-extern "C" int iris_conv3x3_wino_bias_relu(const float* x, const float* packed, const float* bias, const float* zeros, float* y,
-                                           int batch, int height, int width, int cin, int cout, int pool, int out_nhwc, void* stream) {
-    if (!x || !packed || !bias || !zeros || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: NULL argument");
+// x: channel-chunked [B][cin / 8][H][W][8]; packed: iris_wino_pack_weights; y: chunked [B][cout / 8][Ho][Wo][8], or channels-last
+// [B][Ho][Wo][cout] with out_nhwc
+extern "C" int iris_conv3x3_wino_bias_relu(const float* x, const float* packed, const float* bias, float* y, int batch, int height,
+                                           int width, int cin, int cout, int pool, int out_nhwc, void* stream) {
+    if (!x || !packed || !bias || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: NULL argument");
     if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: empty tensor");
     if (cin <= 0 || cout <= 0 || (cin % kWinoKC) || (cout % kWinoTN))
         return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_bias_relu: cin %d must be a multiple of %d, cout %d of %d", cin, kWinoKC, cout, kWinoTN);
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(zeros)) & 15)
-        return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: x, the packed weights and the zero block must be 16-byte aligned");
-    if ((long long)batch * height * width * cin >= 4294967295LL / 2)
-        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_bias_relu: tensor too large for 32-bit element offsets");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) & 15)
+        return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: x and the packed weights must be 16-byte aligned");
+    if ((long long)batch * height * width * cin >= 1073741824LL)
+        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_bias_relu: tensor too large for 32-bit byte offsets (>= 2^30 elements)");
     int dev = 0, n_cu = 256;
     HIP_TRY(hipGetDevice(&dev));
     static std::atomic<unsigned> attr_set[64];
@@ -344,8 +431,8 @@ extern "C" int iris_conv3x3_wino_bias_relu(const float* x, const float* packed, 
     if (n_work >= 2147483647LL) return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_bias_relu: too many tiles");
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const unsigned grid = (unsigned)std::min<long long>(n_work, n_cu);  // persistent: one workgroup (4 waves, 156 KiB of LDS) per CU
-    hipError_t e = pool ? wino_launch<true>(tc, grid, (hipStream_t)stream, x, packed, bias, zeros, y, batch, height, width, cin, cout, out_nhwc)
-                        : wino_launch<false>(tc, grid, (hipStream_t)stream, x, packed, bias, zeros, y, batch, height, width, cin, cout, out_nhwc);
+    hipError_t e = pool ? wino_launch<true>(tc, grid, (hipStream_t)stream, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc)
+                        : wino_launch<false>(tc, grid, (hipStream_t)stream, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc);
     HIP_TRY(e);
     return IRIS_OK;
 }

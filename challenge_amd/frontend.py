@@ -461,20 +461,24 @@ def conv3x3_small_bias_relu_nchw(x: torch.Tensor, weight: torch.Tensor, bias: to
     return conv3x3_small_bias_relu(x, weight, bias, channels_last=False)
 
 
-def conv3x3_c32_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, pool: bool = False) -> torch.Tensor:
+def conv3x3_c32_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, pool: bool = False,
+                          out_chunked: bool = False) -> torch.Tensor:
     """relu(conv2d(x, weight, padding=1) + bias), with `pool` max-pooled 2x2 'same' behind it, for a channels_last
     [B, 32, H, W] input and a [32, 32, 3, 3] weight, on the fp32 matrix cores (iris_conv3x3_c32_bias_relu).  Returns a
-    channels_last tensor."""
+    channels_last tensor, or with `out_chunked` the channel-chunked [B, 4, Ho, Wo, 8] activation of the Winograd layers."""
     if (x.dim() != 4 or x.shape[1] != 32 or not x.is_contiguous(memory_format=torch.channels_last) or not x.is_cuda
             or x.dtype != torch.float32 or tuple(weight.shape) != (32, 32, 3, 3) or not weight.is_contiguous()):
         raise ValueError("conv3x3_c32_bias_relu: x must be a float32 channels_last device tensor [B, 32, H, W], weight a contiguous "
                          "[32, 32, 3, 3]")
     b, _, h, w = (int(v) for v in x.shape)
     oh, ow = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
-    y = torch.empty((b, 32, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if out_chunked:  # [B, 4, Ho, Wo, 8]: what the Winograd layers behind it read (no conversion pass)
+        y = torch.empty((b, 4, oh, ow, 8), dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty((b, 32, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         rc = N.lib().iris_conv3x3_c32_bias_relu(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w,
-                                                1 if pool else 0, _stream_ptr(x.device))
+                                                1 if pool else 0, 1 if out_chunked else 0, _stream_ptr(x.device))
     N.check(rc, "iris_conv3x3_c32_bias_relu")
     return y
 
@@ -497,8 +501,8 @@ def to_chunked(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 2, 3, 1).reshape(b, h, w, c // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
 
 
-def conv3x3_wino_bias_relu(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, zeros: torch.Tensor, cout: int,
-                           pool: bool = False, out_nhwc: bool = False) -> torch.Tensor:
+def conv3x3_wino_bias_relu(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, cout: int, pool: bool = False,
+                           out_nhwc: bool = False) -> torch.Tensor:
     """relu(conv2d(x, weight, padding=1) + bias), with `pool` max-pooled 2x2 'same' behind it, as Winograd F(2x2, 3x3) on the
     fp32 matrix cores (iris_conv3x3_wino_bias_relu).  x: channel-chunked [B, Cin / 8, H, W, 8]; packed: `wino_pack_weights`;
     returns the chunked [B, cout / 8, Ho, Wo, 8] or, with `out_nhwc`, a channels_last [B, cout, Ho, Wo] tensor."""
@@ -511,8 +515,8 @@ def conv3x3_wino_bias_relu(x: torch.Tensor, packed: torch.Tensor, bias: torch.Te
     else:
         y = torch.empty((b, cout // 8, ho, wo, 8), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = N.lib().iris_conv3x3_wino_bias_relu(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), zeros.data_ptr(), y.data_ptr(), b, h, w,
-                                                 8 * cbk, int(cout), 1 if pool else 0, 1 if out_nhwc else 0, _stream_ptr(x.device))
+        rc = N.lib().iris_conv3x3_wino_bias_relu(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w, 8 * cbk,
+                                                 int(cout), 1 if pool else 0, 1 if out_nhwc else 0, _stream_ptr(x.device))
     N.check(rc, "iris_conv3x3_wino_bias_relu")
     return y
 

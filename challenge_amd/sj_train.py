@@ -1024,6 +1024,7 @@ class _ConvBiasReLU(nn.Module):
         self.weight = nn.Parameter(conv.weight.detach().clone(memory_format=fmt), requires_grad=False)
         self.bias = nn.Parameter(conv.bias.detach().clone(), requires_grad=False)
         self.padding, self.pool, self.nchw, self.hip = conv.padding, pool, nchw, hip
+        self.out_chunked = False  # 'mfma32' only: hand the Winograd stack behind this layer its chunked activation directly
 
     @staticmethod
     def hip_form(conv: nn.Conv2d) -> Optional[str]:
@@ -1047,7 +1048,7 @@ class _ConvBiasReLU(nn.Module):
         if self.hip == 'mfma32':
             if not x.is_contiguous(memory_format=torch.channels_last):
                 x = x.contiguous(memory_format=torch.channels_last)
-            return _fe.conv3x3_c32_bias_relu(x, self.weight, self.bias, pool=self.pool)
+            return _fe.conv3x3_c32_bias_relu(x, self.weight, self.bias, pool=self.pool, out_chunked=self.out_chunked)
         if self.hip:  # shape outside the HIP kernel's range: MIOpen on the contiguous weight
             y = torch.nn.functional.conv2d(x, self.weight, self.bias, padding=self.padding).relu_()
             return torch.nn.functional.max_pool2d(y, 2, 2, ceil_mode=True) if self.pool else y
@@ -1096,7 +1097,6 @@ class _WinoStack(nn.Module):
                 self.register_buffer(f"packed{k}", _fe.wino_pack_weights(w), persistent=False)
                 self.register_buffer(f"bias{k}", b.to(torch.float32).contiguous().clone(), persistent=False)
                 self.layers.append((k, int(w.shape[0]), has_pool and i == len(convs) - 1))
-        self.register_buffer("zeros", torch.zeros(64, dtype=torch.float32, device=dev), persistent=False)
 
     @staticmethod
     def eligible(blk) -> bool:
@@ -1117,11 +1117,11 @@ class _WinoStack(nn.Module):
         return True
 
     def forward(self, x):
-        x = _fe.to_chunked(x)
+        if x.dim() != 5:  # (the layer in front may already have written the chunked layout)
+            x = _fe.to_chunked(x)
         last = len(self.layers) - 1
         for k, cout, pool in self.layers:
-            x = _fe.conv3x3_wino_bias_relu(x, getattr(self, f"packed{k}"), getattr(self, f"bias{k}"), self.zeros, cout, pool=pool,
-                                           out_nhwc=(k == last))
+            x = _fe.conv3x3_wino_bias_relu(x, getattr(self, f"packed{k}"), getattr(self, f"bias{k}"), cout, pool=pool, out_nhwc=(k == last))
         return x
 
 
@@ -1253,6 +1253,12 @@ class InferenceEngine:
                 self.fused_convs += len(convs)
         self.fused_convs += self.wino_convs
         self.hip_convs += self.wino_convs
+        if self.wino_convs:  # the 32 -> 32 kernel right in front of the Winograd stack writes its input layout itself
+            feats = list(self.model.features)
+            prev = feats[-2] if len(feats) >= 2 else None
+            tail = list(prev.convs)[-1] if isinstance(prev, ConvMPBlock) and len(prev.convs) else None
+            if isinstance(tail, _ConvBiasReLU) and tail.hip == 'mfma32' and isinstance(prev.pool, nn.Identity):
+                tail.out_chunked = True
         if fuse_lstm and dev.type == 'cuda' and _HipBiLSTM.supports(getattr(self.model, 'lstm', None)):
             self.model.lstm = _HipBiLSTM(self.model.lstm)
             self.fused_lstm = True

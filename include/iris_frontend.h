@@ -342,10 +342,11 @@ int iris_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* dz, int bat
  * Second layer of the CRNN's first block for inference: Conv2D(32 -> 32, 3x3 'same') + (BatchNorm-folded) bias + ReLU, and
  * with pool != 0 the block's MaxPool2D(2, 2, 'same') behind it (sj_train.py:191-201, 244), as an implicit GEMM on the fp32
  * matrix cores (exact fp32).  x [batch, height, width, 32] channels-last, weight [32, 32, 3, 3] contiguous, bias [32];
- * y [batch, height, width, 32] or, pooled, [batch, ceil(height / 2), ceil(width / 2), 32].  x 16-byte aligned.
+ * y [batch, height, width, 32] or, pooled, [batch, ceil(height / 2), ceil(width / 2), 32]; with out_chunked != 0 the same
+ * values in the channel-chunked layout [batch][4][Ho][Wo][8] that iris_conv3x3_wino_bias_relu reads.  x 16-byte aligned.
  */
 int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, const float* bias, float* y, int batch, int height, int width,
-                               int pool, void* stream);
+                               int pool, int out_chunked, void* stream);
 
 /*
  * Blocks 2-5 of the CRNN for inference: Conv2D(cin -> cout, 3x3 'same') + (BatchNorm-folded) bias + ReLU, with pool != 0 the
@@ -354,17 +355,16 @@ int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, const float*
  * layers at the fp32 MFMA rate.  fp32 throughout; against an fp64 convolution the error is that of a direct fp32 convolution
  * (<= 1e-6 of the output's peak).  cin % 8 == 0, cout % 64 == 0.
  *   x      channel-chunked activation [batch][cin / 8][height][width][8] (8 channels of a pixel contiguous), DEVICE, 16-byte
- *          aligned, fewer than 2^31 elements
+ *          aligned, fewer than 2^30 elements
  *   packed iris_wino_pack_weights(weight [cout][cin][3][3] contiguous, HOST) -> U = G g G^T in the kernel's LDS order,
  *          iris_wino_packed_len(cin, cout) = 16 cin cout floats (HOST buffers; upload the result once per layer)
- *   zeros  >= 16 floats of zeros, DEVICE, 16-byte aligned: where every out-of-image pixel is fetched from
  *   y      [batch][cout / 8][Ho][Wo][8] - the next layer's x - or, with out_nhwc != 0, channels-last [batch][Ho][Wo][cout];
  *          Ho x Wo = height x width, or ceil(height / 2) x ceil(width / 2) when pooled
  */
 size_t iris_wino_packed_len(int cin, int cout);
 int iris_wino_pack_weights(const float* weight_host, int cin, int cout, float* packed_host);
-int iris_conv3x3_wino_bias_relu(const float* x, const float* packed, const float* bias, const float* zeros, float* y, int batch,
-                                int height, int width, int cin, int cout, int pool, int out_nhwc, void* stream);
+int iris_conv3x3_wino_bias_relu(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width,
+                                int cin, int cout, int pool, int out_nhwc, void* stream);
 
 /*
  * The CRNN's first layer in TRAINING mode - Conv2D(3x3 'same', 1 or 2 input channels) + BatchNormalization + ReLU

@@ -118,14 +118,14 @@ def test_round3_entry_points_validate_before_any_launch():
     assert lib.iris_conv3x3_small_bias_relu_nhwc(p16, p16, None, p16, 1, 1, 32, 8, 8, None) == INVALID
     assert lib.iris_conv3x3_small_bias_relu_nhwc(p16, p16, p16, p16, 1, 1, 48, 8, 8, None) == UNSUPPORTED   # 48 does not divide 1024
     assert lib.iris_conv3x3_small_bias_relu_nhwc(p16, p16, p16, p16, 1, 1, 32, 8, 4096, None) == UNSUPPORTED  # rows beyond the LDS
-    assert lib.iris_conv3x3_c32_bias_relu(None, p16, p16, p16, 1, 8, 8, 0, None) == INVALID
-    assert lib.iris_conv3x3_c32_bias_relu(p8, p16, p16, p16, 1, 8, 8, 1, None) == INVALID                  # alignment
-    assert lib.iris_conv3x3_c32_bias_relu(p16, p16, p16, p16, 0, 8, 8, 1, None) == INVALID
-    assert lib.iris_conv3x3_wino_bias_relu(None, p16, p16, p16, p16, 1, 8, 8, 64, 64, 0, 0, None) == INVALID
-    assert lib.iris_conv3x3_wino_bias_relu(p16, p16, p16, p16, p16, 1, 8, 8, 12, 64, 0, 0, None) == UNSUPPORTED    # cin % 8
-    assert lib.iris_conv3x3_wino_bias_relu(p16, p16, p16, p16, p16, 1, 8, 8, 64, 96, 0, 0, None) == UNSUPPORTED    # cout % 64
-    assert lib.iris_conv3x3_wino_bias_relu(p8, p16, p16, p16, p16, 1, 8, 8, 64, 64, 0, 0, None) == INVALID         # alignment
-    assert lib.iris_conv3x3_wino_bias_relu(p16, p16, p16, p16, p16, 0, 8, 8, 64, 64, 0, 0, None) == INVALID
+    assert lib.iris_conv3x3_c32_bias_relu(None, p16, p16, p16, 1, 8, 8, 0, 0, None) == INVALID
+    assert lib.iris_conv3x3_c32_bias_relu(p8, p16, p16, p16, 1, 8, 8, 1, 0, None) == INVALID                  # alignment
+    assert lib.iris_conv3x3_c32_bias_relu(p16, p16, p16, p16, 0, 8, 8, 1, 1, None) == INVALID
+    assert lib.iris_conv3x3_wino_bias_relu(None, p16, p16, p16, 1, 8, 8, 64, 64, 0, 0, None) == INVALID
+    assert lib.iris_conv3x3_wino_bias_relu(p16, p16, p16, p16, 1, 8, 8, 12, 64, 0, 0, None) == UNSUPPORTED    # cin % 8
+    assert lib.iris_conv3x3_wino_bias_relu(p16, p16, p16, p16, 1, 8, 8, 64, 96, 0, 0, None) == UNSUPPORTED    # cout % 64
+    assert lib.iris_conv3x3_wino_bias_relu(p8, p16, p16, p16, 1, 8, 8, 64, 64, 0, 0, None) == INVALID         # alignment
+    assert lib.iris_conv3x3_wino_bias_relu(p16, p16, p16, p16, 0, 8, 8, 64, 64, 0, 0, None) == INVALID
     assert lib.iris_wino_pack_weights(None, 8, 64, p16) == INVALID and lib.iris_wino_pack_weights(p16, 8, 48, p16) == UNSUPPORTED
     assert lib.iris_wino_packed_len(8, 64) == 16 * 8 * 64 and lib.iris_wino_packed_len(0, 64) == 0
     assert lib.iris_bilstm128_forward(None, p16, p16, None, 4, 16, None) == INVALID

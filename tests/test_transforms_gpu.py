@@ -1079,6 +1079,9 @@ def test_conv32_matrix_core_kernel(dev):
         wantp = torch.nn.functional.max_pool2d(want, 2, 2, ceil_mode=True)
         gotp = FE.conv3x3_c32_bias_relu(x, wt, bias, pool=True)
         assert gotp.shape == wantp.shape and float((gotp - wantp).abs().max()) <= tol, (b, h, w)
+        # the same values in the channel-chunked layout the Winograd layers read
+        assert torch.equal(FE.conv3x3_c32_bias_relu(x, wt, bias, out_chunked=True), FE.to_chunked(got))
+        assert torch.equal(FE.conv3x3_c32_bias_relu(x, wt, bias, pool=True, out_chunked=True), FE.to_chunked(gotp))
     with pytest.raises(ValueError):
         FE.conv3x3_c32_bias_relu(torch.zeros(1, 16, 4, 4, device=dev).contiguous(memory_format=torch.channels_last),
                                  torch.zeros(32, 32, 3, 3, device=dev), torch.zeros(32, device=dev))
@@ -1127,26 +1130,25 @@ def test_winograd_convolution_matches_fp64(dev, b, h, w, cin, cout):
     x = torch.randn(b, cin, h, w, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
     wt = torch.randn(cout, cin, 3, 3, generator=g, device=dev) * (2.0 / (9 * cin)) ** 0.5
     bias = torch.randn(cout, generator=g, device=dev) * 0.1
-    zeros = torch.zeros(64, device=dev)
     packed = FE.wino_pack_weights(wt)
     xc = FE.to_chunked(x)
     assert tuple(xc.shape) == (b, cin // 8, h, w, 8)
     ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1).relu()
     for pool in (False, True):
         want = torch.nn.functional.max_pool2d(ref, 2, 2, ceil_mode=True) if pool else ref
-        y_cl = FE.conv3x3_wino_bias_relu(xc, packed, bias, zeros, cout, pool=pool, out_nhwc=True)
+        y_cl = FE.conv3x3_wino_bias_relu(xc, packed, bias, cout, pool=pool, out_nhwc=True)
         assert tuple(y_cl.shape) == tuple(want.shape) and y_cl.is_contiguous(memory_format=torch.channels_last)
         err = float((y_cl.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
         assert err <= 2e-6, (pool, err)
-        y_ch = FE.conv3x3_wino_bias_relu(xc, packed, bias, zeros, cout, pool=pool)
+        y_ch = FE.conv3x3_wino_bias_relu(xc, packed, bias, cout, pool=pool)
         ho, wo = want.shape[2], want.shape[3]
         assert tuple(y_ch.shape) == (b, cout // 8, ho, wo, 8)
         assert torch.equal(y_ch.permute(0, 1, 4, 2, 3).reshape(b, cout, ho, wo), y_cl)
         assert torch.equal(FE.to_chunked(y_cl), y_ch)      # the next layer's input, either way
     with pytest.raises(ValueError):
-        FE.conv3x3_wino_bias_relu(xc, packed, bias, zeros, cout + 8)       # cout must be a multiple of 64
+        FE.conv3x3_wino_bias_relu(xc, packed, bias, cout + 8)       # cout must be a multiple of 64
     with pytest.raises(ValueError):
-        FE.conv3x3_wino_bias_relu(x, packed, bias, zeros, cout)            # not the chunked layout
+        FE.conv3x3_wino_bias_relu(x, packed, bias, cout)            # not the chunked layout
 
 
 def test_hip_bilstm_matches_torch(dev):
