@@ -282,29 +282,40 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
     t_wdata_host = timed(lambda: next(wds), steps)
     del wds, wsrc
     # what bounds c3 / c4 once the frontend is 1 % of them: the CRNN's convolutions on the fp32 matrix cores (157.3 TFLOP/s)
-    conv_flops, hw = 0.0, (N_MEL, 512)
+    conv_flops, wino_flops, hw = 0.0, 0.0, (N_MEL, 512)
     for blk in model.features:
         for m in blk.modules():
             if isinstance(m, torch.nn.Conv2d):
-                conv_flops += 2.0 * batch * hw[0] * hw[1] * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
+                f = 2.0 * batch * hw[0] * hw[1] * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
+                conv_flops += f
+                # what the inference engine issues on the matrix cores: Winograd F(2x2, 3x3) needs 16 instead of 36 multiplies
+                # per output tile wherever its kernel applies (8 | Cin, 64 | Cout: blocks 2-5)
+                wino_flops += f / 2.25 if (infer.wino_convs and m.in_channels % 8 == 0 and m.out_channels % 64 == 0) else f
         if isinstance(getattr(blk, "pool", None), torch.nn.MaxPool2d):
             hw = (-(-hw[0] // 2), -(-hw[1] // 2))
     best_fwd_ms = 1e3 * min(t for t in (t_fwd, t_fwd_folded, t_fwd_graph) if t is not None)
     mfma = {"conv_gflop_per_forward": round(conv_flops / 1e9, 1), "fp32_mfma_peak_tflops": 157.3,
-            "c3_bound_ms": round(1e3 * conv_flops / 157.3e12, 3), "c3_frac_of_bound": round(1e3 * conv_flops / 157.3e12 / best_fwd_ms, 3),
+            "c3_direct_bound_ms": round(1e3 * conv_flops / 157.3e12, 3),
+            "c3_mfma_gflop_issued_by_the_engine": round(wino_flops / 1e9, 1),
+            "c3_bound_ms": round(1e3 * wino_flops / 157.3e12, 3), "c3_frac_of_bound": round(1e3 * wino_flops / 157.3e12 / best_fwd_ms, 3),
             "c4_bound_ms": round(3e3 * conv_flops / 157.3e12, 3), "c4_frac_of_bound": round(3e3 * conv_flops / 157.3e12 / (1e3 * t_train), 3),
-            "note": "forward = one pass over the convolutions, training = three (forward, backward-data, backward-weight); "
-                    "fp32 in / fp32 accumulate MFMA, the precision the reference trains in"}
+            "winograd_layers": infer.wino_convs,
+            "note": "forward = one pass over the convolutions, training = three (forward, backward-data, backward-weight); fp32 in / "
+                    "fp32 accumulate MFMA, the precision the reference trains in.  c3_bound_ms prices the multiplies the inference "
+                    "engine really issues (Winograd F(2x2, 3x3) in blocks 2-5: 2.25x fewer than the direct convolution, whose own "
+                    "bound c3_direct_bound_ms the engine now runs BELOW); 157.3 TFLOP/s is the MFMA peak at 2.4 GHz - a bare MFMA "
+                    "loop sustains ~131 on this chip (scripts/gpu_wino_bench.py ablation)"}
     c3 = {"audio_s_per_s": round(world * audio_s / t_fwd, 1), "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch,
           "what": "training-mode model object in eval(): BatchNorm kernels, separate bias / ReLU kernels (the literal module)",
           "inference_engine": {
-              "what": "same function for inference (sj_train.InferenceEngine): BatchNorm folded into the convolutions, MIOpen "
-                      "convolution + ONE HIP epilogue pass (bias + ReLU, + the block's 2x2 max-pool), fp32; outputs equal to "
-                      "1e-4 (GPU test)",
+              "what": "same function for inference (sj_train.InferenceEngine): BatchNorm folded into the convolutions, every "
+                      "convolution a HIP kernel with bias + ReLU (+ the block's 2x2 max-pool) fused - stencil (layer 1), implicit "
+                      "GEMM on the fp32 MFMA (32 -> 32), Winograd F(2x2, 3x3) on the fp32 MFMA (blocks 2-5) -, fp32; outputs equal "
+                      "to 1e-4 (GPU test)",
               "eager": {"audio_s_per_s": round(world * audio_s / t_fwd_folded, 1), "ms_per_step": round(1e3 * t_fwd_folded, 3)},
               "hipgraph_replay": None if t_fwd_graph is None else {
                   "audio_s_per_s": round(world * audio_s / t_fwd_graph, 1), "ms_per_step": round(1e3 * t_fwd_graph, 3)},
-              "fused_conv_bias_relu": infer.fused_convs}}
+              "fused_conv_bias_relu": infer.fused_convs, "hip_convolutions": infer.hip_convs, "winograd_convolutions": infer.wino_convs}}
     best_fwd = min(t for t in (t_fwd, t_fwd_folded, t_fwd_graph) if t is not None)
     return {
         "device_dataset": {"ms_per_batch": round(1e3 * t_data, 3), "ms_per_batch_host_draws": round(1e3 * t_data_host, 3),

@@ -76,12 +76,19 @@ __device__ __forceinline__ void wino_dma16_gather(const float* base /*uniform*/,
                  : "=&s"(keep), "=&s"(keep_exec) : "v"(off), "s"(s), "s"(mask), "s"(lds) : "memory");
 }
 typedef struct { f32x2 lo, hi; } wino_v4;  // four channels as two register pairs: sums and differences are v_pk_add_f32
-__device__ __forceinline__ wino_v4 operator+(wino_v4 a, wino_v4 b) { return {a.lo + b.lo, a.hi + b.hi}; }
-// (a - b as a packed FMA with a (-1, -1) constant: exact, and ONE v_pk_fma_f32 - the compiler scalarises a vector fsub)
-__device__ __forceinline__ f32x2 wino_sub2(f32x2 a, f32x2 b) {
-    const f32x2 m1 = {-1.0f, -1.0f};
-    return __builtin_elementwise_fma(b, m1, a);
+// packed adds / subtractions written out (the compiler scalarises both the vector fsub and the fma-by-(-1) form of it here):
+// ONE v_pk_add_f32 per register pair, the sign of b on the VOP3P neg modifiers
+__device__ __forceinline__ f32x2 wino_add2(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
+__device__ __forceinline__ f32x2 wino_sub2(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ wino_v4 operator+(wino_v4 a, wino_v4 b) { return {wino_add2(a.lo, b.lo), wino_add2(a.hi, b.hi)}; }
 __device__ __forceinline__ wino_v4 operator-(wino_v4 a, wino_v4 b) { return {wino_sub2(a.lo, b.lo), wino_sub2(a.hi, b.hi)}; }
 
 struct WinoWave {
