@@ -281,6 +281,24 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
         // the extra LDS pass and its registers cost 15 us more than the scattered stores: they keep storing from registers)
         const bool direct = out_nhwc || !POOL;
         if (!direct) __syncthreads();
+        // The wave's 32 tiles lie in one tile row of the block (TC = 16: two, registers 0-7 and 8-15): image, tile row, validity
+        // and the output row's address are formed once per strip, not once per tile (an integer division and 64-bit address
+        // arithmetic per pixel made this loop cost 6 us per work item: 50 us of a 32 x 256 layer)
+        constexpr int kStrips = TC >= 32 ? 1 : 2;
+        const int ps = out_nhwc ? Cout : 8;   // floats between pixels
+        float* e_base[kStrips];               // (b, first output row of the strip, pixel 0, co)
+        bool e_ok[kStrips], e_row1[kStrips];  // strip exists; its second output row is inside the image
+        int e_th[kStrips];
+#pragma unroll
+        for (int ss = 0; ss < kStrips; ++ss) {
+            const int strip = TC >= 64 ? 0 : (TC == 32 ? wm : 2 * wm + ss);
+            const int R = R0 + strip, b_ = R / TH, th_ = R - b_ * TH;
+            e_ok[ss] = R < n_rows;
+            e_row1[ss] = 2 * th_ + 1 < H;
+            e_th[ss] = th_;
+            e_base[ss] = y + (size_t)b_ * Ho * Wo * Cout + (out_nhwc ? (size_t)co : ((size_t)(co >> 3) * Ho * Wo) * 8 + (co & 7))
+                         + (size_t)(POOL ? th_ : 2 * th_) * Wo * ps;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hl;
@@ -297,33 +315,33 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
                 o[i][0] = sr[i][0] + sr[i][1] + sr[i][2];
                 o[i][1] = sr[i][1] - sr[i][2] - sr[i][3];
             }
-            const int t = 32 * wm + row;  // tile of the block
-            const int R = R0 + t / TC, tw_ = tc0 + t % TC;
-            const int b_ = R / TH, th_ = R - b_ * TH;
-            const int oh = 2 * th_, ow = 2 * tw_;
+            const int ss = kStrips == 2 ? (r >> 3) : 0;   // (registers 8-15 hold MFMA rows 16-31)
+            const int tw_ = tc0 + ((32 * wm + row) & (TC - 1));
+            const int ow = 2 * tw_;
+            const bool col1 = ow + 1 < W;
             float pooled = 0.f;
             if constexpr (POOL) {
                 pooled = o[0][0];  // (oh, ow) is inside whenever the tile exists; values outside the image never win
-                if (ow + 1 < W) pooled = fmaxf(pooled, o[0][1]);
-                if (oh + 1 < H) {
+                if (col1) pooled = fmaxf(pooled, o[0][1]);
+                if (e_row1[ss]) {
                     pooled = fmaxf(pooled, o[1][0]);
-                    if (ow + 1 < W) pooled = fmaxf(pooled, o[1][1]);
+                    if (col1) pooled = fmaxf(pooled, o[1][1]);
                 }
                 pooled = fmaxf(pooled + bj, 0.f);
             }
             if (direct) {  // channels-last (the stack's last layer) or unpooled: straight from the registers
-                if (R < n_rows && tw_ < TW) {
-                    // element (b, oh, ow, co): chunked [B][Cout / 8][Ho][Wo][8] or channels-last [B][Ho][Wo][Cout]
-                    float* const yb = y + (size_t)b_ * Ho * Wo * Cout + (out_nhwc ? (size_t)co : ((size_t)(co >> 3) * Ho * Wo) * 8 + (co & 7));
-                    const int ps = out_nhwc ? Cout : 8;
+                if (e_ok[ss] && tw_ < TW) {
+                    float* const yp = e_base[ss] + (unsigned)((POOL ? tw_ : ow) * ps);
                     if constexpr (POOL) {
-                        yb[((size_t)th_ * Wo + tw_) * ps] = pooled;
+                        yp[0] = pooled;
                     } else {
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                if (oh + i < H && ow + j < W) yb[((size_t)(oh + i) * Wo + ow + j) * ps] = fmaxf(o[i][j] + bj, 0.f);
+                        const unsigned rowp = (unsigned)(Wo * ps);
+                        yp[0] = fmaxf(o[0][0] + bj, 0.f);
+                        if (col1) yp[ps] = fmaxf(o[0][1] + bj, 0.f);
+                        if (e_row1[ss]) {
+                            yp[rowp] = fmaxf(o[1][0] + bj, 0.f);
+                            if (col1) yp[rowp + ps] = fmaxf(o[1][1] + bj, 0.f);
+                        }
                     }
                 }
             } else {
