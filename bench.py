@@ -47,7 +47,7 @@ STRONG_GLOBAL_BATCH = 256       # --strong: c2 clips over all ranks (= 8 x 32)
 STRONG_GLOBAL_TRAIN_BATCH = 512  # --strong: c4 training batch over all ranks
 ALGO_BYTES_PER_AUDIO_S = 4 * SR + 4 * N_MEL * SR // HOP  # fp32 wave in + fp32 mel out = 80,000
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
-PMC_JSON = os.path.join("profiles", "r4", "pmc_traffic.json")
+PMC_JSON = os.path.join("profiles", "r5", "pmc_traffic.json")
 
 
 def cpu_baseline(wav_cpu: np.ndarray):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 --pmc passes of scripts/gpu_pmc.sh (gpurun_out/pmc/p*/ ... counter_collection.csv)
-into profiles/r4/pmc_traffic.json, stamped with the git sha and the hash of the kernel sources the passes
+into profiles/r5/pmc_traffic.json, stamped with the git sha and the hash of the kernel sources the passes
 ran on (bench.py refuses the figure when the sources have changed since).
 Corrections per MI355X_MICROARCH.md, section HBM: FETCH_SIZE (KB) reads 1/2 of a wide coalesced read stream on
 gfx950 -> doubled; WRITE_SIZE (KB) as is.   usage: python scripts/pmc_summarise.py [pmc_dir] [out_json]"""
@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from bench import kernel_source_sha, ALGO_BYTES_PER_AUDIO_S, BATCH, SECONDS  # noqa: E402
 
 pmc_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
-out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r4", "pmc_traffic.json")
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r5", "pmc_traffic.json")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(pmc_dir, "p*", "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
