@@ -264,3 +264,59 @@ def test_hand_set_vmcnt_has_enough_loads_behind_the_staging_rows(device_asm):
         assert loaded and min(loaded) >= n_wait, (head, n_wait, blocks)
         checked += 1
     assert checked >= 60, checked   # every direct-load variant of the fused kernel (with / without epilogue, bands, mel modes)
+
+
+def test_winograd_kernel_hand_set_waits_match_its_requests(device_asm):
+    """k_conv3x3_wino stages its operands by LDS-DMA from inline asm and waits with hand-set counters (csrc/k_conv_wino.h): in
+    every steady-state chunk body the wave requests 7 rows of input, then 8 rows of U, and `s_waitcnt vmcnt(8)` in front of the
+    patch reads relies on exactly that order - a wave's vector-memory operations return in order, so at most the 8 YOUNGER U
+    requests may be outstanding once the input has landed.  Checked on the assembly of all six variants: in each loop body with
+    the 64 MFMAs of a chunk and the hand-set wait, the vector-memory instructions in front of the wait are 15 LDS-DMA requests
+    and nothing else, and the loop has no scratch access."""
+    import re
+    text = open(device_asm).read()
+    fns = re.split(r"\n(?=_Z14k_conv3x3_winoILb[01]ELi\d+EE[^\n]*:\s)", text)
+    assert len(fns) == 7, len(fns)   # preamble + 2 (pooled or not) x 3 (tile columns)
+    checked = 0
+    for fn in fns[1:]:
+        body = fn.split("s_endpgm")[0]
+        blocks, cur = [], []
+        for ln in body.split("\n"):
+            t = ln.strip()
+            if re.match(r"\.LBB\d+_\d+:", t):
+                blocks.append(cur)
+                cur = []
+            elif t and not t.startswith(";"):
+                cur.append(t)
+        blocks.append(cur)
+        loops = [b for b in blocks if sum(1 for t in b if t.startswith("v_mfma_f32_32x32x2")) == 64 and "s_waitcnt vmcnt(8)" in b]
+        assert len(loops) == 2, len(loops)   # one copy of the loop per transform half (wave-uniform branch)
+        for b in loops:
+            upto = b[:b.index("s_waitcnt vmcnt(8)")]
+            vmem = [t.split()[0] for t in upto if re.match(r"(global|buffer|flat|scratch)_", t)]
+            assert vmem == ["global_load_lds_dwordx4"] * 15, vmem
+            assert not any(t.startswith("scratch_") for t in b)
+            checked += 1
+    assert checked == 12
+
+
+def test_winograd_weight_packing_on_the_host():
+    """iris_wino_pack_weights (host code, no GPU): U = G g G^T per (cout, cin), stored in the kernel's LDS order
+    [cout block][chunk of 8 cin][position 16][pair 2][hl 2][cout 64][2] with channel 4 pair + 2 hl + j of the chunk at (pair, hl, j)."""
+    import numpy as np
+    lib = N.lib()
+    rng = np.random.default_rng(0)
+    cin, cout = 16, 128
+    w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    out = np.empty(lib.iris_wino_packed_len(cin, cout), np.float32)
+    assert out.size == 16 * cin * cout
+    assert lib.iris_wino_pack_weights(w.ctypes.data, cin, cout, out.ctypes.data) == 0
+    G = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], np.float64)
+    U = np.einsum("xi,ocij,yj->ocxy", G, w.astype(np.float64), G)          # [cout, cin, 4, 4]
+    packed = out.reshape(cout // 64, cin // 8, 16, 2, 2, 64, 2)
+    for o, c in [(0, 0), (5, 3), (63, 7), (64, 8), (127, 15), (70, 10)]:
+        k = c % 8
+        got = packed[o // 64, c // 8, :, k >> 2, (k >> 1) & 1, o % 64, k & 1]
+        assert np.allclose(got, U[o, c].reshape(16).astype(np.float32), rtol=0, atol=1e-7), (o, c)
+    # every element is used exactly once: the packed tensor is a permutation of U
+    assert np.allclose(np.sort(out), np.sort(U.astype(np.float32).ravel()), atol=1e-7)
