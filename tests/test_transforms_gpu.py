@@ -1313,6 +1313,32 @@ def test_inference_engine_matches_module(dev):
     assert tuple(a.shape) == (4, 4, 3) and torch.isfinite(a).all() and torch.isfinite(b).all()
 
 
+@pytest.mark.parametrize("v,n_mels,n_chan", [(6, 64, 1), (7, 64, 2), (8, 80, 1), (1, 80, 2)])
+def test_inference_engine_other_model_variants(dev, v, n_mels, n_chan):
+    """The engine's HIP convolutions pick their layers by shape, whatever the variant: v6 / v7 put smoothing pools / bottlenecks
+    between the blocks (only the trailing run of plain blocks becomes the Winograd stack), v8 has 48-channel-based widths (96 is no
+    multiple of 64: that block stays on MIOpen, the ones behind it convert from channels-last), v1 has no LSTM; 80 mel bands give
+    odd heights (5, 3).  Same outputs as the module in eval mode to 1e-4."""
+    from challenge_amd import sj_train as S
+    S.configure_miopen()
+    cfg = S.ARGS().get(['--v', str(v), '--n_mels', str(n_mels), '--n_frame', '128', '--n_chan', str(n_chan), '--batch_size', '3'])
+    torch.manual_seed(v)
+    model = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                mod.running_mean.uniform_(-0.2, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+    x = torch.rand(3, n_mels, 128, n_chan, device=dev)
+    eng = S.InferenceEngine(model)
+    model.eval()
+    with torch.no_grad():
+        want = model(x)
+    got = eng(x)
+    assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-4, float((got - want).abs().max())
+    assert eng.wino_convs >= 3, eng.wino_convs
+
+
 def test_bench_self_launch_two_ranks(dev):
     """`python bench.py --gpus 2` without a launcher starts its own ranks (torch.distributed.run children) before it
     touches the GPU; IRIS_BENCH_SHARE_GPU=1 lets both ranks use cuda:0 over gloo so this runs on a one-GPU box."""
