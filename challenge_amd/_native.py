@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("IRIS_LIB") or os.path.join(_HERE, "csrc", "libiris_fr
 IRIS_F_MINMAX, IRIS_F_LOG, IRIS_F_NORMALIZE = 1, 2, 4
 IRIS_MEL_F32, IRIS_MEL_F16_MFMA = 0, 1
 IRIS_EPILOGUE_FUSED, IRIS_EPILOGUE_TWO_KERNELS, IRIS_EPILOGUE_IN_PLACE = 0, 1, 2
+IRIS_WINO_POOL, IRIS_WINO_OUT_NHWC, IRIS_WINO_IN_NHWC, IRIS_WINO_RELU = 1, 2, 4, 8
 IRIS_E_EPILOGUE_TIMEOUT = -5
 
 # every symbol include/iris_frontend.h declares, with (restype, argtypes)
@@ -60,7 +61,8 @@ SIGNATURES = {
     "iris_conv3x3_c32_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "iris_wino_packed_len": (_sz, [_i, _i]),
     "iris_wino_pack_weights": (_i, [_vp, _i, _i, _vp]),
-    "iris_conv3x3_wino_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "iris_wino_pack_weights_device": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _vp, _vp]),
+    "iris_conv3x3_wino": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "iris_conv0_dweight_len": (_sz, [_i, _i]),
     "iris_conv0_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "iris_conv0_bn_relu": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -99,10 +99,13 @@ struct WinoWave {
 };
 
 // TC: tile columns of a workgroup's block (64 / TC tile rows): min(ceil(W / 2), 64) rounded up to a power of two
+// in_nhwc: x is channels-last [B][H][W][Cin] (a chunk of a pixel = 32 bytes at a stride of Cin x 4: every gather touches 64
+// cache lines instead of 16 - 14 % slower over the CRNN's layers, what a training pass pays for keeping its activations where
+// MIOpen's weight-gradient kernels read them); relu == 0 and bias == nullptr: the bare convolution (training: BatchNorm follows)
 template <bool POOL, int TC>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict__ x, const float* __restrict__ u,
                                                          const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
-                                                         int Cin, int Cout, int out_nhwc) {
+                                                         int Cin, int Cout, int out_nhwc, int in_nhwc, int relu) {
     extern __shared__ __attribute__((aligned(16))) float wino_lds[];
     constexpr int TR = kWinoTM / TC, PW = 2 * TC + 2, kPieces = TR * 3 * PW, kDmaRows = (kPieces + 63) / 64;
     static_assert(kPieces <= kWinoRawPieces, "raw region too small");
@@ -142,12 +145,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
             const int R = R0 + strip, b_ = R / TH, th = R - b_ * TH;
             const int hh = 2 * th - 1 + p_half + r, ww = 2 * tc0 - 1 + px;
             const bool ok = i < kPieces && R < n_rows && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            poff[k] = ok ? ((unsigned)((((size_t)b_ * (Cin / 8)) * H + hh) * W + ww) * 8u + 4u * p_cg) * 4u : 0u;
+            poff[k] = !ok ? 0u : in_nhwc ? ((unsigned)(((size_t)b_ * H + hh) * W + ww) * (unsigned)Cin + 4u * p_cg) * 4u
+                                         : ((unsigned)((((size_t)b_ * (Cin / 8)) * H + hh) * W + ww) * 8u + 4u * p_cg) * 4u;
             pmask[k] = __ballot(ok);
             if (!ok && i < kWinoRawPieces) reinterpret_cast<float4*>(raw)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         auto dma_x = [&](int chunk, int k0, int k1) {  // rows k0 .. k1 - 1 of the wave's staging area for `chunk`
-            const float* xc = x + (size_t)chunk * plane;  // uniform
+            const float* xc = x + (size_t)chunk * (in_nhwc ? (size_t)8 : plane);  // uniform
 #pragma unroll
             for (int k = 0; k < kDmaRows; ++k)
                 if (k >= k0 && k < k1) wino_dma16_gather(xc, poff[k], pmask[k], raw_l + 1024u * k);
@@ -269,7 +273,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
 
         // ---- output transform, bias, ReLU (, MaxPool) and store: lane = output channel, register r = tile
         const int co = cb * kWinoTN + 32 * wn + li;
-        const float bj = bias[co];
+        const float bj = bias ? bias[co] : 0.f;
+        const float floor_ = relu ? 0.f : -INFINITY;  // max(v, floor_): ReLU, or nothing
         const int Ho = POOL ? TH : H, Wo = POOL ? TW : W;
         constexpr int kPix = POOL ? 1 : 4;                       // output pixels per tile
         constexpr int kCcStride = 32 * kPix * 8 + 8;             // floats between channel chunks in the staging area (+ 8: banks)
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
                     pooled = fmaxf(pooled, o[1][0]);
                     if (col1) pooled = fmaxf(pooled, o[1][1]);
                 }
-                pooled = fmaxf(pooled + bj, 0.f);
+                pooled = fmaxf(pooled + bj, floor_);
             }
             if (direct) {  // channels-last (the stack's last layer) or unpooled: straight from the registers
                 if (e_ok[ss] && tw_ < TW) {
@@ -336,11 +341,11 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
                         yp[0] = pooled;
                     } else {
                         const unsigned rowp = (unsigned)(Wo * ps);
-                        yp[0] = fmaxf(o[0][0] + bj, 0.f);
-                        if (col1) yp[ps] = fmaxf(o[0][1] + bj, 0.f);
+                        yp[0] = fmaxf(o[0][0] + bj, floor_);
+                        if (col1) yp[ps] = fmaxf(o[0][1] + bj, floor_);
                         if (e_row1[ss]) {
-                            yp[rowp] = fmaxf(o[1][0] + bj, 0.f);
-                            if (col1) yp[rowp + ps] = fmaxf(o[1][1] + bj, 0.f);
+                            yp[rowp] = fmaxf(o[1][0] + bj, floor_);
+                            if (col1) yp[rowp + ps] = fmaxf(o[1][1] + bj, floor_);
                         }
                     }
                 }
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) sp[((i * 32 + row) * 2 + j) * 8] = fmaxf(o[i][j] + bj, 0.f);
+                        for (int j = 0; j < 2; ++j) sp[((i * 32 + row) * 2 + j) * 8] = fmaxf(o[i][j] + bj, floor_);
                 }
             }
         }
@@ -420,27 +425,76 @@ extern "C" int iris_wino_pack_weights(const float* weight_host, int cin, int cou
     return IRIS_OK;
 }
 
+// The same packing on the DEVICE, from a weight tensor with arbitrary element strides (a channels_last parameter as it is):
+// a training step re-packs its weights every step, inside the stream (and inside a captured hipGraph).  transposed != 0 packs
+// the weights of the backward-data pass: dx = conv(dz, W') with W'[ci][co][i][j] = W[co][ci][2 - i][2 - j], i.e. `cin` counts
+// the ORIGINAL output channels and `cout` the original input channels.
+__global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, long so, long si, long sh, long sw, int cin, int cout,
+                                                   int transposed, float* __restrict__ packed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (o, c) of the convolution being packed
+    if (idx >= cin * cout) return;
+    const int o = idx / cin, c = idx - o * cin;
+    float g[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            g[i][j] = transposed ? w[(long)c * so + (long)o * si + (long)(2 - i) * sh + (long)(2 - j) * sw]
+                                 : w[(long)o * so + (long)c * si + (long)i * sh + (long)j * sw];
+    // G g: rows (g0), (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, (g2)
+    float t[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t[0][j] = g[0][j];
+        t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+        t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+        t[3][j] = g[2][j];
+    }
+    const int n_chunks = cin / kWinoKC;
+    const int cb = o / kWinoTN, oc = o % kWinoTN, chunk = c / kWinoKC, k = c % kWinoKC;
+    const int pair = k >> 2, hl = (k >> 1) & 1, j2 = k & 1;
+    float* const dst = packed + ((size_t)cb * n_chunks + chunk) * kWinoUFloats + ((size_t)(pair * 2 + hl) * kWinoTN + oc) * 2 + j2;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+        const float v[4] = {t[xi][0], 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]), t[xi][2]};
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) dst[(size_t)(4 * xi + nu) * (4 * kWinoTN * 2)] = v[nu];
+    }
+}
+
+extern "C" int iris_wino_pack_weights_device(const float* weight, long stride_o, long stride_i, long stride_h, long stride_w, int cin,
+                                             int cout, int transposed, float* packed, void* stream) {
+    if (!weight || !packed) return fail(IRIS_E_INVALID, "iris_wino_pack_weights_device: NULL argument");
+    if (cin <= 0 || cout <= 0 || (cin % kWinoKC) || (cout % kWinoTN))
+        return fail(IRIS_E_UNSUPPORTED, "iris_wino_pack_weights_device: cin %d must be a multiple of %d, cout %d of %d", cin, kWinoKC, cout, kWinoTN);
+    k_wino_pack<<<(cin * cout + 255) / 256, 256, 0, (hipStream_t)stream>>>(weight, stride_o, stride_i, stride_h, stride_w, cin, cout,
+                                                                            transposed, packed);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
+}
+
 template <bool POOL>
 static hipError_t wino_launch(int tc, unsigned grid, hipStream_t s, const float* x, const float* packed, const float* bias,
-                              float* y, int batch, int height, int width, int cin, int cout, int out_nhwc) {
-    if (tc >= 64) k_conv3x3_wino<POOL, 64><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc);
-    else if (tc >= 32) k_conv3x3_wino<POOL, 32><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc);
-    else k_conv3x3_wino<POOL, 16><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc);
+                              float* y, int batch, int height, int width, int cin, int cout, int out_nhwc, int in_nhwc, int relu) {
+    if (tc >= 64) k_conv3x3_wino<POOL, 64><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, in_nhwc, relu);
+    else if (tc >= 32) k_conv3x3_wino<POOL, 32><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, in_nhwc, relu);
+    else k_conv3x3_wino<POOL, 16><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, in_nhwc, relu);
     return hipGetLastError();
 }
 
-// x: channel-chunked [B][cin / 8][H][W][8]; packed: iris_wino_pack_weights; y: chunked [B][cout / 8][Ho][Wo][8], or channels-last
-// [B][Ho][Wo][cout] with out_nhwc
-extern "C" int iris_conv3x3_wino_bias_relu(const float* x, const float* packed, const float* bias, float* y, int batch, int height,
-                                           int width, int cin, int cout, int pool, int out_nhwc, void* stream) {
-    if (!x || !packed || !bias || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: NULL argument");
-    if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: empty tensor");
+// x: channel-chunked [B][cin / 8][H][W][8] (IRIS_WINO_IN_NHWC: channels-last [B][H][W][cin]); packed: iris_wino_pack_weights[_device];
+// bias: nullable; y: chunked [B][cout / 8][Ho][Wo][8] (IRIS_WINO_OUT_NHWC: channels-last [B][Ho][Wo][cout]); flags = IRIS_WINO_*
+extern "C" int iris_conv3x3_wino(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width,
+                                 int cin, int cout, int flags, void* stream) {
+    if (!x || !packed || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_wino: NULL argument");
+    if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_wino: empty tensor");
+    if (flags & ~(IRIS_WINO_POOL | IRIS_WINO_OUT_NHWC | IRIS_WINO_IN_NHWC | IRIS_WINO_RELU)) return fail(IRIS_E_INVALID, "iris_conv3x3_wino: flags 0x%x", flags);
     if (cin <= 0 || cout <= 0 || (cin % kWinoKC) || (cout % kWinoTN))
-        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_bias_relu: cin %d must be a multiple of %d, cout %d of %d", cin, kWinoKC, cout, kWinoTN);
+        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino: cin %d must be a multiple of %d, cout %d of %d", cin, kWinoKC, cout, kWinoTN);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) & 15)
-        return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bias_relu: x and the packed weights must be 16-byte aligned");
+        return fail(IRIS_E_INVALID, "iris_conv3x3_wino: x and the packed weights must be 16-byte aligned");
     if ((long long)batch * height * width * cin >= 1073741824LL)
-        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_bias_relu: tensor too large for 32-bit byte offsets (>= 2^30 elements)");
+        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino: tensor too large for 32-bit byte offsets (>= 2^30 elements)");
     int dev = 0, n_cu = 256;
     HIP_TRY(hipGetDevice(&dev));
     static std::atomic<unsigned> attr_set[64];
@@ -450,14 +504,16 @@ extern "C" int iris_conv3x3_wino_bias_relu(const float* x, const float* packed, 
         for (const void* k : ks) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsBytes));
         if (dev >= 0 && dev < 64) attr_set[dev].store(1u, std::memory_order_release);
     }
+    const int pool = (flags & IRIS_WINO_POOL) != 0, out_nhwc = (flags & IRIS_WINO_OUT_NHWC) != 0;
+    const int in_nhwc = (flags & IRIS_WINO_IN_NHWC) != 0, relu = (flags & IRIS_WINO_RELU) != 0;
     const int th = (height + 1) / 2, tw = (width + 1) / 2;
     const int tc = tw > 32 ? 64 : (tw > 16 ? 32 : 16), tr = kWinoTM / tc;
     const long long n_work = (((long long)batch * th + tr - 1) / tr) * ((tw + tc - 1) / tc) * (cout / kWinoTN);
-    if (n_work >= 2147483647LL) return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_bias_relu: too many tiles");
+    if (n_work >= 2147483647LL) return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino: too many tiles");
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const unsigned grid = (unsigned)std::min<long long>(n_work, n_cu);  // persistent: one workgroup (4 waves, 156 KiB of LDS) per CU
-    hipError_t e = pool ? wino_launch<true>(tc, grid, (hipStream_t)stream, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc)
-                        : wino_launch<false>(tc, grid, (hipStream_t)stream, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc);
+    hipError_t e = pool ? wino_launch<true>(tc, grid, (hipStream_t)stream, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, in_nhwc, relu)
+                        : wino_launch<false>(tc, grid, (hipStream_t)stream, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, in_nhwc, relu);
     HIP_TRY(e);
     return IRIS_OK;
 }

@@ -501,24 +501,61 @@ def to_chunked(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 2, 3, 1).reshape(b, h, w, c // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
 
 
-def conv3x3_wino_bias_relu(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, cout: int, pool: bool = False,
-                           out_nhwc: bool = False) -> torch.Tensor:
-    """relu(conv2d(x, weight, padding=1) + bias), with `pool` max-pooled 2x2 'same' behind it, as Winograd F(2x2, 3x3) on the
-    fp32 matrix cores (iris_conv3x3_wino_bias_relu).  x: channel-chunked [B, Cin / 8, H, W, 8]; packed: `wino_pack_weights`;
-    returns the chunked [B, cout / 8, Ho, Wo, 8] or, with `out_nhwc`, a channels_last [B, cout, Ho, Wo] tensor."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[4] == 8 and x.is_contiguous()):
-        raise ValueError("conv3x3_wino_bias_relu: x must be a contiguous float32 device tensor [B, Cin / 8, H, W, 8] (no CPU fallback)")
-    b, cbk, h, w, _ = (int(v) for v in x.shape)
+def wino_pack_weights_device(weight: torch.Tensor, transposed: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The same packing on the device, on the current stream, from the weight as it lies in memory (any strides: a
+    channels_last parameter needs no copy) - what a training step does every step.  `transposed`: the weights of the
+    backward-data pass (dx = conv(dz, W'), W'[ci][co][i][j] = W[co][ci][2 - i][2 - j])."""
+    if not (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
+        raise ValueError("wino_pack_weights_device: a float32 device weight [Cout, Cin, 3, 3] is expected (no CPU fallback)")
+    co, ci = int(weight.shape[0]), int(weight.shape[1])
+    cin, cout = (co, ci) if transposed else (ci, co)
+    n = int(N.lib().iris_wino_packed_len(cin, cout))
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=weight.device)
+    so, si, sh, sw = (int(v) for v in weight.stride())
+    with torch.cuda.device(weight.device):
+        rc = N.lib().iris_wino_pack_weights_device(weight.data_ptr(), so, si, sh, sw, cin, cout, 1 if transposed else 0,
+                                                   out.data_ptr(), _stream_ptr(weight.device))
+    N.check(rc, "iris_wino_pack_weights_device")
+    return out
+
+
+def conv3x3_wino(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, pool: bool = False,
+                 out_nhwc: bool = False, relu: bool = True) -> torch.Tensor:
+    """conv2d(x, weight, padding=1) (+ bias, + ReLU, + MaxPool 2x2 'same') as Winograd F(2x2, 3x3) on the fp32 matrix cores
+    (iris_conv3x3_wino).  x: channel-chunked [B, Cin / 8, H, W, 8], or a channels_last [B, Cin, H, W] tensor (read where it
+    lies: IRIS_WINO_IN_NHWC); packed: `wino_pack_weights[_device]`; returns the chunked [B, cout / 8, Ho, Wo, 8] or, with
+    `out_nhwc`, a channels_last [B, cout, Ho, Wo] tensor."""
+    if not (x.is_cuda and x.dtype == torch.float32):
+        raise ValueError("conv3x3_wino: x must be a float32 device tensor (no CPU fallback)")
+    if x.dim() == 5 and x.shape[4] == 8 and x.is_contiguous():
+        b, cbk, h, w, _ = (int(v) for v in x.shape)
+        cin, in_nhwc = 8 * cbk, False
+    elif x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        b, cin, h, w = (int(v) for v in x.shape)
+        in_nhwc = True
+    else:
+        raise ValueError("conv3x3_wino: x must be contiguous [B, Cin / 8, H, W, 8] or channels_last [B, Cin, H, W]")
     ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
     if out_nhwc:
         y = torch.empty((b, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     else:
         y = torch.empty((b, cout // 8, ho, wo, 8), dtype=torch.float32, device=x.device)
+    flags = (N.IRIS_WINO_POOL if pool else 0) | (N.IRIS_WINO_OUT_NHWC if out_nhwc else 0) | \
+        (N.IRIS_WINO_IN_NHWC if in_nhwc else 0) | (N.IRIS_WINO_RELU if relu else 0)
     with torch.cuda.device(x.device):
-        rc = N.lib().iris_conv3x3_wino_bias_relu(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w, 8 * cbk,
-                                                 int(cout), 1 if pool else 0, 1 if out_nhwc else 0, _stream_ptr(x.device))
-    N.check(rc, "iris_conv3x3_wino_bias_relu")
+        rc = N.lib().iris_conv3x3_wino(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                       b, h, w, cin, int(cout), flags, _stream_ptr(x.device))
+    N.check(rc, "iris_conv3x3_wino")
     return y
+
+
+def conv3x3_wino_bias_relu(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, cout: int, pool: bool = False,
+                           out_nhwc: bool = False) -> torch.Tensor:
+    """The inference form: relu(conv2d(x, weight, padding=1) + bias), with `pool` max-pooled, on the chunked layout."""
+    if not (x.dim() == 5 and x.shape[-1] == 8):
+        raise ValueError("conv3x3_wino_bias_relu: x must be the channel-chunked activation [B, Cin / 8, H, W, 8]")
+    return conv3x3_wino(x, packed, bias, cout, pool=pool, out_nhwc=out_nhwc, relu=True)
 
 
 def _check_bilstm(gx, w_hh, who):

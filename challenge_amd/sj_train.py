@@ -708,6 +708,67 @@ def _is_first_layer_conv(conv, x) -> bool:
             and x.shape[3] <= 2048)
 
 
+# Training: the bare 3x3 convolutions of blocks 2-5 - forward and backward-data - as Winograd F(2x2, 3x3) on the fp32 matrix
+# cores (iris_conv3x3_wino) instead of MIOpen's implicit GEMMs, reading and writing channels_last where MIOpen's weight-gradient
+# kernel keeps reading it (that layout costs the kernel 14 % against its own chunked one).  Wherever the kernel's shape rule
+# holds (8 | input channels, 64 | output channels - per direction, the backward-data pass swaps them) and the wider side has
+# >= 64 channels: every layer of blocks 2-5 forward, all but block 2's first backward.  Thresholds per direction by environment
+# (the measured step is flat within noise between 64 and 128: profiles/r5/c4_wino_train_ab.log); IRIS_WINO_TRAIN=0 keeps MIOpen
+# everywhere.  13.4-13.7 -> 12.2-12.8 ms per batch-64 step.
+WINO_TRAIN = os.environ.get("IRIS_WINO_TRAIN", "1") != "0"
+WINO_TRAIN_MIN_C_FWD = int(os.environ.get("IRIS_WINO_TRAIN_MIN_C_FWD", "64"))
+WINO_TRAIN_MIN_C_BWD = int(os.environ.get("IRIS_WINO_TRAIN_MIN_C_BWD", "64"))
+
+
+class _WinoConv3x3(torch.autograd.Function):
+    """z = conv2d(x, weight, padding=1) for channels_last fp32 tensors.  forward (`fwd`): iris_conv3x3_wino on the weights packed
+    on the device this step, else MIOpen; backward: dx (`bwd`) by the same kernel on the transposed / flipped weights, else
+    MIOpen; dW always by MIOpen's weight-gradient kernel (aten.convolution_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, fwd=True, bwd=True):
+        if fwd:
+            z = _fe.conv3x3_wino(x, _fe.wino_pack_weights_device(weight), None, int(weight.shape[0]), out_nhwc=True, relu=False)
+        else:
+            z = torch.nn.functional.conv2d(x, weight, None, 1, 1)
+        ctx.save_for_backward(x, weight)
+        ctx.wino_bwd = bool(bwd)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight = ctx.saved_tensors
+        cin = int(weight.shape[1])
+        if not dz.is_contiguous(memory_format=torch.channels_last):
+            dz = dz.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        wino_dx = ctx.needs_input_grad[0] and ctx.wino_bwd
+        if wino_dx:
+            dx = _fe.conv3x3_wino(dz, _fe.wino_pack_weights_device(weight, transposed=True), None, cin, out_nhwc=True, relu=False)
+        need = [ctx.needs_input_grad[0] and not wino_dx, ctx.needs_input_grad[1], False]
+        if need[0] or need[1]:
+            gi, gw, _ = torch.ops.aten.convolution_backward(dz, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
+            dx = gi if need[0] else dx
+            dw = gw if need[1] else None
+        return dx, dw, None, None
+
+
+def _wino_train_conv(conv: nn.Conv2d, x: torch.Tensor):
+    """(forward by Winograd?, backward-data by Winograd?) for this layer and input, or None: MIOpen for everything."""
+    def pair(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    if not (WINO_TRAIN and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and pair(conv.kernel_size) == (3, 3) and pair(conv.padding) == (1, 1) and pair(conv.stride) == (1, 1)
+            and pair(conv.dilation) == (1, 1) and conv.groups == 1 and conv.weight.dtype == torch.float32
+            and x.is_contiguous(memory_format=torch.channels_last) and x.numel() < (1 << 30)
+            and x.shape[0] * x.shape[2] * x.shape[3] * max(conv.in_channels, conv.out_channels) < (1 << 30)):
+        return None
+    ci, co, big = conv.in_channels, conv.out_channels, max(conv.in_channels, conv.out_channels)
+    fwd = ci % 8 == 0 and co % 64 == 0 and big >= WINO_TRAIN_MIN_C_FWD
+    bwd = co % 8 == 0 and ci % 64 == 0 and big >= WINO_TRAIN_MIN_C_BWD
+    return (fwd, bwd) if (fwd or bwd) else None
+
+
 class _ConvBNReLU(nn.Sequential):
     def __init__(self, cin, cout, k=3, bn=True):
         layers = [nn.Conv2d(cin, cout, k, padding=k // 2)]
@@ -727,7 +788,11 @@ class _ConvBNReLU(nn.Sequential):
                     bn.num_batches_tracked.add_(1)  # the model's first layer: convolution recomputed inside the passes
                     return _FusedConv0BNReLU.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                                    bn.running_var, bn.eps, bn.momentum)
-                z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+                wino = _wino_train_conv(conv, x)
+                if wino is not None:
+                    z = _WinoConv3x3.apply(x, conv.weight, wino[0], wino[1])
+                else:
+                    z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
                 if z.is_contiguous(memory_format=torch.channels_last):
                     bn.num_batches_tracked.add_(1)
                     fold = FUSED_BN_POOL and _is_pool_2x2_same(pool)

@@ -349,22 +349,32 @@ int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, const float*
                                int pool, int out_chunked, void* stream);
 
 /*
- * Blocks 2-5 of the CRNN for inference: Conv2D(cin -> cout, 3x3 'same') + (BatchNorm-folded) bias + ReLU, with pool != 0 the
- * block's MaxPool2D(2, 2, 'same') behind it (sj_train.py:191-201, 222-242), as a Winograd F(2x2, 3x3) transform on the fp32
- * matrix cores: 16 instead of 36 multiplies per 2 x 2 output tile and channel pair - MIOpen's implicit GEMMs already run these
- * layers at the fp32 MFMA rate.  fp32 throughout; against an fp64 convolution the error is that of a direct fp32 convolution
- * (<= 1e-6 of the output's peak).  cin % 8 == 0, cout % 64 == 0.
- *   x      channel-chunked activation [batch][cin / 8][height][width][8] (8 channels of a pixel contiguous), DEVICE, 16-byte
- *          aligned, fewer than 2^30 elements
- *   packed iris_wino_pack_weights(weight [cout][cin][3][3] contiguous, HOST) -> U = G g G^T in the kernel's LDS order,
- *          iris_wino_packed_len(cin, cout) = 16 cin cout floats (HOST buffers; upload the result once per layer)
- *   y      [batch][cout / 8][Ho][Wo][8] - the next layer's x - or, with out_nhwc != 0, channels-last [batch][Ho][Wo][cout];
- *          Ho x Wo = height x width, or ceil(height / 2) x ceil(width / 2) when pooled
+ * Conv2D(cin -> cout, 3x3 'same', stride 1) as a Winograd F(2x2, 3x3) transform on the fp32 matrix cores: 16 instead of 36
+ * multiplies per 2 x 2 output tile and channel pair - MIOpen's implicit GEMMs already run these layers at the fp32 MFMA rate.
+ * Blocks 2-5 of the CRNN (sj_train.py:191-201, 222-242): for inference with the (BatchNorm-folded) bias, ReLU and the block's
+ * MaxPool2D(2, 2, 'same') fused; for training as the bare convolution of the deep layers' forward and backward-data passes.
+ * fp32 throughout; against an fp64 convolution the error is that of a direct fp32 convolution (<= 1e-6 of the output's peak).
+ * cin % 8 == 0, cout % 64 == 0.
+ *   x      channel-chunked activation [batch][cin / 8][height][width][8] (8 channels of a pixel contiguous) - or, with
+ *          IRIS_WINO_IN_NHWC, channels-last [batch][height][width][cin] (14 % slower: every gather touches 4x the cache lines);
+ *          DEVICE, 16-byte aligned, fewer than 2^30 elements
+ *   packed U = G g G^T in the kernel's LDS order, 16 cin cout floats (iris_wino_packed_len), DEVICE, 16-byte aligned:
+ *          iris_wino_pack_weights (HOST buffers in and out, weight [cout][cin][3][3] contiguous; upload the result once per layer) or
+ *          iris_wino_pack_weights_device (DEVICE, on `stream`, weight with arbitrary element strides - a channels_last parameter as
+ *          it is -; transposed != 0 packs the weights of the backward-data pass, dx = conv(dz, W') with W'[ci][co][i][j] =
+ *          W[co][ci][2 - i][2 - j]: `cin` then counts the original OUTPUT channels)
+ *   bias   [cout] or NULL
+ *   y      [batch][cout / 8][Ho][Wo][8] - the next layer's x - or, with IRIS_WINO_OUT_NHWC, channels-last [batch][Ho][Wo][cout];
+ *          Ho x Wo = height x width, or ceil(height / 2) x ceil(width / 2) with IRIS_WINO_POOL
+ *   flags  IRIS_WINO_POOL | IRIS_WINO_OUT_NHWC | IRIS_WINO_IN_NHWC | IRIS_WINO_RELU
  */
+enum { IRIS_WINO_POOL = 1, IRIS_WINO_OUT_NHWC = 2, IRIS_WINO_IN_NHWC = 4, IRIS_WINO_RELU = 8 };
 size_t iris_wino_packed_len(int cin, int cout);
 int iris_wino_pack_weights(const float* weight_host, int cin, int cout, float* packed_host);
-int iris_conv3x3_wino_bias_relu(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width,
-                                int cin, int cout, int pool, int out_nhwc, void* stream);
+int iris_wino_pack_weights_device(const float* weight, long stride_o, long stride_i, long stride_h, long stride_w, int cin, int cout,
+                                  int transposed, float* packed, void* stream);
+int iris_conv3x3_wino(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width, int cin,
+                      int cout, int flags, void* stream);
 
 /*
  * The CRNN's first layer in TRAINING mode - Conv2D(3x3 'same', 1 or 2 input channels) + BatchNormalization + ReLU

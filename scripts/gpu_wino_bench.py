@@ -15,7 +15,7 @@ lib = C.CDLL(os.environ.get("WINO_LIB", os.path.join(ROOT, "scripts", "microbenc
 lib.iris_wino_packed_len.restype = C.c_size_t
 lib.iris_wino_packed_len.argtypes = [C.c_int, C.c_int]
 lib.iris_wino_pack_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-lib.iris_conv3x3_wino_bias_relu.argtypes = [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]
+lib.iris_conv3x3_wino.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]
 lib.wino_last_error.restype = C.c_char_p
 dev = torch.device("cuda", 0)
 
@@ -48,9 +48,9 @@ def wino(x_chunked, packed, bias, cout, pool, out_nhwc=False):
     cin = 8 * cbk
     ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
     y = torch.empty((b, ho, wo, cout) if out_nhwc else (b, cout // 8, ho, wo, 8), device=dev)
-    rc = lib.iris_conv3x3_wino_bias_relu(x_chunked.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w,
-                                         cin, cout, 1 if pool else 0, 1 if out_nhwc else 0,
-                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    rc = lib.iris_conv3x3_wino(x_chunked.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w,
+                               cin, cout, (1 if pool else 0) | (2 if out_nhwc else 0) | 8,
+                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     assert rc == 0, lib.wino_last_error()
     return y
 

@@ -11,6 +11,8 @@
 #include <type_traits>
 
 enum { IRIS_OK = 0, IRIS_E_INVALID = -1, IRIS_E_UNSUPPORTED = -2 };
+enum { IRIS_WINO_POOL = 1, IRIS_WINO_OUT_NHWC = 2, IRIS_WINO_IN_NHWC = 4, IRIS_WINO_RELU = 8 };
+#include <cmath>
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
     va_list ap;

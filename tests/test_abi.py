@@ -121,11 +121,14 @@ def test_round3_entry_points_validate_before_any_launch():
     assert lib.iris_conv3x3_c32_bias_relu(None, p16, p16, p16, 1, 8, 8, 0, 0, None) == INVALID
     assert lib.iris_conv3x3_c32_bias_relu(p8, p16, p16, p16, 1, 8, 8, 1, 0, None) == INVALID                  # alignment
     assert lib.iris_conv3x3_c32_bias_relu(p16, p16, p16, p16, 0, 8, 8, 1, 1, None) == INVALID
-    assert lib.iris_conv3x3_wino_bias_relu(None, p16, p16, p16, 1, 8, 8, 64, 64, 0, 0, None) == INVALID
-    assert lib.iris_conv3x3_wino_bias_relu(p16, p16, p16, p16, 1, 8, 8, 12, 64, 0, 0, None) == UNSUPPORTED    # cin % 8
-    assert lib.iris_conv3x3_wino_bias_relu(p16, p16, p16, p16, 1, 8, 8, 64, 96, 0, 0, None) == UNSUPPORTED    # cout % 64
-    assert lib.iris_conv3x3_wino_bias_relu(p8, p16, p16, p16, 1, 8, 8, 64, 64, 0, 0, None) == INVALID         # alignment
-    assert lib.iris_conv3x3_wino_bias_relu(p16, p16, p16, p16, 0, 8, 8, 64, 64, 0, 0, None) == INVALID
+    assert lib.iris_conv3x3_wino(None, p16, p16, p16, 1, 8, 8, 64, 64, 0, None) == INVALID
+    assert lib.iris_conv3x3_wino(p16, p16, p16, p16, 1, 8, 8, 12, 64, 0, None) == UNSUPPORTED    # cin % 8
+    assert lib.iris_conv3x3_wino(p16, p16, p16, p16, 1, 8, 8, 64, 96, 0, None) == UNSUPPORTED    # cout % 64
+    assert lib.iris_conv3x3_wino(p8, p16, p16, p16, 1, 8, 8, 64, 64, 0, None) == INVALID         # alignment
+    assert lib.iris_conv3x3_wino(p16, p16, p16, p16, 0, 8, 8, 64, 64, 0, None) == INVALID
+    assert lib.iris_conv3x3_wino(p16, p16, None, p16, 1, 8, 8, 64, 64, 16, None) == INVALID                          # unknown flag
+    assert lib.iris_wino_pack_weights_device(None, 9, 1, 3, 1, 8, 64, 0, p16, None) == INVALID
+    assert lib.iris_wino_pack_weights_device(p16, 9, 1, 3, 1, 8, 48, 0, p16, None) == UNSUPPORTED
     assert lib.iris_wino_pack_weights(None, 8, 64, p16) == INVALID and lib.iris_wino_pack_weights(p16, 8, 48, p16) == UNSUPPORTED
     assert lib.iris_wino_packed_len(8, 64) == 16 * 8 * 64 and lib.iris_wino_packed_len(0, 64) == 0
     assert lib.iris_bilstm128_forward(None, p16, p16, None, 4, 16, None) == INVALID

@@ -1151,6 +1151,39 @@ def test_winograd_convolution_matches_fp64(dev, b, h, w, cin, cout):
         FE.conv3x3_wino_bias_relu(x, packed, bias, cout)            # not the chunked layout
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout", [(4, 8, 64, 128, 256), (3, 8, 64, 256, 256), (5, 4, 32, 256, 512), (2, 4, 32, 512, 512),
+                                            (3, 5, 9, 64, 128), (2, 6, 10, 24, 64)])
+def test_winograd_training_convolution_matches_torch(dev, b, h, w, cin, cout):
+    """The training step's deep convolutions (sj_train._WinoConv3x3): forward z = conv(x, W) and backward-data dx by the
+    Winograd kernel on channels_last tensors with the weights packed on the device (plain and transposed / flipped), dW by
+    MIOpen - equal to torch's conv2d and its autograd gradients; the device packing equals the host packing to fp32 rounding.
+    (cin = 24 -> 64: the backward-data pass's shape rule fails for the swapped channel counts and MIOpen computes dx.)"""
+    from challenge_amd import frontend as FE
+    from challenge_amd import sj_train as S
+    g = torch.Generator(device=dev).manual_seed(cin + cout + h)
+    x = torch.randn(b, cin, h, w, generator=g, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g, device=dev) * (2.0 / (9 * cin)) ** 0.5).contiguous(memory_format=torch.channels_last)
+    wt.requires_grad_(True)
+    # (the host packs in double precision and rounds once, the device in fp32: equal to a few ulp of the largest weight)
+    wmax = float(wt.detach().abs().max())
+    assert float((FE.wino_pack_weights_device(wt.detach()) - FE.wino_pack_weights(wt.detach())).abs().max()) <= 4e-7 * wmax
+    if cout % 8 == 0 and cin % 64 == 0:   # the transposed packing == the host packing of the flipped, transposed weight
+        flipped = wt.detach().flip(2, 3).transpose(0, 1).contiguous()
+        assert float((FE.wino_pack_weights_device(wt.detach(), transposed=True) - FE.wino_pack_weights(flipped)).abs().max()) <= 4e-7 * wmax
+    z = S._WinoConv3x3.apply(x, wt, True, cout % 8 == 0 and cin % 64 == 0)
+    assert z.is_contiguous(memory_format=torch.channels_last)
+    dz = torch.randn(z.shape, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
+    z.backward(dz)
+    x2, w2 = x.detach().clone().requires_grad_(True), wt.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(x2.double(), w2.double(), None, padding=1)
+    ref.backward(dz.double())
+
+    def rel(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max())
+    assert rel(z, ref) <= 2e-6 and rel(x.grad, x2.grad) <= 2e-6, (rel(z, ref), rel(x.grad, x2.grad))
+    assert rel(wt.grad, w2.grad) <= 2e-5     # MIOpen's weight gradient (fp32 atomics)
+
+
 def test_hip_bilstm_matches_torch(dev):
     """iris_bilstm128_forward behind sj_train._HipBiLSTM: the whole bidirectional recurrence in one launch equals
     torch.nn.LSTM (MIOpen) on the same weights - odd batch sizes (a workgroup owns two rows), one step, long sequences,
