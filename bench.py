@@ -282,7 +282,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
     t_wdata_host = timed(lambda: next(wds), steps)
     del wds, wsrc
     # what bounds c3 / c4 once the frontend is 1 % of them: the CRNN's convolutions on the fp32 matrix cores (157.3 TFLOP/s)
-    conv_flops, wino_flops, hw = 0.0, 0.0, (N_MEL, 512)
+    conv_flops, wino_flops, train_flops, hw = 0.0, 0.0, 0.0, (N_MEL, 512)
     for blk in model.features:
         for m in blk.modules():
             if isinstance(m, torch.nn.Conv2d):
@@ -291,6 +291,11 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                 # what the inference engine issues on the matrix cores: Winograd F(2x2, 3x3) needs 16 instead of 36 multiplies
                 # per output tile wherever its kernel applies (8 | Cin, 64 | Cout: blocks 2-5)
                 wino_flops += f / 2.25 if (infer.wino_convs and m.in_channels % 8 == 0 and m.out_channels % 64 == 0) else f
+                # ... and the training step: forward and backward-data by the same rule per direction, weight gradient direct
+                ci, co, big = m.in_channels, m.out_channels, max(m.in_channels, m.out_channels)
+                fwd = S.WINO_TRAIN and ci % 8 == 0 and co % 64 == 0 and big >= S.WINO_TRAIN_MIN_C_FWD
+                bwd = S.WINO_TRAIN and co % 8 == 0 and ci % 64 == 0 and big >= S.WINO_TRAIN_MIN_C_BWD
+                train_flops += (f / 2.25 if fwd else f) + (f / 2.25 if bwd else f) + f
         if isinstance(getattr(blk, "pool", None), torch.nn.MaxPool2d):
             hw = (-(-hw[0] // 2), -(-hw[1] // 2))
     best_fwd_ms = 1e3 * min(t for t in (t_fwd, t_fwd_folded, t_fwd_graph) if t is not None)
@@ -298,12 +303,15 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
             "c3_direct_bound_ms": round(1e3 * conv_flops / 157.3e12, 3),
             "c3_mfma_gflop_issued_by_the_engine": round(wino_flops / 1e9, 1),
             "c3_bound_ms": round(1e3 * wino_flops / 157.3e12, 3), "c3_frac_of_bound": round(1e3 * wino_flops / 157.3e12 / best_fwd_ms, 3),
-            "c4_bound_ms": round(3e3 * conv_flops / 157.3e12, 3), "c4_frac_of_bound": round(3e3 * conv_flops / 157.3e12 / (1e3 * t_train), 3),
-            "winograd_layers": infer.wino_convs,
+            "c4_direct_bound_ms": round(3e3 * conv_flops / 157.3e12, 3),
+            "c4_mfma_gflop_issued_by_the_step": round(train_flops / 1e9, 1),
+            "c4_bound_ms": round(1e3 * train_flops / 157.3e12, 3), "c4_frac_of_bound": round(1e3 * train_flops / 157.3e12 / (1e3 * t_train), 3),
+            "winograd_layers": infer.wino_convs, "winograd_in_training": bool(S.WINO_TRAIN),
             "note": "forward = one pass over the convolutions, training = three (forward, backward-data, backward-weight); fp32 in / "
-                    "fp32 accumulate MFMA, the precision the reference trains in.  c3_bound_ms prices the multiplies the inference "
-                    "engine really issues (Winograd F(2x2, 3x3) in blocks 2-5: 2.25x fewer than the direct convolution, whose own "
-                    "bound c3_direct_bound_ms the engine now runs BELOW); 157.3 TFLOP/s is the MFMA peak at 2.4 GHz - a bare MFMA "
+                    "fp32 accumulate MFMA, the precision the reference trains in.  c3_bound_ms / c4_bound_ms price the multiplies "
+                    "really issued (Winograd F(2x2, 3x3) in blocks 2-5 - inference: every layer; training: forward and backward-data, "
+                    "the weight gradient stays MIOpen's direct kernel - 2.25x fewer than the direct convolution, whose own bound "
+                    "c3_direct_bound_ms the engine now runs BELOW); 157.3 TFLOP/s is the MFMA peak at 2.4 GHz - a bare MFMA "
                     "loop sustains ~131 on this chip (scripts/gpu_wino_bench.py ablation)"}
     c3 = {"audio_s_per_s": round(world * audio_s / t_fwd, 1), "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch,
           "what": "training-mode model object in eval(): BatchNorm kernels, separate bias / ReLU kernels (the literal module)",
