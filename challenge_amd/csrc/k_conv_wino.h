@@ -102,10 +102,11 @@ struct WinoWave {
 // in_nhwc: x is channels-last [B][H][W][Cin] (a chunk of a pixel = 32 bytes at a stride of Cin x 4: every gather touches 64
 // cache lines instead of 16 - 14 % slower over the CRNN's layers, what a training pass pays for keeping its activations where
 // MIOpen's weight-gradient kernels read them); relu == 0 and bias == nullptr: the bare convolution (training: BatchNorm follows)
-template <bool POOL, int TC>
+template <bool POOL, int TC, bool IN_NHWC>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict__ x, const float* __restrict__ u,
                                                          const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
-                                                         int Cin, int Cout, int out_nhwc, int in_nhwc, int relu) {
+                                                         int Cin, int Cout, int out_nhwc, int relu) {
+    constexpr bool in_nhwc = IN_NHWC;
     extern __shared__ __attribute__((aligned(16))) float wino_lds[];
     constexpr int TR = kWinoTM / TC, PW = 2 * TC + 2, kPieces = TR * 3 * PW, kDmaRows = (kPieces + 63) / 64;
     static_assert(kPieces <= kWinoRawPieces, "raw region too small");
@@ -473,13 +474,24 @@ extern "C" int iris_wino_pack_weights_device(const float* weight, long stride_o,
     return IRIS_OK;
 }
 
-template <bool POOL>
+template <bool POOL, bool IN_NHWC>
 static hipError_t wino_launch(int tc, unsigned grid, hipStream_t s, const float* x, const float* packed, const float* bias,
-                              float* y, int batch, int height, int width, int cin, int cout, int out_nhwc, int in_nhwc, int relu) {
-    if (tc >= 64) k_conv3x3_wino<POOL, 64><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, in_nhwc, relu);
-    else if (tc >= 32) k_conv3x3_wino<POOL, 32><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, in_nhwc, relu);
-    else k_conv3x3_wino<POOL, 16><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, in_nhwc, relu);
+                              float* y, int batch, int height, int width, int cin, int cout, int out_nhwc, int relu) {
+    if (tc >= 64) k_conv3x3_wino<POOL, 64, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
+    else if (tc >= 32) k_conv3x3_wino<POOL, 32, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
+    else k_conv3x3_wino<POOL, 16, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
     return hipGetLastError();
+}
+
+template <bool POOL, bool IN_NHWC>
+static hipError_t wino_set_lds_limit() {
+    const void* ks[3] = {(const void*)k_conv3x3_wino<POOL, 64, IN_NHWC>, (const void*)k_conv3x3_wino<POOL, 32, IN_NHWC>,
+                         (const void*)k_conv3x3_wino<POOL, 16, IN_NHWC>};
+    for (const void* k : ks) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsBytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // x: channel-chunked [B][cin / 8][H][W][8] (IRIS_WINO_IN_NHWC: channels-last [B][H][W][cin]); packed: iris_wino_pack_weights[_device];
@@ -499,9 +511,10 @@ extern "C" int iris_conv3x3_wino(const float* x, const float* packed, const floa
     HIP_TRY(hipGetDevice(&dev));
     static std::atomic<unsigned> attr_set[64];
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        const void* ks[6] = {(const void*)k_conv3x3_wino<false, 64>, (const void*)k_conv3x3_wino<false, 32>, (const void*)k_conv3x3_wino<false, 16>,
-                             (const void*)k_conv3x3_wino<true, 64>,  (const void*)k_conv3x3_wino<true, 32>,  (const void*)k_conv3x3_wino<true, 16>};
-        for (const void* k : ks) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsBytes));
+        HIP_TRY((wino_set_lds_limit<false, false>()));
+        HIP_TRY((wino_set_lds_limit<false, true>()));
+        HIP_TRY((wino_set_lds_limit<true, false>()));
+        HIP_TRY((wino_set_lds_limit<true, true>()));
         if (dev >= 0 && dev < 64) attr_set[dev].store(1u, std::memory_order_release);
     }
     const int pool = (flags & IRIS_WINO_POOL) != 0, out_nhwc = (flags & IRIS_WINO_OUT_NHWC) != 0;
@@ -512,8 +525,12 @@ extern "C" int iris_conv3x3_wino(const float* x, const float* packed, const floa
     if (n_work >= 2147483647LL) return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino: too many tiles");
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const unsigned grid = (unsigned)std::min<long long>(n_work, n_cu);  // persistent: one workgroup (4 waves, 156 KiB of LDS) per CU
-    hipError_t e = pool ? wino_launch<true>(tc, grid, (hipStream_t)stream, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, in_nhwc, relu)
-                        : wino_launch<false>(tc, grid, (hipStream_t)stream, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, in_nhwc, relu);
+    const hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    if (pool) e = in_nhwc ? wino_launch<true, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu)
+                          : wino_launch<true, false>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
+    else e = in_nhwc ? wino_launch<false, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu)
+                     : wino_launch<false, false>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
     HIP_TRY(e);
     return IRIS_OK;
 }

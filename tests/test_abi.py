@@ -273,15 +273,18 @@ def test_winograd_kernel_hand_set_waits_match_its_requests(device_asm):
     """k_conv3x3_wino stages its operands by LDS-DMA from inline asm and waits with hand-set counters (csrc/k_conv_wino.h): in
     every steady-state chunk body the wave requests 7 rows of input, then 8 rows of U, and `s_waitcnt vmcnt(8)` in front of the
     patch reads relies on exactly that order - a wave's vector-memory operations return in order, so at most the 8 YOUNGER U
-    requests may be outstanding once the input has landed.  Checked on the assembly of all six variants: in each loop body with
-    the 64 MFMAs of a chunk and the hand-set wait, the vector-memory instructions in front of the wait are 15 LDS-DMA requests
-    and nothing else, and the loop has no scratch access."""
+    requests may be outstanding once the input has landed.  Checked on the assembly of all twelve variants (pooled or not x
+    tile columns x input layout): in each loop body with the 64 MFMAs of a chunk and the hand-set wait, the vector-memory
+    instructions in front of the wait are 15 LDS-DMA requests and nothing else, and the loop has no scratch access.  (The
+    unpooled variants sit at the 256 + 256 register limit of a one-wave-per-SIMD kernel and keep up to 31 dwords of per-work-item
+    geometry in scratch OUTSIDE the chunk loop - stored once, reloaded once per 64 x 64 block; the pooled ones use none.)"""
     import re
     text = open(device_asm).read()
-    fns = re.split(r"\n(?=_Z14k_conv3x3_winoILb[01]ELi\d+EE[^\n]*:\s)", text)
-    assert len(fns) == 7, len(fns)   # preamble + 2 (pooled or not) x 3 (tile columns)
+    fns = re.split(r"\n(?=_Z14k_conv3x3_winoILb[01]ELi\d+ELb[01]EE[^\n]*:\s)", text)
+    assert len(fns) == 13, len(fns)   # preamble + 2 (pooled or not) x 3 (tile columns) x 2 (chunked / channels-last input)
     checked = 0
     for fn in fns[1:]:
+        head = fn.split(":", 1)[0]
         body = fn.split("s_endpgm")[0]
         blocks, cur = [], []
         for ln in body.split("\n"):
@@ -293,14 +296,17 @@ def test_winograd_kernel_hand_set_waits_match_its_requests(device_asm):
                 cur.append(t)
         blocks.append(cur)
         loops = [b for b in blocks if sum(1 for t in b if t.startswith("v_mfma_f32_32x32x2")) == 64 and "s_waitcnt vmcnt(8)" in b]
-        assert len(loops) == 2, len(loops)   # one copy of the loop per transform half (wave-uniform branch)
+        assert len(loops) == 2, (head, len(loops))   # one copy of the loop per transform half (wave-uniform branch)
         for b in loops:
             upto = b[:b.index("s_waitcnt vmcnt(8)")]
             vmem = [t.split()[0] for t in upto if re.match(r"(global|buffer|flat|scratch)_", t)]
-            assert vmem == ["global_load_lds_dwordx4"] * 15, vmem
-            assert not any(t.startswith("scratch_") for t in b)
+            assert vmem == ["global_load_lds_dwordx4"] * 15, (head, vmem)
+            assert not any(t.startswith("scratch_") for t in b), head
             checked += 1
-    assert checked == 12
+        scratch = int(re.search(r"\.amdhsa_kernel " + re.escape(head) + r"\s.*?\.amdhsa_private_segment_fixed_size (\d+)", text, re.S).group(1))
+        pooled = head.startswith("_Z14k_conv3x3_winoILb1")
+        assert scratch == 0 if pooled else scratch <= 128, (head, scratch)
+    assert checked == 24
 
 
 def test_winograd_weight_packing_on_the_host():
