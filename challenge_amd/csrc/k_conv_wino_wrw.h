@@ -15,34 +15,64 @@
 // B (V: 2 tiles x 32 cin).  A lane loads ITS channel's 4 x 4 input patch and 2 x 2 gradient tile straight from memory
 // (32 consecutive channels = one 128-byte line per pixel and half-wave), transforms both in registers and feeds the matrix
 // core: no LDS, no cross-lane traffic, no barrier anywhere in the loop.
-// Decomposition: a wave owns 32 cout x 32 cin x 16 positions = 16 accumulators (256 AGPRs, one wave per SIMD); a workgroup
-// of 4 waves a 64 x 64 block; the tile rows of the batch are split over `n_split` workgroups per block, each writing its partial
+// Decomposition: a wave owns 32 cout x 32 cin x 8 positions = 8 accumulators (128 AGPRs, two waves per SIMD); a workgroup
+// of 8 waves a 64 x 64 block x 16 positions; the tile rows of the batch are split over `n_split` workgroups per block, each writing its partial
 // dU to a workspace [split][16][Cout][Cin]; k_wino_wrw_reduce sums the splits in a fixed order (deterministic, unlike MIOpen's
 // atomics) and applies G^T . G.  Out-of-image pixels: buffer loads with an out-of-range offset return 0 without a branch.
 // Signs: A's last row is (0, -1); the kernel accumulates with +1 there (dM' = s_a s_b dM, s = (1, 1, 1, -1): adds only) and the
 // reduce kernel folds s into G.
 // ---------------------------------------------------------------------------
 #ifndef IRIS_WINO_WRW_DEPTH
-#define IRIS_WINO_WRW_DEPTH 4   // tile sets in flight per lane (loads issued DEPTH - 1 MFMA batches ahead of their transform)
+#define IRIS_WINO_WRW_DEPTH 4   // tiles in flight per lane: a tile's loads are issued DEPTH batches ahead of its transform
 #endif
-constexpr unsigned kWrwBadCol = 0x40000000u, kWrwBadRow = 0x80000000u;   // byte offsets no tensor reaches (< 2^30 bytes checked)
+// timing experiments only (results wrong when non-zero): 1 no loads in the loop, 2 no transform
+#ifndef IRIS_WRW_ABLATE
+#define IRIS_WRW_ABLATE 0
+#endif
+#define WRW_ABL(bit) ((IRIS_WRW_ABLATE & (bit)) != 0)
+typedef float wrw_f2 __attribute__((ext_vector_type(2)));
+// packed fp32 adds on register pairs, written out (the compiler scalarises vector fsub): plain, and with the halves of the
+// sources selected per result half (VOP3P op_sel / op_sel_hi: 0 = low register of the pair, 1 = high) and negated (neg_lo / neg_hi)
+#define WRW_PK(name, mods)                                                       \
+    __device__ __forceinline__ wrw_f2 name(wrw_f2 a, wrw_f2 b) {                 \
+        wrw_f2 r;                                                                \
+        asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(r) : "v"(a), "v"(b));         \
+        return r;                                                                \
+    }
+WRW_PK(wrw_add, "")                                                               // (a0 + b0, a1 + b1)
+WRW_PK(wrw_sub, "neg_lo:[0,1] neg_hi:[0,1]")                                      // (a0 - b0, a1 - b1)
+WRW_PK(wrw_row01, "op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1]")                    // (a0 - b0, a1 + b0)
+WRW_PK(wrw_row23, "op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]")       // (a0 - b1, b1 - a1)
+WRW_PK(wrw_sumdiff, "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]")                  // (a0 + b1, a0 - b1)
 
 struct WrwRaw {
-    float x[4][4];
-    float d[2][2];
+    wrw_f2 x[3][2];   // the three patch rows this wave's position half needs x (columns 0 1, columns 2 3)
+    wrw_f2 d[2];      // the gradient tile's rows (columns 0 1)
 };
 
 __device__ __forceinline__ float wrw_ld(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
 }
+// descriptor of ONE image row (`bytes` = 0: a row outside the image, every load returns 0): a column left or right of the image
+// is then an offset outside the descriptor - the hardware's range check is the zero padding
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wrw_row_rsrc(const float* base, long long row_floats, int bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base + row_floats);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, bytes, 0x00020000);
+}
 
 // x: [B][H][W][Cin], dy: [B][H][W][Cout] (channels-last, fp32), part: [n_split][16][Cout][Cin]
-__global__ __launch_bounds__(256, 1) void k_wino_wrw(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
-                                                     int B, int H, int W, int Cin, int Cout, int n_split) {
+// 8 waves = (cout half, cin half, position half) of a 64 x 64 block: TWO waves per SIMD (128 accumulators each), so that one
+// wave's loads, address arithmetic and transform run under the other's MFMAs and a wave waiting for memory does not idle the
+// matrix core (one wave per SIMD with all 16 positions: 62-68 TFLOP/s, memory latency exposed - EXPERIMENTS.md round 5).
+// PH = the wave's position half: positions 8 PH .. 8 PH + 7 = rows 2 PH, 2 PH + 1 of the 4 x 4 transforms, which read the patch
+// rows PH .. PH + 2 only.  Per tile pair a wave issues 8 MFMAs, 16 loads, 11 packed adds and 6 offset increments; the row
+// bookkeeping (five row descriptors) runs once per tile row under a uniform branch.
+template <int PH>
+__device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                              int B, int H, int W, int Cin, int Cout, int n_split, int wm, int wn) {
     constexpr int D = IRIS_WINO_WRW_DEPTH;
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, kh = lane >> 5;  // channel of the wave's 32, tile parity
-    const int wm = wv & 1, wn = wv >> 1;       // cout half / cin half of the workgroup's 64 x 64 block
+    const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;  // channel of the wave's 32, tile parity
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1, hn = (TW + 1) >> 1;  // tiles per half-wave and tile row
     const int n_rows = B * TH;
     const int cin_blocks = Cin >> 6, n_bp = cin_blocks * (Cout >> 6), total = n_bp * n_split;
@@ -53,122 +83,149 @@ __global__ __launch_bounds__(256, 1) void k_wino_wrw(const float* __restrict__ x
     const int cb = bp / cin_blocks, ib = bp - cb * cin_blocks;
     const int R_lo = (int)(((long long)n_rows * split) / n_split), R_hi = (int)(((long long)n_rows * (split + 1)) / n_split);
     const int n_it = (R_hi - R_lo) * hn;
-
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)((size_t)B * H * W * Cin * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, (int)((size_t)B * H * W * Cout * 4), 0x00020000);
-    const unsigned xch = (unsigned)(ib * 64 + 32 * wn + li) * 4u, dch = (unsigned)(cb * 64 + 32 * wm + li) * 4u;
     const unsigned xpix = (unsigned)Cin * 4u, dpix = (unsigned)Cout * 4u;
+    const int xrow_bytes = W * (int)xpix, drow_bytes = W * (int)dpix;
 
-    // running position of the load stream (uniform): tile row R_lo + it / hn, column pair it % hn
-    int ld_it = 0, ld_j = 0, ld_R = R_lo;
-    unsigned xrow[4], drow[2];  // byte offsets of the patch / gradient rows of the current tile row (uniform), or kWrwBadRow
-    auto set_rows = [&](int R) {
-        const int b_ = R / TH, th = R - b_ * TH;
+    // the load stream: tile row ld_R = (ld_b, ld_th) and column pair ld_j are uniform; a lane's tile column is kh hn + ld_j.
+    // Byte offsets inside the row of the lane's channel at the patch's four columns / the tile's two columns: the first is
+    // "negative" (wraps) for tile column 0, the last ones pass the row's end for the last tile - both outside the row descriptor.
+    unsigned col[4], dcol[2];
+    auto set_cols = [&]() {
+        const int tw0 = kh * hn;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int hh = 2 * th - 1 + r;
-            xrow[r] = (hh >= 0 && hh < H && R < R_hi) ? (unsigned)((b_ * H + hh) * W) * xpix : kWrwBadRow;
+        for (int c = 0; c < 4; ++c) col[c] = (unsigned)(2 * tw0 - 1 + c) * xpix + (unsigned)(ib * 64 + 32 * wn + li) * 4u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dcol[j] = (unsigned)(2 * tw0 + j) * dpix + (unsigned)(cb * 64 + 32 * wm + li) * 4u;
+    };
+    __amdgpu_buffer_rsrc_t rxr[3], rdr[2];
+    int ld_j = 0, ld_R = R_lo, ld_b = R_lo / TH, ld_th = R_lo - (R_lo / TH) * TH;
+    auto set_rows = [&]() {
+        const int live = ld_R < R_hi;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hh = 2 * ld_th - 1 + PH + r;
+            const int ok = live & ((unsigned)hh < (unsigned)H);
+            rxr[r] = wrw_row_rsrc(x, ok ? (long long)(ld_b * H + hh) * W * Cin : 0, ok ? xrow_bytes : 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int hh = 2 * th + i;
-            drow[i] = (hh < H && R < R_hi) ? (unsigned)((b_ * H + hh) * W) * dpix : kWrwBadRow;
+            const int hh = 2 * ld_th + i;
+            const int ok = live & (hh < H);
+            rdr[i] = wrw_row_rsrc(dy, ok ? (long long)(ld_b * H + hh) * W * Cout : 0, ok ? drow_bytes : 0);
         }
     };
-    set_rows(ld_R);
+    set_cols();
+    set_rows();
     auto issue = [&](WrwRaw& raw) {
-        const int tw = kh * hn + ld_j;
-        const bool t_ok = tw < TW;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int ww = 2 * tw - 1 + c;
-            const unsigned col = (t_ok && ww >= 0 && ww < W) ? (unsigned)ww * xpix + xch : kWrwBadCol;
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) raw.x[r][c] = wrw_ld(rx, col + xrow[r]);
-        }
+            for (int c = 0; c < 4; ++c) raw.x[r][c >> 1][c & 1] = wrw_ld(rxr[r], col[c]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ww = 2 * tw + j;
-            const unsigned col = (t_ok && ww < W) ? (unsigned)ww * dpix + dch : kWrwBadCol;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) raw.d[i][j] = wrw_ld(rd, col + drow[i]);
-        }
-        ++ld_it;
-        if (++ld_j == hn) {
+            for (int j = 0; j < 2; ++j) raw.d[i][j] = wrw_ld(rdr[i], dcol[j]);
+        if (++ld_j == hn) {   // uniform: next tile row
             ld_j = 0;
-            set_rows(++ld_R);
+            ++ld_R;
+            if (++ld_th == TH) {
+                ld_th = 0;
+                ++ld_b;
+            }
+            set_cols();
+            set_rows();
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) col[c] += 2u * xpix;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dcol[j] += 2u * dpix;
         }
     };
-    // V = B^T d B (16 values) and dM' = |A| dY |A|^T (16 values, see the header for the signs)
-    auto xform = [&](const WrwRaw& raw, float (&V)[16], float (&M)[16]) {
-        float t[4][4];
+    // rows 2 PH, 2 PH + 1 of V = B^T d B and of dM' = |A| dY |A|^T (see the header for the signs): 8 + 8 values, as pairs
+    // V[i][0] = (V_i0, V_i1), V[i][1] = (V_i2, V_i3); M likewise
+    auto xform = [&](const WrwRaw& raw, wrw_f2 (&V)[2][2], wrw_f2 (&M)[2][2]) {
+        wrw_f2 t[2][2], s[2];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t[0][c] = raw.x[0][c] - raw.x[2][c];
-            t[1][c] = raw.x[1][c] + raw.x[2][c];
-            t[2][c] = raw.x[2][c] - raw.x[1][c];
-            t[3][c] = raw.x[1][c] - raw.x[3][c];
+        for (int h = 0; h < 2; ++h) {
+            if (PH == 0) {   // patch rows 0 1 2: t0 = d0 - d2, t1 = d1 + d2
+                t[0][h] = wrw_sub(raw.x[0][h], raw.x[2][h]);
+                t[1][h] = wrw_add(raw.x[1][h], raw.x[2][h]);
+            } else {         // patch rows 1 2 3: t2 = d2 - d1, t3 = d1 - d3
+                t[0][h] = wrw_sub(raw.x[1][h], raw.x[0][h]);
+                t[1][h] = wrw_sub(raw.x[0][h], raw.x[2][h]);
+            }
+        }
+        if (PH == 0) {       // s0 = y0, s1 = y0 + y1
+            s[0] = raw.d[0];
+            s[1] = wrw_add(raw.d[0], raw.d[1]);
+        } else {             // s2 = y0 - y1, s3 = y1
+            s[0] = wrw_sub(raw.d[0], raw.d[1]);
+            s[1] = raw.d[1];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            V[4 * i + 0] = t[i][0] - t[i][2];
-            V[4 * i + 1] = t[i][1] + t[i][2];
-            V[4 * i + 2] = t[i][2] - t[i][1];
-            V[4 * i + 3] = t[i][1] - t[i][3];
-        }
-        float s[4][2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            s[0][j] = raw.d[0][j];
-            s[1][j] = raw.d[0][j] + raw.d[1][j];
-            s[2][j] = raw.d[0][j] - raw.d[1][j];
-            s[3][j] = raw.d[1][j];
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            M[4 * a + 0] = s[a][0];
-            M[4 * a + 1] = s[a][0] + s[a][1];
-            M[4 * a + 2] = s[a][0] - s[a][1];
-            M[4 * a + 3] = s[a][1];
+        for (int i = 0; i < 2; ++i) {
+            V[i][0] = wrw_row01(t[i][0], t[i][1]);   // (t0 - t2, t1 + t2)
+            V[i][1] = wrw_row23(t[i][1], t[i][0]);   // (t2 - t1, t1 - t3)
+            const wrw_f2 sd = wrw_sumdiff(s[i], s[i]);   // (s0 + s1, s0 - s1)
+            M[i][0] = wrw_f2{s[i][0], sd[0]};
+            M[i][1] = wrw_f2{sd[1], s[i][1]};
         }
     };
 
-    f32x16 acc[16];
+    f32x16 acc[8];
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     WrwRaw raw[D];
-    float V[2][16], M[2][16];
+    wrw_f2 V[2][2], M[2][2];
 #pragma unroll
     for (int q = 0; q < D; ++q) issue(raw[q]);
-    xform(raw[0], V[0], M[0]);
-    issue(raw[0]);
-    // batch `it`: MFMAs on tile it (operands V / M [it & 1]), transform of tile it + 1, loads of tile it + D + 1
     for (int it = 0; it < n_it; it += D) {
 #pragma unroll
-        for (int q = 0; q < D; ++q) {
-            const int cur = q & 1, nxt = cur ^ 1;       // D is even: (it + q) & 1 == q & 1
-            xform(raw[(q + 1) % D], V[nxt], M[nxt]);
-            issue(raw[(q + 1) % D]);
+        for (int q = 0; q < D; ++q) {   // tile it + q: transform, reload its registers with tile it + q + D, 8 MFMAs
+            if (!WRW_ABL(2) || it == 0) xform(raw[q], V, M);
+            if (!WRW_ABL(1)) issue(raw[q]);
 #pragma unroll
-            for (int p = 0; p < 16; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(M[cur][p], V[cur][p], acc[p], 0, 0, 0);
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // the next tile's transform / addresses in its shadow
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // and the loads of the tile D batches ahead
-            }
+            for (int p = 0; p < 8; ++p)
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(M[p >> 2][(p >> 1) & 1][p & 1], V[p >> 2][(p >> 1) & 1][p & 1], acc[p], 0, 0, 0);
         }
     }
     // partial dU' of this split: [split][p][cout][cin]; D register r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
-    float* const out = part + ((size_t)split * 16) * Cout * Cin + (size_t)(cb * 64 + 32 * wm + 4 * kh) * Cin + (ib * 64 + 32 * wn + li);
+    float* const out = part + ((size_t)split * 16 + 8 * PH) * Cout * Cin + (size_t)(cb * 64 + 32 * wm + 4 * kh) * Cin + (ib * 64 + 32 * wn + li);
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             out[(size_t)p * Cout * Cin + (size_t)((r & 3) + 8 * (r >> 2)) * Cin] = acc[p][r];
+}
+
+__global__ __launch_bounds__(512, 1) void k_wino_wrw(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                     int B, int H, int W, int Cin, int Cout, int n_split) {
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // waves w and w + 4 share a SIMD (round-robin placement): the same channels, the two position halves - their loads of the
+    // shared patch rows hit the same lines
+    if ((wv >> 2) == 0) wino_wrw_wave<0>(x, dy, part, B, H, W, Cin, Cout, n_split, wv & 1, (wv >> 1) & 1);
+    else wino_wrw_wave<1>(x, dy, part, B, H, W, Cin, Cout, n_split, wv & 1, (wv >> 1) & 1);
+}
+
+// First stage of the sum over many splits (layers with few channel blocks: 256 splits of a 64 x 64 layer), in place: split g < G
+// becomes the sum of the splits g, g + G, g + 2 G ... (ascending: a fixed order) - enough threads to read at memory speed, which
+// the (cout, 64 cin) workgroups of k_wino_wrw_reduce alone are not when there are only 64 of them.
+__global__ __launch_bounds__(256) void k_wino_wrw_fold(float4* __restrict__ part, int n_split, int groups, size_t n4 /* float4 per split */) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (e >= n4) return;
+    float4 a = part[(size_t)g * n4 + e];
+    for (int s = g + groups; s < n_split; s += groups) {
+        const float4 b = part[(size_t)s * n4 + e];
+        a.x += b.x;
+        a.y += b.y;
+        a.z += b.z;
+        a.w += b.w;
+    }
+    part[(size_t)g * n4 + e] = a;
 }
 
 // dW[cout][cin][a][b] = sum_{i, j} G[i][a] G[j][b] s_i s_j sum_split part[split][4 i + j][cout][cin], written with the weight
@@ -229,8 +286,8 @@ extern "C" int iris_conv3x3_wino_wrw(const float* x, const float* dy, float* dw,
     if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_wrw: empty tensor");
     if (cin <= 0 || cout <= 0 || (cin % 64) || (cout % 64))
         return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_wrw: cin %d and cout %d must be multiples of 64", cin, cout);
-    if ((long long)batch * height * width * std::max(cin, cout) * 4 >= 1073741824LL)
-        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_wrw: tensor too large for the out-of-range offsets (>= 2^30 bytes)");
+    if ((long long)batch * height * width * std::max(cin, cout) * 4 >= 2147483648LL)
+        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_wrw: tensor of 2^31 bytes or more");
     int dev = 0, n_cu = 256;
     HIP_TRY(hipGetDevice(&dev));
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
@@ -239,9 +296,17 @@ extern "C" int iris_conv3x3_wino_wrw(const float* x, const float* dy, float* dw,
     if (workspace_len < n_split * 16 * (size_t)cin * cout)
         return fail(IRIS_E_INVALID, "iris_conv3x3_wino_wrw: workspace of %zu floats, %zu needed", workspace_len, n_split * 16 * (size_t)cin * cout);
     const hipStream_t st = (hipStream_t)stream;
-    k_wino_wrw<<<(unsigned)(n_bp * n_split), 256, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
+    k_wino_wrw<<<(unsigned)(n_bp * n_split), 512, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
     HIP_TRY(hipGetLastError());
-    k_wino_wrw_reduce<<<(unsigned)(cout * (cin / 64)), 256, 0, st>>>(workspace, (int)n_split, cin, cout, dw, stride_o, stride_i, stride_h,
+    int n_left = (int)n_split;
+    if (n_left > 16) {
+        const int groups = 8;
+        const size_t n4 = (size_t)4 * cin * cout;
+        k_wino_wrw_fold<<<dim3((unsigned)((n4 + 255) / 256), groups), 256, 0, st>>>(reinterpret_cast<float4*>(workspace), n_left, groups, n4);
+        HIP_TRY(hipGetLastError());
+        n_left = groups;
+    }
+    k_wino_wrw_reduce<<<(unsigned)(cout * (cin / 64)), 256, 0, st>>>(workspace, n_left, cin, cout, dw, stride_o, stride_i, stride_h,
                                                                      stride_w, accumulate);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;

@@ -550,6 +550,41 @@ def conv3x3_wino(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch.Ten
     return y
 
 
+_WRW_WORKSPACES = {}   # device index -> scratch tensors of conv3x3_wino_wrw (grow-only: a captured hipGraph keeps its pointers)
+
+
+def _wrw_workspace(device: torch.device, floats: int) -> torch.Tensor:
+    held = _WRW_WORKSPACES.setdefault(device.index, [])
+    if not held or held[-1].numel() < floats:
+        held.append(torch.empty(max(floats, 1 << 24), dtype=torch.float32, device=device))
+    return held[-1]
+
+
+def conv3x3_wino_wrw(x: torch.Tensor, dy: torch.Tensor, like: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The weight gradient of z = conv2d(x, weight, padding=1) given dy = dL/dz, as Winograd F(2x2, 3x3) on the fp32 matrix
+    cores (iris_conv3x3_wino_wrw).  x [B, Cin, H, W] and dy [B, Cout, H, W]: channels_last float32 device tensors, Cin and
+    Cout multiples of 64.  Returns dW [Cout, Cin, 3, 3] with the strides of `like` (the weight) or channels_last."""
+    if not (x.is_cuda and x.dtype == torch.float32 and dy.dtype == torch.float32 and dy.device == x.device):
+        raise ValueError("conv3x3_wino_wrw: x and dy must be float32 tensors on one device (no CPU fallback)")
+    if not (x.dim() == 4 and dy.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and dy.is_contiguous(memory_format=torch.channels_last) and x.shape[0] == dy.shape[0] and x.shape[2:] == dy.shape[2:]):
+        raise ValueError("conv3x3_wino_wrw: x [B, Cin, H, W] and dy [B, Cout, H, W] must be channels_last and of one geometry")
+    b, cin, h, w = (int(v) for v in x.shape)
+    cout = int(dy.shape[1])
+    if like is not None and tuple(like.shape) == (cout, cin, 3, 3) and like.dtype == torch.float32:
+        dw = torch.empty_like(like)   # preserves the parameter's strides: AccumulateGrad takes it without a copy
+    else:
+        dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    lib = N.lib()
+    with torch.cuda.device(x.device):
+        ws = _wrw_workspace(x.device, int(lib.iris_wino_wrw_workspace_len(b, h, w, cin, cout)))
+        so, si, sh, sw = (int(v) for v in dw.stride())
+        rc = lib.iris_conv3x3_wino_wrw(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), so, si, sh, sw, b, h, w, cin, cout, 0,
+                                       ws.data_ptr(), ws.numel(), _stream_ptr(x.device))
+    N.check(rc, "iris_conv3x3_wino_wrw")
+    return dw
+
+
 def conv3x3_wino_bias_relu(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, cout: int, pool: bool = False,
                            out_nhwc: bool = False) -> torch.Tensor:
     """The inference form: relu(conv2d(x, weight, padding=1) + bias), with `pool` max-pooled, on the chunked layout."""

@@ -718,21 +718,25 @@ def _is_first_layer_conv(conv, x) -> bool:
 WINO_TRAIN = os.environ.get("IRIS_WINO_TRAIN", "1") != "0"
 WINO_TRAIN_MIN_C_FWD = int(os.environ.get("IRIS_WINO_TRAIN_MIN_C_FWD", "64"))
 WINO_TRAIN_MIN_C_BWD = int(os.environ.get("IRIS_WINO_TRAIN_MIN_C_BWD", "64"))
+# the weight gradient of the same layers as Winograd on the fp32 MFMA too (k_conv_wino_wrw.h; channels multiples of 64):
+# 1.5-1.7x MIOpen's weight-gradient kernels on the step's shapes, deterministic; IRIS_WINO_TRAIN_WRW=0 keeps MIOpen's
+WINO_TRAIN_WRW = WINO_TRAIN and os.environ.get("IRIS_WINO_TRAIN_WRW", "1") != "0"
 
 
 class _WinoConv3x3(torch.autograd.Function):
     """z = conv2d(x, weight, padding=1) for channels_last fp32 tensors.  forward (`fwd`): iris_conv3x3_wino on the weights packed
     on the device this step, else MIOpen; backward: dx (`bwd`) by the same kernel on the transposed / flipped weights, else
-    MIOpen; dW always by MIOpen's weight-gradient kernel (aten.convolution_backward)."""
+    MIOpen; dW (`wrw`) by iris_conv3x3_wino_wrw, else MIOpen's weight-gradient kernel (aten.convolution_backward)."""
 
     @staticmethod
-    def forward(ctx, x, weight, fwd=True, bwd=True):
+    def forward(ctx, x, weight, fwd=True, bwd=True, wrw=False):
         if fwd:
             z = _fe.conv3x3_wino(x, _fe.wino_pack_weights_device(weight), None, int(weight.shape[0]), out_nhwc=True, relu=False)
         else:
             z = torch.nn.functional.conv2d(x, weight, None, 1, 1)
         ctx.save_for_backward(x, weight)
         ctx.wino_bwd = bool(bwd)
+        ctx.wino_wrw = bool(wrw)
         return z
 
     @staticmethod
@@ -745,16 +749,20 @@ class _WinoConv3x3(torch.autograd.Function):
         wino_dx = ctx.needs_input_grad[0] and ctx.wino_bwd
         if wino_dx:
             dx = _fe.conv3x3_wino(dz, _fe.wino_pack_weights_device(weight, transposed=True), None, cin, out_nhwc=True, relu=False)
-        need = [ctx.needs_input_grad[0] and not wino_dx, ctx.needs_input_grad[1], False]
+        wino_dw = ctx.needs_input_grad[1] and ctx.wino_wrw
+        if wino_dw:
+            dw = _fe.conv3x3_wino_wrw(x, dz, like=weight)
+        need = [ctx.needs_input_grad[0] and not wino_dx, ctx.needs_input_grad[1] and not wino_dw, False]
         if need[0] or need[1]:
             gi, gw, _ = torch.ops.aten.convolution_backward(dz, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
             dx = gi if need[0] else dx
-            dw = gw if need[1] else None
-        return dx, dw, None, None
+            dw = gw if need[1] else dw
+        return dx, dw, None, None, None
 
 
 def _wino_train_conv(conv: nn.Conv2d, x: torch.Tensor):
-    """(forward by Winograd?, backward-data by Winograd?) for this layer and input, or None: MIOpen for everything."""
+    """(forward by Winograd?, backward-data by Winograd?, weight gradient by Winograd?) for this layer and input, or None:
+    MIOpen for everything."""
     def pair(v):
         return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     if not (WINO_TRAIN and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
@@ -766,7 +774,8 @@ def _wino_train_conv(conv: nn.Conv2d, x: torch.Tensor):
     ci, co, big = conv.in_channels, conv.out_channels, max(conv.in_channels, conv.out_channels)
     fwd = ci % 8 == 0 and co % 64 == 0 and big >= WINO_TRAIN_MIN_C_FWD
     bwd = co % 8 == 0 and ci % 64 == 0 and big >= WINO_TRAIN_MIN_C_BWD
-    return (fwd, bwd) if (fwd or bwd) else None
+    wrw = WINO_TRAIN_WRW and ci % 64 == 0 and co % 64 == 0 and x.shape[0] * x.shape[2] * x.shape[3] * big < (1 << 29)
+    return (fwd, bwd, wrw) if (fwd or bwd or wrw) else None
 
 
 class _ConvBNReLU(nn.Sequential):
@@ -790,7 +799,7 @@ class _ConvBNReLU(nn.Sequential):
                                                    bn.running_var, bn.eps, bn.momentum)
                 wino = _wino_train_conv(conv, x)
                 if wino is not None:
-                    z = _WinoConv3x3.apply(x, conv.weight, wino[0], wino[1])
+                    z = _WinoConv3x3.apply(x, conv.weight, wino[0], wino[1], wino[2])
                 else:
                     z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
                 if z.is_contiguous(memory_format=torch.channels_last):

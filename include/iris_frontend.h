@@ -377,6 +377,24 @@ int iris_conv3x3_wino(const float* x, const float* packed, const float* bias, fl
                       int cout, int flags, void* stream);
 
 /*
+ * The WEIGHT GRADIENT of the same convolution, y = conv3x3_same(x, w), as a Winograd F(2x2, 3x3) transform on the fp32 matrix
+ * cores - model.fit's backward pass through blocks 2-5 (sj_train.py:191-201, 222-242, 408), which MIOpen runs as implicit
+ * GEMMs at 82-127 TFLOP/s: dU[p] = sum over the tiles of the batch of (A dY A^T)[p] (B^T d B)[p] per position p, dW = G^T dU G -
+ * 16 instead of 36 multiplies per 2 x 2 tile and channel pair.  Both free dimensions of that GEMM are channels, so with
+ * channels-last activations a lane loads its channel's patch straight from memory into the MFMA operand layout (no LDS).
+ * Deterministic (the tile rows are split over workgroups whose partial sums are added in a fixed order); against an fp64
+ * gradient the error is that of a direct fp32 one (2e-7 .. 6e-7 of the gradient's peak).  cin % 64 == 0, cout % 64 == 0.
+ *   x, dy      channels-last [batch][height][width][cin] / [...][cout], DEVICE, fewer than 2^31 bytes each
+ *   dw         the gradient, element strides stride_o / _i / _h / _w over [cout][cin][3][3] (a channels_last parameter's
+ *              gradient is written as it lies); accumulate != 0 adds to what is there
+ *   workspace  DEVICE scratch of at least iris_wino_wrw_workspace_len(batch, height, width, cin, cout) floats (64 MiB on 256 CUs)
+ */
+size_t iris_wino_wrw_workspace_len(int batch, int height, int width, int cin, int cout);
+int iris_conv3x3_wino_wrw(const float* x, const float* dy, float* dw, long stride_o, long stride_i, long stride_h, long stride_w,
+                          int batch, int height, int width, int cin, int cout, int accumulate, float* workspace,
+                          size_t workspace_len, void* stream);
+
+/*
  * The CRNN's first layer in TRAINING mode - Conv2D(3x3 'same', 1 or 2 input channels) + BatchNormalization + ReLU
  * (sj_train.py:191-201, 244) - with the convolution recomputed from x wherever its output is needed (9-18 FMAs per value
  * against 4 bytes of traffic): z is never stored.  x [batch, in_channels, height, width] contiguous; weight

@@ -309,6 +309,47 @@ def test_winograd_kernel_hand_set_waits_match_its_requests(device_asm):
     assert checked == 24
 
 
+def test_winograd_weight_gradient_kernel_fits_two_waves_per_simd(device_asm):
+    """k_wino_wrw (csrc/k_conv_wino_wrw.h) hides memory latency with TWO waves per SIMD: workgroups of 512 threads need at most
+    256 registers per lane (vector + accumulation), no scratch; its transform is written as packed adds (11 v_pk_add_f32 per
+    tile and position half) and the hot block of a tile holds exactly 8 MFMAs and 16 loads."""
+    import re
+    text = open(device_asm).read()
+    m = re.search(r"\.amdhsa_kernel _Z10k_wino_wrwPKfS0_Pfiiiiii\s(.*?)\.end_amdhsa_kernel", text, re.S)
+    assert m
+    assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(1)).group(1)) == 0
+    assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(1)).group(1)) <= 256
+    body = text.split("\n_Z10k_wino_wrwPKfS0_Pfiiiiii:", 1)[1].split("s_endpgm")[0]
+    assert not re.search(r"\bscratch_", body)
+    blocks, cur = [], []
+    for ln in body.split("\n"):
+        t = ln.strip()
+        if re.match(r"\.LBB\d+_\d+:", t):
+            blocks.append(cur)
+            cur = []
+        elif t and not t.startswith(";"):
+            cur.append(t)
+    blocks.append(cur)
+    hot = [b for b in blocks if sum(t.startswith("v_mfma_f32_32x32x2") for t in b) == 8 and sum(t.startswith("buffer_load_dword ") for t in b) == 16]
+    assert len(hot) >= 4, len(hot)      # both position halves, several slots of the unrolled ring
+    assert body.count("v_pk_add_f32") >= 2 * 11
+
+
+def test_winograd_weight_gradient_argument_checks():
+    """iris_conv3x3_wino_wrw refuses what the kernel does not cover before touching the device."""
+    lib = N.lib()
+    import ctypes as C
+    buf = (C.c_float * 16)()
+    p = C.addressof(buf)
+    assert lib.iris_wino_wrw_workspace_len(4, 8, 8, 64, 128) in (0, 16 * 64 * 128 * 16) or lib.iris_wino_wrw_workspace_len(4, 8, 8, 64, 128) % (16 * 64 * 128) == 0
+    assert lib.iris_wino_wrw_workspace_len(4, 8, 8, 32, 128) == 0
+    assert lib.iris_conv3x3_wino_wrw(None, p, p, 1, 1, 1, 1, 1, 4, 4, 64, 64, 0, p, 16, None) == -1
+    assert lib.iris_conv3x3_wino_wrw(p, p, p, 1, 1, 1, 1, 0, 4, 4, 64, 64, 0, p, 16, None) == -1
+    assert lib.iris_conv3x3_wino_wrw(p, p, p, 1, 1, 1, 1, 1, 4, 4, 32, 64, 0, p, 16, None) == -2
+    assert lib.iris_conv3x3_wino_wrw(p, p, p, 1, 1, 1, 1, 1, 4, 4, 64, 96, 0, p, 16, None) == -2
+    assert lib.iris_conv3x3_wino_wrw(p, p, p, 1, 1, 1, 1, 4096, 64, 64, 64, 64, 0, p, 16, None) == -2   # 2^32 bytes
+
+
 def test_winograd_weight_packing_on_the_host():
     """iris_wino_pack_weights (host code, no GPU): U = G g G^T per (cout, cin), stored in the kernel's LDS order
     [cout block][chunk of 8 cin][position 16][pair 2][hl 2][cout 64][2] with channel 4 pair + 2 hl + j of the chunk at (pair, hl, j)."""

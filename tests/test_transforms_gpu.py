@@ -1156,7 +1156,9 @@ def test_winograd_convolution_matches_fp64(dev, b, h, w, cin, cout):
 def test_winograd_training_convolution_matches_torch(dev, b, h, w, cin, cout):
     """The training step's deep convolutions (sj_train._WinoConv3x3): forward z = conv(x, W) and backward-data dx by the
     Winograd kernel on channels_last tensors with the weights packed on the device (plain and transposed / flipped), dW by
-    MIOpen - equal to torch's conv2d and its autograd gradients; the device packing equals the host packing to fp32 rounding.
+    the Winograd weight-gradient kernel where both channel counts are multiples of 64 (MIOpen otherwise) - equal to torch's
+    conv2d and its autograd gradients; the device packing equals the host packing to fp32 rounding; the gradient of a
+    channels_last parameter comes back in the parameter's own strides.
     (cin = 24 -> 64: the backward-data pass's shape rule fails for the swapped channel counts and MIOpen computes dx.)"""
     from challenge_amd import frontend as FE
     from challenge_amd import sj_train as S
@@ -1170,7 +1172,8 @@ def test_winograd_training_convolution_matches_torch(dev, b, h, w, cin, cout):
     if cout % 8 == 0 and cin % 64 == 0:   # the transposed packing == the host packing of the flipped, transposed weight
         flipped = wt.detach().flip(2, 3).transpose(0, 1).contiguous()
         assert float((FE.wino_pack_weights_device(wt.detach(), transposed=True) - FE.wino_pack_weights(flipped)).abs().max()) <= 4e-7 * wmax
-    z = S._WinoConv3x3.apply(x, wt, True, cout % 8 == 0 and cin % 64 == 0)
+    wrw = cin % 64 == 0 and cout % 64 == 0
+    z = S._WinoConv3x3.apply(x, wt, True, cout % 8 == 0 and cin % 64 == 0, wrw)
     assert z.is_contiguous(memory_format=torch.channels_last)
     dz = torch.randn(z.shape, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
     z.backward(dz)
@@ -1181,7 +1184,40 @@ def test_winograd_training_convolution_matches_torch(dev, b, h, w, cin, cout):
     def rel(a, r):
         return float((a.double() - r).abs().max() / r.abs().max())
     assert rel(z, ref) <= 2e-6 and rel(x.grad, x2.grad) <= 2e-6, (rel(z, ref), rel(x.grad, x2.grad))
-    assert rel(wt.grad, w2.grad) <= 2e-5     # MIOpen's weight gradient (fp32 atomics)
+    assert rel(wt.grad, w2.grad) <= (2e-6 if wrw else 2e-5)     # (MIOpen's weight gradient: fp32 atomics)
+    assert wt.grad.stride() == wt.stride()
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout", [(2, 8, 12, 64, 64), (3, 7, 9, 64, 128), (1, 5, 33, 128, 64), (2, 16, 128, 128, 128),
+                                            (2, 4, 32, 512, 512), (64, 4, 32, 256, 512), (5, 1, 1, 64, 64), (1, 2, 3, 64, 64),
+                                            (300, 2, 5, 64, 64), (64, 32, 256, 64, 64)])
+def test_winograd_weight_gradient_matches_fp64(dev, b, h, w, cin, cout):
+    """iris_conv3x3_wino_wrw (csrc/k_conv_wino_wrw.h): dW of the 3x3 'same' convolution as Winograd F(2x2, 3x3) on the fp32
+    MFMA, against aten's convolution_backward in float64 - odd heights and widths (tiles hanging over the right / bottom edge),
+    single pixels, more tile rows than workgroups and fewer, the step's largest activation (64 x 32 x 256 x 64), 4 and 256
+    splits (the two-stage sum).  Error of a direct fp32 gradient (MIOpen's beside it), the same bits on every call, the
+    parameter's strides honoured."""
+    from challenge_amd import frontend as FE
+    g = torch.Generator(device=dev).manual_seed(b + h + w + cin)
+    x = torch.randn(b, cin, h, w, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(b, cout, h, w, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
+    like_cl = torch.empty(cout, cin, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+    like_nchw = torch.empty(cout, cin, 3, 3, device=dev)
+    got = FE.conv3x3_wino_wrw(x, dy, like=like_cl)
+    assert got.stride() == like_cl.stride()
+    w0 = torch.zeros(cout, cin, 3, 3, device=dev, dtype=torch.float64)
+    ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w0, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1]
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-6, err
+    again = FE.conv3x3_wino_wrw(x, dy, like=like_nchw)
+    assert again.stride() == like_nchw.stride() and torch.equal(again, got)
+    with pytest.raises(ValueError):
+        FE.conv3x3_wino_wrw(x.contiguous(), dy)                       # not channels_last (unless a dimension is 1)
+        if 1 in (h * w, cin):
+            raise ValueError("layouts coincide")
+    with pytest.raises(ValueError):
+        FE.conv3x3_wino_wrw(x[:, :32].contiguous(memory_format=torch.channels_last), dy)   # 32 input channels: unsupported
 
 
 def test_hip_bilstm_matches_torch(dev):
