@@ -68,14 +68,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wrw_row_rsrc(const float* base
 // PH = the wave's position half: positions 8 PH .. 8 PH + 7 = rows 2 PH, 2 PH + 1 of the 4 x 4 transforms, which read the patch
 // rows PH .. PH + 2 only.  Per tile pair a wave issues 8 MFMAs, 16 loads, 11 packed adds and 6 offset increments; the row
 // bookkeeping (five row descriptors) runs once per tile row under a uniform branch.
-template <int PH>
+template <int PH, int NW>
 __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
                                               int B, int H, int W, int Cin, int Cout, int n_split, int wm, int wn) {
     constexpr int D = IRIS_WINO_WRW_DEPTH;
     const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;  // channel of the wave's 32, tile parity
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1, hn = (TW + 1) >> 1;  // tiles per half-wave and tile row
     const int n_rows = B * TH;
-    const int cin_blocks = Cin >> 6, n_bp = cin_blocks * (Cout >> 6), total = n_bp * n_split;
+    const int cin_blocks = Cin / (32 * NW), n_bp = cin_blocks * (Cout >> 6), total = n_bp * n_split;
     // workgroups of one XCD (blockIdx mod 8) take neighbouring work: the same tile rows for different channel blocks
     int wk = blockIdx.x;
     if ((total & 7) == 0) wk = (wk & 7) * (total >> 3) + (wk >> 3);
@@ -93,7 +93,7 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
     auto set_cols = [&]() {
         const int tw0 = kh * hn;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) col[c] = (unsigned)(2 * tw0 - 1 + c) * xpix + (unsigned)(ib * 64 + 32 * wn + li) * 4u;
+        for (int c = 0; c < 4; ++c) col[c] = (unsigned)(2 * tw0 - 1 + c) * xpix + (unsigned)(ib * 32 * NW + 32 * wn + li) * 4u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) dcol[j] = (unsigned)(2 * tw0 + j) * dpix + (unsigned)(cb * 64 + 32 * wm + li) * 4u;
     };
@@ -193,7 +193,7 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
         }
     }
     // partial dU' of this split: [split][p][cout][cin]; D register r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
-    float* const out = part + ((size_t)split * 16 + 8 * PH) * Cout * Cin + (size_t)(cb * 64 + 32 * wm + 4 * kh) * Cin + (ib * 64 + 32 * wn + li);
+    float* const out = part + ((size_t)split * 16 + 8 * PH) * Cout * Cin + (size_t)(cb * 64 + 32 * wm + 4 * kh) * Cin + (ib * 32 * NW + 32 * wn + li);
 #pragma unroll
     for (int p = 0; p < 8; ++p)
 #pragma unroll
@@ -201,13 +201,16 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
             out[(size_t)p * Cout * Cin + (size_t)((r & 3) + 8 * (r >> 2)) * Cin] = acc[p][r];
 }
 
-__global__ __launch_bounds__(512, 1) void k_wino_wrw(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
-                                                     int B, int H, int W, int Cin, int Cout, int n_split) {
+// NW = 2: 8 waves, a 64 x 64 block (cin % 64 == 0).  NW = 1: 4 waves, 64 cout x 32 cin (cin % 32 == 0: the 32 -> 64 layer); two such
+// workgroups share a CU, so every SIMD still holds two waves
+template <int NW>
+__global__ __launch_bounds__(256 * NW, 2) void k_wino_wrw(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                          int B, int H, int W, int Cin, int Cout, int n_split) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // waves w and w + 4 share a SIMD (round-robin placement): the same channels, the two position halves - their loads of the
-    // shared patch rows hit the same lines
-    if ((wv >> 2) == 0) wino_wrw_wave<0>(x, dy, part, B, H, W, Cin, Cout, n_split, wv & 1, (wv >> 1) & 1);
-    else wino_wrw_wave<1>(x, dy, part, B, H, W, Cin, Cout, n_split, wv & 1, (wv >> 1) & 1);
+    // waves w and w + 2 NW share a SIMD (round-robin placement): the same channels, the two position halves - their loads of
+    // the shared patch rows hit the same lines
+    if (wv < 2 * NW) wino_wrw_wave<0, NW>(x, dy, part, B, H, W, Cin, Cout, n_split, wv & 1, (wv >> 1) & (NW - 1));
+    else wino_wrw_wave<1, NW>(x, dy, part, B, H, W, Cin, Cout, n_split, wv & 1, (wv >> 1) & (NW - 1));
 }
 
 // First stage of the sum over many splits (layers with few channel blocks: 256 splits of a 64 x 64 layer), in place: split g < G
@@ -229,15 +232,16 @@ __global__ __launch_bounds__(256) void k_wino_wrw_fold(float4* __restrict__ part
 }
 
 // dW[cout][cin][a][b] = sum_{i, j} G[i][a] G[j][b] s_i s_j sum_split part[split][4 i + j][cout][cin], written with the weight
-// tensor's own element strides (a channels_last parameter's gradient as it is).  One workgroup per (cout, 64 cin): thread
-// (i = t >> 6, cin = t & 63) sums row i of the 4 x 4 over the splits in ascending order and applies G along j; the column
+// tensor's own element strides (a channels_last parameter's gradient as it is).  One workgroup per (cout, CB = 64 or 32 cin): thread
+// (i = t / CB, cin = t % CB) sums row i of the 4 x 4 over the splits in ascending order and applies G along j; the column
 // pass over i goes through LDS.
-__global__ __launch_bounds__(256) void k_wino_wrw_reduce(const float* __restrict__ part, int n_split, int Cin, int Cout,
-                                                         float* __restrict__ dw, long so, long si, long sh, long sw, int accumulate) {
-    __shared__ float rows[4][3][64];
-    const int t = threadIdx.x, i = t >> 6, cl = t & 63;
-    const int cin_blocks = Cin >> 6;
-    const int co = blockIdx.x / cin_blocks, ci = (blockIdx.x - co * cin_blocks) * 64 + cl;
+template <int CB>
+__global__ __launch_bounds__(4 * CB) void k_wino_wrw_reduce(const float* __restrict__ part, int n_split, int Cin, int Cout,
+                                                            float* __restrict__ dw, long so, long si, long sh, long sw, int accumulate) {
+    __shared__ float rows[4][3][CB];
+    const int t = threadIdx.x, i = t / CB, cl = t % CB;
+    const int cin_blocks = Cin / CB;
+    const int co = blockIdx.x / cin_blocks, ci = (blockIdx.x - co * cin_blocks) * CB + cl;
     const size_t plane = (size_t)Cout * Cin;
     const float* p = part + ((size_t)4 * i) * plane + (size_t)co * Cin + ci;
     float u[4] = {0.f, 0.f, 0.f, 0.f};
@@ -262,15 +266,18 @@ __global__ __launch_bounds__(256) void k_wino_wrw_reduce(const float* __restrict
     }
 }
 
+// workgroups of 64 cout x (64 or 32) cin; as many splits of the tile rows as fill every SIMD with two waves
+static int wino_wrw_cin_block(int cin) { return (cin % 64) ? 32 : 64; }
 static size_t wino_wrw_splits(int batch, int height, int cin, int cout, int n_cu) {
-    const int n_bp = (cin / 64) * (cout / 64), n_rows = batch * ((height + 1) / 2);
-    return (size_t)std::max(1, std::min(n_rows, n_cu / std::max(1, std::min(n_bp, n_cu))));
+    const int cbk = wino_wrw_cin_block(cin), want = n_cu * (64 / cbk);
+    const int n_bp = (cin / cbk) * (cout / 64), n_rows = batch * ((height + 1) / 2);
+    return (size_t)std::max(1, std::min(n_rows, want / std::max(1, std::min(n_bp, want))));
 }
 
 // floats of workspace iris_conv3x3_wino_wrw needs for this geometry (partial sums of the tile-row splits)
 extern "C" size_t iris_wino_wrw_workspace_len(int batch, int height, int width, int cin, int cout) {
     (void)width;
-    if (batch <= 0 || height <= 0 || cin <= 0 || cout <= 0 || (cin % 64) || (cout % 64)) return 0;
+    if (batch <= 0 || height <= 0 || cin <= 0 || cout <= 0 || (cin % 32) || (cout % 64)) return 0;
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     return wino_wrw_splits(batch, height, cin, cout, n_cu) * 16 * (size_t)cin * cout;
@@ -284,19 +291,20 @@ extern "C" int iris_conv3x3_wino_wrw(const float* x, const float* dy, float* dw,
                                      float* workspace, size_t workspace_len, void* stream) {
     if (!x || !dy || !dw || !workspace) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_wrw: NULL argument");
     if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_wrw: empty tensor");
-    if (cin <= 0 || cout <= 0 || (cin % 64) || (cout % 64))
-        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_wrw: cin %d and cout %d must be multiples of 64", cin, cout);
+    if (cin <= 0 || cout <= 0 || (cin % 32) || (cout % 64))
+        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_wrw: cin %d must be a multiple of 32, cout %d of 64", cin, cout);
     if ((long long)batch * height * width * std::max(cin, cout) * 4 >= 2147483648LL)
         return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_wrw: tensor of 2^31 bytes or more");
     int dev = 0, n_cu = 256;
     HIP_TRY(hipGetDevice(&dev));
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const size_t n_split = wino_wrw_splits(batch, height, cin, cout, n_cu);
-    const int n_bp = (cin / 64) * (cout / 64);
+    const int cbk = wino_wrw_cin_block(cin), n_bp = (cin / cbk) * (cout / 64);
     if (workspace_len < n_split * 16 * (size_t)cin * cout)
         return fail(IRIS_E_INVALID, "iris_conv3x3_wino_wrw: workspace of %zu floats, %zu needed", workspace_len, n_split * 16 * (size_t)cin * cout);
     const hipStream_t st = (hipStream_t)stream;
-    k_wino_wrw<<<(unsigned)(n_bp * n_split), 512, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
+    if (cbk == 64) k_wino_wrw<2><<<(unsigned)(n_bp * n_split), 512, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
+    else k_wino_wrw<1><<<(unsigned)(n_bp * n_split), 256, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
     HIP_TRY(hipGetLastError());
     int n_left = (int)n_split;
     if (n_left > 16) {
@@ -306,8 +314,12 @@ extern "C" int iris_conv3x3_wino_wrw(const float* x, const float* dy, float* dw,
         HIP_TRY(hipGetLastError());
         n_left = groups;
     }
-    k_wino_wrw_reduce<<<(unsigned)(cout * (cin / 64)), 256, 0, st>>>(workspace, n_left, cin, cout, dw, stride_o, stride_i, stride_h,
-                                                                     stride_w, accumulate);
+    if (cbk == 64)
+        k_wino_wrw_reduce<64><<<(unsigned)(cout * (cin / 64)), 256, 0, st>>>(workspace, n_left, cin, cout, dw, stride_o, stride_i,
+                                                                             stride_h, stride_w, accumulate);
+    else
+        k_wino_wrw_reduce<32><<<(unsigned)(cout * (cin / 32)), 128, 0, st>>>(workspace, n_left, cin, cout, dw, stride_o, stride_i,
+                                                                             stride_h, stride_w, accumulate);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }
