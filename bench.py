@@ -291,11 +291,12 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                 # what the inference engine issues on the matrix cores: Winograd F(2x2, 3x3) needs 16 instead of 36 multiplies
                 # per output tile wherever its kernel applies (8 | Cin, 64 | Cout: blocks 2-5)
                 wino_flops += f / 2.25 if (infer.wino_convs and m.in_channels % 8 == 0 and m.out_channels % 64 == 0) else f
-                # ... and the training step: forward and backward-data by the same rule per direction, weight gradient direct
+                # ... and the training step: forward, backward-data and weight gradient by the same rule per pass
                 ci, co, big = m.in_channels, m.out_channels, max(m.in_channels, m.out_channels)
                 fwd = S.WINO_TRAIN and ci % 8 == 0 and co % 64 == 0 and big >= S.WINO_TRAIN_MIN_C_FWD
                 bwd = S.WINO_TRAIN and co % 8 == 0 and ci % 64 == 0 and big >= S.WINO_TRAIN_MIN_C_BWD
-                train_flops += (f / 2.25 if fwd else f) + (f / 2.25 if bwd else f) + f
+                wrw = S.WINO_TRAIN_WRW and ci % 32 == 0 and co % 64 == 0
+                train_flops += (f / 2.25 if fwd else f) + (f / 2.25 if bwd else f) + (f / 2.25 if wrw else f)
         if isinstance(getattr(blk, "pool", None), torch.nn.MaxPool2d):
             hw = (-(-hw[0] // 2), -(-hw[1] // 2))
     best_fwd_ms = 1e3 * min(t for t in (t_fwd, t_fwd_folded, t_fwd_graph) if t is not None)
@@ -307,10 +308,11 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
             "c4_mfma_gflop_issued_by_the_step": round(train_flops / 1e9, 1),
             "c4_bound_ms": round(1e3 * train_flops / 157.3e12, 3), "c4_frac_of_bound": round(1e3 * train_flops / 157.3e12 / (1e3 * t_train), 3),
             "winograd_layers": infer.wino_convs, "winograd_in_training": bool(S.WINO_TRAIN),
+            "winograd_weight_gradient": bool(S.WINO_TRAIN_WRW),
             "note": "forward = one pass over the convolutions, training = three (forward, backward-data, backward-weight); fp32 in / "
                     "fp32 accumulate MFMA, the precision the reference trains in.  c3_bound_ms / c4_bound_ms price the multiplies "
-                    "really issued (Winograd F(2x2, 3x3) in blocks 2-5 - inference: every layer; training: forward and backward-data, "
-                    "the weight gradient stays MIOpen's direct kernel - 2.25x fewer than the direct convolution, whose own bound "
+                    "really issued (Winograd F(2x2, 3x3) in blocks 2-5 - inference: every layer; training: forward, backward-data and "
+                    "the weight gradient (k_conv_wino_wrw.h) - 2.25x fewer than the direct convolution, whose own bound "
                     "c3_direct_bound_ms the engine now runs BELOW); 157.3 TFLOP/s is the MFMA peak at 2.4 GHz - a bare MFMA "
                     "loop sustains ~131 on this chip (scripts/gpu_wino_bench.py ablation)"}
     c3 = {"audio_s_per_s": round(world * audio_s / t_fwd, 1), "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch,

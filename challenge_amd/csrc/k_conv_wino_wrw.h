@@ -45,9 +45,16 @@ WRW_PK(wrw_row01, "op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1]")                  
 WRW_PK(wrw_row23, "op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]")       // (a0 - b1, b1 - a1)
 WRW_PK(wrw_sumdiff, "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]")                  // (a0 + b1, a0 - b1)
 
+// 1: a lane walks its tiles left to right and keeps the column transform of the two patch columns it shares with the next
+// tile (6 + 4 loads per tile instead of 12 + 4; the first tile of a tile row loads all four columns); 0: every tile loads its
+// whole patch
+#ifndef IRIS_WRW_SLIDE
+#define IRIS_WRW_SLIDE 1
+#endif
 struct WrwRaw {
     wrw_f2 x[3][2];   // the three patch rows this wave's position half needs x (columns 0 1, columns 2 3)
     wrw_f2 d[2];      // the gradient tile's rows (columns 0 1)
+    int first;        // uniform: the tile is the first of its tile row (x[.][0] was loaded)
 };
 
 __device__ __forceinline__ float wrw_ld(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
@@ -117,10 +124,17 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
     set_cols();
     set_rows();
     auto issue = [&](WrwRaw& raw) {
+        raw.first = !IRIS_WRW_SLIDE || ld_j == 0;
+        if (raw.first) {   // uniform
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) raw.x[r][0][c] = wrw_ld(rxr[r], col[c]);
+        }
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) raw.x[r][c >> 1][c & 1] = wrw_ld(rxr[r], col[c]);
+            for (int c = 2; c < 4; ++c) raw.x[r][1][c & 1] = wrw_ld(rxr[r], col[c]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -143,17 +157,26 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
     };
     // rows 2 PH, 2 PH + 1 of V = B^T d B and of dM' = |A| dY |A|^T (see the header for the signs): 8 + 8 values, as pairs
     // V[i][0] = (V_i0, V_i1), V[i][1] = (V_i2, V_i3); M likewise
+    wrw_f2 carry[2] = {wrw_f2{0.f, 0.f}, wrw_f2{0.f, 0.f}};   // B^T d of the previous tile's columns 2 3 = this tile's columns 0 1
     auto xform = [&](const WrwRaw& raw, wrw_f2 (&V)[2][2], wrw_f2 (&M)[2][2]) {
         wrw_f2 t[2][2], s[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        auto colop = [&](int h, wrw_f2 (&out)[2]) {
             if (PH == 0) {   // patch rows 0 1 2: t0 = d0 - d2, t1 = d1 + d2
-                t[0][h] = wrw_sub(raw.x[0][h], raw.x[2][h]);
-                t[1][h] = wrw_add(raw.x[1][h], raw.x[2][h]);
+                out[0] = wrw_sub(raw.x[0][h], raw.x[2][h]);
+                out[1] = wrw_add(raw.x[1][h], raw.x[2][h]);
             } else {         // patch rows 1 2 3: t2 = d2 - d1, t3 = d1 - d3
-                t[0][h] = wrw_sub(raw.x[1][h], raw.x[0][h]);
-                t[1][h] = wrw_sub(raw.x[0][h], raw.x[2][h]);
+                out[0] = wrw_sub(raw.x[1][h], raw.x[0][h]);
+                out[1] = wrw_sub(raw.x[0][h], raw.x[2][h]);
             }
+        };
+        if (raw.first) colop(0, carry);   // uniform
+        wrw_f2 right[2];
+        colop(1, right);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            t[i][0] = carry[i];
+            t[i][1] = right[i];
+            carry[i] = right[i];
         }
         if (PH == 0) {       // s0 = y0, s1 = y0 + y1
             s[0] = raw.d[0];

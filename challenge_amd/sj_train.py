@@ -567,6 +567,65 @@ def _is_pool_2x2_same(pool):
             and pair(pool.padding) == (0, 0) and pair(pool.dilation) == (1, 1) and pool.ceil_mode and not pool.return_indices)
 
 
+class _ZeroPool:
+    """Zero-initialised device scratch for the fused passes (the shifted sums of the BatchNorm passes, the first layer's
+    weight-gradient copies, the identically-zero bias gradients): `take` hands out slices of one buffer per dtype and
+    `begin_step` re-zeroes what the previous step used with ONE fill per dtype - 58 fill launches per training step fewer
+    (profiles/r5/c4_step_kernel_stats.csv).  Outside a step `take` keeps handing out untouched zeros and falls back to
+    torch.zeros when the buffer is exhausted.  Buffers are only ever replaced by larger ones and the old ones kept: a captured
+    hipGraph (GraphedTrainStep) replays with their addresses.  A slice stays valid until the next `begin_step` on its device;
+    a bias gradient that autograd adopts from a slice is zero and stays zero."""
+
+    def __init__(self):
+        self._state = {}   # (device index, dtype) -> [buffer, offset, wanted]
+        self._old = []
+
+    def take(self, n: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+        key = (device.index, dtype)
+        st = self._state.get(key)
+        step = -(-n // 8) * 8   # 32- / 64-byte granules: every slice 16-byte aligned
+        if st is None:
+            st = self._state[key] = [None, 0, 0]
+        st[2] += step
+        if st[0] is None or st[1] + step > st[0].numel():
+            return torch.zeros(n, dtype=dtype, device=device)
+        out = st[0][st[1]:st[1] + n]
+        st[1] += step
+        return out
+
+    def begin_step(self, device: torch.device) -> None:
+        for (index, dtype), st in self._state.items():
+            if index != device.index:
+                continue
+            if st[0] is None or st[2] > st[0].numel():   # the last step wanted more than there is: grow (already zero)
+                if st[0] is not None:
+                    self._old.append(st[0])
+                st[0] = torch.zeros(max(2 * st[2], 4096), dtype=dtype, device=device)
+            elif st[1]:
+                st[0][:st[1]].zero_()
+            st[1] = st[2] = 0
+
+
+# BatchNorm's num_batches_tracked counters of the layers whose fused passes ran, bumped by ONE _foreach_add_ at the end of
+# CustomModel.forward instead of one launch per layer (None outside that forward: the layers then bump their own)
+_NBT_PENDING = None
+
+
+def _count_batch(bn) -> None:
+    if _NBT_PENDING is not None:
+        _NBT_PENDING.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
+_ZERO_POOL = _ZeroPool()
+ZERO_POOL = os.environ.get("IRIS_ZERO_POOL", "1") != "0"
+
+
+def _zeros(n: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    return _ZERO_POOL.take(int(n), dtype, device) if ZERO_POOL else torch.zeros(int(n), dtype=dtype, device=device)
+
+
 class _FusedBiasBNReLU(torch.autograd.Function):
     """y = relu(batch_norm(z + conv_bias)) in training mode on a channels_last fp32 convolution output z (sj_train.py:191-201),
     with `pool` also the block's MaxPool2d(2, 2, ceil_mode=True) behind it (the full-size y and dy then never exist).
@@ -581,7 +640,7 @@ class _FusedBiasBNReLU(torch.autograd.Function):
         rows = b * h * w
         dev = z.device
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        sums = torch.zeros(int(N.lib().iris_bn_sums_len(c)), dtype=torch.float64, device=dev)
+        sums = _zeros(N.lib().iris_bn_sums_len(c), torch.float64, dev)
         if pool:
             y = torch.empty((b, c, (h + 1) // 2, (w + 1) // 2), dtype=z.dtype, device=dev, memory_format=torch.channels_last)
         else:
@@ -615,7 +674,7 @@ class _FusedBiasBNReLU(torch.autograd.Function):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
-        sums = torch.zeros(int(N.lib().iris_bn_sums_len(c)), dtype=torch.float64, device=dev)
+        sums = _zeros(N.lib().iris_bn_sums_len(c), torch.float64, dev)
         dz = torch.empty_like(z)
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
@@ -631,7 +690,7 @@ class _FusedBiasBNReLU(torch.autograd.Function):
                 N.check(lib.iris_bn_relu_bwd_reduce(z.data_ptr(), dy.data_ptr(), rows, c, *stats, stream), "iris_bn_relu_bwd_reduce")
                 N.check(lib.iris_bn_relu_bwd_dx(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, c, *stats,
                                                 dgamma.data_ptr(), dbeta.data_ptr(), stream), "iris_bn_relu_bwd_dx")
-        dbias = torch.zeros(c, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        dbias = _zeros(c, torch.float32, dev) if ctx.has_bias else None
         return dz, dbias, dgamma, dbeta, None, None, None, None, None
 
 
@@ -651,7 +710,7 @@ class _FusedConv0BNReLU(torch.autograd.Function):
         xc = x.contiguous()                     # [B, CIN, H, W]; one channel: the channels_last tensor already is
         wc = weight.detach().contiguous()       # [COUT, CIN, 3, 3]
         lib = N.lib()
-        sums = torch.zeros(int(lib.iris_bn_sums_len(cout)), dtype=torch.float64, device=dev)
+        sums = _zeros(lib.iris_bn_sums_len(cout), torch.float64, dev)
         y = torch.empty((b, cout, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
         save_mean = torch.empty(cout, dtype=torch.float32, device=dev)
         save_rstd = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -681,8 +740,8 @@ class _FusedConv0BNReLU(torch.autograd.Function):
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         lib = N.lib()
-        sums = torch.zeros(int(lib.iris_bn_sums_len(cout)), dtype=torch.float64, device=dev)
-        dw64 = torch.zeros(int(lib.iris_conv0_dweight_len(cin, cout)), dtype=torch.float64, device=dev)
+        sums = _zeros(lib.iris_bn_sums_len(cout), torch.float64, dev)
+        dw64 = _zeros(lib.iris_conv0_dweight_len(cin, cout), torch.float64, dev)
         dgamma = torch.empty(cout, dtype=torch.float32, device=dev)
         dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
@@ -691,7 +750,7 @@ class _FusedConv0BNReLU(torch.autograd.Function):
                                                     sums.data_ptr(), dw64.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream),
                     "iris_conv0_bn_relu_backward")
         dw = dw64.view(-1, cout, cin, 3, 3).sum(0).to(torch.float32).contiguous(memory_format=ctx.weight_format)
-        dbias = torch.zeros(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        dbias = _zeros(cout, torch.float32, dev) if ctx.has_bias else None
         return None, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
@@ -794,7 +853,7 @@ class _ConvBNReLU(nn.Sequential):
             conv, bn = self[0], self[1]
             if x.dtype == torch.float32 and conv.out_channels % 4 == 0 and bn.track_running_stats and bn.momentum is not None:
                 if FUSED_CONV0 and pool is None and _is_first_layer_conv(conv, x):
-                    bn.num_batches_tracked.add_(1)  # the model's first layer: convolution recomputed inside the passes
+                    _count_batch(bn)  # the model's first layer: convolution recomputed inside the passes
                     return _FusedConv0BNReLU.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                                    bn.running_var, bn.eps, bn.momentum)
                 wino = _wino_train_conv(conv, x)
@@ -803,7 +862,7 @@ class _ConvBNReLU(nn.Sequential):
                 else:
                     z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
                 if z.is_contiguous(memory_format=torch.channels_last):
-                    bn.num_batches_tracked.add_(1)
+                    _count_batch(bn)
                     fold = FUSED_BN_POOL and _is_pool_2x2_same(pool)
                     y = _FusedBiasBNReLU.apply(z, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                                bn.eps, bn.momentum, fold)
@@ -851,7 +910,7 @@ class FullyConnectedLayer(nn.Module):
             z = torch.nn.functional.linear(x, self.fc.weight)                # [B, T, C]
             z4 = z.permute(0, 2, 1).unsqueeze(-1)                             # [B, C, T, 1]: a channels_last view of the same memory
             if z4.is_contiguous(memory_format=torch.channels_last):
-                bn.num_batches_tracked.add_(1)
+                _count_batch(bn)
                 y4 = _FusedBiasBNReLU.apply(z4, self.fc.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                             bn.momentum, False)
                 return y4.squeeze(-1).permute(0, 2, 1)
@@ -945,6 +1004,16 @@ class CustomModel(nn.Module):
 
     def forward(self, x):
         """x: [B, n_mels, n_frame, n_chan] (the reference's channels-last input)."""
+        global _NBT_PENDING
+        outer, _NBT_PENDING = _NBT_PENDING, []
+        try:
+            return self._forward(x)
+        finally:
+            pending, _NBT_PENDING = _NBT_PENDING, outer
+            if pending:
+                torch._foreach_add_(pending, 1)
+
+    def _forward(self, x):
         x = x.permute(0, 3, 1, 2)  # NCHW view of the NHWC tensor (channels_last strides)
         x = self.features(x)       # [B, C, M', T']
         x = x.permute(0, 3, 2, 1).flatten(2)  # [B, T', M' * C], m' major as Keras Permute+Reshape
@@ -978,6 +1047,8 @@ class CustomModel(nn.Module):
         # zeroed buffer (84 elementwise launches and the zero fills fewer per step); FusedAGC keeps one table per recurring
         # address set of the gradient buffers, so nothing is re-uploaded in steady state
         self.optimizer.zero_grad(set_to_none=True)
+        if x.is_cuda and ZERO_POOL:
+            _ZERO_POOL.begin_step(x.device)
         y_pred = self._call(x)
         loss = self.loss_fn(y, y_pred)
         mark('forward')
@@ -1805,6 +1876,8 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             model.train()
+            if ZERO_POOL:
+                _ZERO_POOL.begin_step(x.device)
             loss = model.loss_fn(self.y, model._call(self.x))
             loss.backward()
             if model.use_agc:
@@ -1836,22 +1909,47 @@ class GraphedTrainStep:
 _PLAN_CHECK_ON_CPU = False  # test hook (tests/test_ddp_gloo.py): consult the frontend plans' status for a CPU-resident loss too
 
 
+GRAPH_STEP = os.environ.get("IRIS_GRAPH_STEP", "0") == "1"
+
+
 def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=None, validation_steps=16,
         scheduler=None, csv_path=None, checkpoint_path=None, patience=None, rank=0, world=1, verbose=True,
-        swa=None):
+        swa=None, graph: Optional[bool] = None):
     """Minimal Keras-fit equivalent for this path: per-epoch LR schedule, CSV log,
-    best-val-loss checkpoint, early stopping, TerminateOnNaN (sj_train.py:489-519)."""
+    best-val-loss checkpoint, early stopping, TerminateOnNaN (sj_train.py:489-519).
+    `graph` (default: IRIS_GRAPH_STEP=1): run the training step as ONE replayed hipGraph (GraphedTrainStep) - single GPU
+    without DDP, a capturable optimiser (make_optimizer(..., capturable=True)), batches of one shape; a batch of another
+    shape (a ragged last one) takes the eager step.  The step then costs what its kernels cost (10.4 ms per batch of 64)
+    however slow the host is at launching ~330 kernels."""
     best, bad, history = math.inf, 0, []
     coll = collectives_on(world)  # world > 1, or a forced process group at world 1 (IRIS_FORCE_PG=1)
     it = iter(train_set)
+    graph = GRAPH_STEP if graph is None else bool(graph)
+    graph = graph and model._ddp is None and all(g.get('capturable', False) for g in model.optimizer.param_groups)
+    gstep = None
+
+    def one_step(data):
+        nonlocal gstep
+        x, y = data
+        if not (graph and x.is_cuda):
+            return model.train_step(data)
+        if gstep is None:
+            gstep = GraphedTrainStep(model, data)   # its warm-up steps train on this batch
+        if x.shape == gstep.x.shape and y.shape == gstep.y.shape and x.dtype == gstep.x.dtype:
+            return gstep(data)
+        return model.train_step(data)
+
     for epoch in range(epochs):
         if scheduler is not None:
             lr = scheduler(epoch)
             for g in model.optimizer.param_groups:
-                g['lr'] = lr
+                if torch.is_tensor(g['lr']):
+                    g['lr'].fill_(float(lr))   # capturable optimiser: the rate lives in a device tensor (a graph reads it)
+                else:
+                    g['lr'] = lr
         t0, losses = time.time(), []
         for _ in range(steps_per_epoch):
-            losses.append(model.train_step(next(it))['loss'])
+            losses.append(one_step(next(it))['loss'].clone() if graph else one_step(next(it))['loss'])
         loss = torch.stack(losses).mean()
         # The one place per epoch where the frontend plans' status words are read for certain (the hot path also reports a
         # failed earlier launch at the plan's next call, without a sync): EpilogueTimeout naming the plan instead of training
@@ -1872,7 +1970,7 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
                                                      "log epilogue (NaN features); stopping with them")
         if plan_failure is not None:
             raise plan_failure
-        row = {'epoch': epoch, 'loss': float(loss), 'lr': model.optimizer.param_groups[0]['lr'],
+        row = {'epoch': epoch, 'loss': float(loss), 'lr': float(model.optimizer.param_groups[0]['lr']),
                'time': time.time() - t0}
         if coll:
             average_bn_statistics(model, world)
@@ -1931,7 +2029,9 @@ def main(argv=None):
         print(config)
     NAME = run_name(config)
     model = get_model(config).to(device).to(memory_format=torch.channels_last)
-    opt = make_optimizer(config, model.parameters())
+    # IRIS_GRAPH_STEP=1 (one GPU, Adam): the step as one replayed hipGraph - the optimiser then keeps its rate on the device
+    opt = make_optimizer(config, model.parameters(),
+                         capturable=GRAPH_STEP and world == 1 and device.type == 'cuda' and config.optimizer == 'adam')
     loss = binary_crossentropy if config.loss == 'BCE' else \
         (lambda yt, yp: sigmoid_focal_crossentropy(yt, yp).mean())
     model.compile(opt, loss, clipvalue=None if config.no_clipvalue_after_agc else config.clipvalue,
