@@ -1041,7 +1041,8 @@ class CustomModel(nn.Module):
         `_mark(name)` (bench hook) is called after each phase: 'forward', 'backward', 'agc_clip', 'optimizer'."""
         mark = _mark or (lambda name: None)
         x, y = data
-        self.train()
+        if not self.training:   # (Module.train() walks every submodule: 0.4 ms of host time per step when nothing changes)
+            self.train()
         self.bump_generation()
         # the gradients are dropped, not zeroed: AccumulateGrad then takes each incoming gradient instead of adding it to a
         # zeroed buffer (84 elementwise launches and the zero fills fewer per step); FusedAGC keeps one table per recurring

@@ -21,6 +21,11 @@ timeout -k 10 300 python3 scripts/gpu_c4prof.py 10 > $OUT/c4.pre.log 2>&1; tail 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -o c4 -- python3 scripts/gpu_c4prof.py 10 > $OUT/c4.log 2>&1; grep "train step" $OUT/c4.log
 python3 scripts/trace_steps.py $OUT/c4/c4_kernel_trace.csv k_wav_to_mel 6 $OUT/c4_step_kernel_stats.csv
 find $OUT/c4 -name "*kernel_trace.csv" -delete
+# the Winograd weight gradient: microbenchmark against MIOpen on the step's shapes, and the step with / without it (eager, graphed)
+timeout -k 10 300 python3 scripts/gpu_wino_wrw_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/wino_wrw_microbench.log; tail -10 $OUT/wino_wrw_microbench.log
+for v in 0 1 0 1; do
+  echo "IRIS_WINO_TRAIN_WRW=$v:"; IRIS_WINO_TRAIN_WRW=$v timeout -k 10 200 python3 scripts/gpu_graph_train.py 30 2>&1 | grep -v amdgpu.ids | tail -2
+done > $OUT/c4_wino_wrw_ab.log 2>&1; cat $OUT/c4_wino_wrw_ab.log
 # RCCL at world size 1: the bench line with the forced process group, and a kernel trace of DDP steps
 IRIS_FORCE_PG=1 timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --extra-steps 10 --no-cpu-baseline > $OUT/bench_rccl_world1.json 2> $OUT/bench_rccl_world1.err; echo "rccl bench rc $?"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rccl_w1 -o rccl_w1 -- python3 scripts/gpu_rccl_world1.py > $OUT/rccl_world1_trace.log 2>&1; echo "rccl trace rc $?"; grep "^{" $OUT/rccl_world1_trace.log

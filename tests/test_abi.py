@@ -312,7 +312,7 @@ def test_winograd_kernel_hand_set_waits_match_its_requests(device_asm):
 def test_winograd_weight_gradient_kernel_fits_two_waves_per_simd(device_asm):
     """k_wino_wrw (csrc/k_conv_wino_wrw.h) hides memory latency with TWO waves per SIMD: workgroups of 512 threads need at most
     256 registers per lane (vector + accumulation), no scratch; its transform is written as packed adds (11 v_pk_add_f32 per
-    tile and position half) and the hot block of a tile holds exactly 8 MFMAs and 16 loads."""
+    tile and position half) and a tile costs 8 MFMAs and 10 loads."""
     import re
     text = open(device_asm).read()
     m = re.search(r"\.amdhsa_kernel _Z10k_wino_wrwILi2EEvPKfS1_Pfiiiiii\s(.*?)\.end_amdhsa_kernel", text, re.S)
@@ -330,9 +330,13 @@ def test_winograd_weight_gradient_kernel_fits_two_waves_per_simd(device_asm):
         elif t and not t.startswith(";"):
             cur.append(t)
     blocks.append(cur)
-    hot = [b for b in blocks if sum(t.startswith("v_mfma_f32_32x32x2") for t in b) == 8 and sum(t.startswith("buffer_load_dword ") for t in b) == 16]
-    assert len(hot) >= 4, len(hot)      # both position halves, several slots of the unrolled ring
-    assert body.count("v_pk_add_f32") >= 2 * 11
+    n_mfma = [sum(t.startswith("v_mfma_f32_32x32x2") for t in b) for b in blocks]
+    n_load = [sum(t.startswith("buffer_load_dword ") for t in b) for b in blocks]
+    # both position halves x the four slots of the unrolled load ring: a tile = 8 MFMAs, and 6 + 4 loads (a lane keeps the
+    # column transform of the two patch columns it shares with its next tile; only the first tile of a row loads 6 more)
+    assert sum(n == 8 for n in n_mfma) >= 8 and set(n_mfma) <= {0, 8}, sorted(set(n_mfma))
+    assert sum(n == 10 for n in n_load) >= 8 and sum(n == 6 for n in n_load) >= 8, sorted(set(n_load))
+    assert body.count("v_pk_add_f32") >= 2 * 9
 
 
 def test_winograd_weight_gradient_argument_checks():
