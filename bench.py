@@ -295,7 +295,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                 ci, co, big = m.in_channels, m.out_channels, max(m.in_channels, m.out_channels)
                 fwd = S.WINO_TRAIN and ci % 8 == 0 and co % 64 == 0 and big >= S.WINO_TRAIN_MIN_C_FWD
                 bwd = S.WINO_TRAIN and co % 8 == 0 and ci % 64 == 0 and big >= S.WINO_TRAIN_MIN_C_BWD
-                wrw = S.WINO_TRAIN_WRW and ci % 32 == 0 and co % 64 == 0
+                wrw = S.WINO_TRAIN_WRW and ci % 32 == 0 and co % 32 == 0
                 train_flops += (f / 2.25 if fwd else f) + (f / 2.25 if bwd else f) + (f / 2.25 if wrw else f)
         if isinstance(getattr(blk, "pool", None), torch.nn.MaxPool2d):
             hw = (-(-hw[0] // 2), -(-hw[1] // 2))

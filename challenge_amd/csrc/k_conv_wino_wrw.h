@@ -75,14 +75,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wrw_row_rsrc(const float* base
 // PH = the wave's position half: positions 8 PH .. 8 PH + 7 = rows 2 PH, 2 PH + 1 of the 4 x 4 transforms, which read the patch
 // rows PH .. PH + 2 only.  Per tile pair a wave issues 8 MFMAs, 16 loads, 11 packed adds and 6 offset increments; the row
 // bookkeeping (five row descriptors) runs once per tile row under a uniform branch.
-template <int PH, int NW>
+template <int PH, int MW, int NW>
 __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
                                               int B, int H, int W, int Cin, int Cout, int n_split, int wm, int wn) {
     constexpr int D = IRIS_WINO_WRW_DEPTH;
     const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;  // channel of the wave's 32, tile parity
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1, hn = (TW + 1) >> 1;  // tiles per half-wave and tile row
     const int n_rows = B * TH;
-    const int cin_blocks = Cin / (32 * NW), n_bp = cin_blocks * (Cout >> 6), total = n_bp * n_split;
+    const int cin_blocks = Cin / (32 * NW), n_bp = cin_blocks * (Cout / (32 * MW)), total = n_bp * n_split;
     // workgroups of one XCD (blockIdx mod 8) take neighbouring work: the same tile rows for different channel blocks
     int wk = blockIdx.x;
     if ((total & 7) == 0) wk = (wk & 7) * (total >> 3) + (wk >> 3);
@@ -102,7 +102,7 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
 #pragma unroll
         for (int c = 0; c < 4; ++c) col[c] = (unsigned)(2 * tw0 - 1 + c) * xpix + (unsigned)(ib * 32 * NW + 32 * wn + li) * 4u;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) dcol[j] = (unsigned)(2 * tw0 + j) * dpix + (unsigned)(cb * 64 + 32 * wm + li) * 4u;
+        for (int j = 0; j < 2; ++j) dcol[j] = (unsigned)(2 * tw0 + j) * dpix + (unsigned)(cb * 32 * MW + 32 * wm + li) * 4u;
     };
     __amdgpu_buffer_rsrc_t rxr[3], rdr[2];
     int ld_j = 0, ld_R = R_lo, ld_b = R_lo / TH, ld_th = R_lo - (R_lo / TH) * TH;
@@ -216,7 +216,7 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
         }
     }
     // partial dU' of this split: [split][p][cout][cin]; D register r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
-    float* const out = part + ((size_t)split * 16 + 8 * PH) * Cout * Cin + (size_t)(cb * 64 + 32 * wm + 4 * kh) * Cin + (ib * 32 * NW + 32 * wn + li);
+    float* const out = part + ((size_t)split * 16 + 8 * PH) * Cout * Cin + (size_t)(cb * 32 * MW + 32 * wm + 4 * kh) * Cin + (ib * 32 * NW + 32 * wn + li);
 #pragma unroll
     for (int p = 0; p < 8; ++p)
 #pragma unroll
@@ -224,16 +224,18 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
             out[(size_t)p * Cout * Cin + (size_t)((r & 3) + 8 * (r >> 2)) * Cin] = acc[p][r];
 }
 
-// NW = 2: 8 waves, a 64 x 64 block (cin % 64 == 0).  NW = 1: 4 waves, 64 cout x 32 cin (cin % 32 == 0: the 32 -> 64 layer); two such
-// workgroups share a CU, so every SIMD still holds two waves
-template <int NW>
-__global__ __launch_bounds__(256 * NW, 2) void k_wino_wrw(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
-                                                          int B, int H, int W, int Cin, int Cout, int n_split) {
+// MW x NW = halves of 32 output / input channels of a workgroup's block: 2 x 2 = 8 waves, 64 x 64 (cout % 64 == 0, cin % 64 == 0);
+// 2 x 1 (1 x 2) = 4 waves, 64 cout x 32 cin (the 32 -> 64 layer) or 32 x 64; 1 x 1 = 2 waves, 32 x 32 (block 1's 32 -> 32 layer).  Several of
+// the smaller workgroups share a CU, so every SIMD still holds two waves.
+template <int MW, int NW>
+__global__ __launch_bounds__(128 * MW * NW, 2) void k_wino_wrw(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ part, int B, int H, int W, int Cin, int Cout, int n_split) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // waves w and w + 2 NW share a SIMD (round-robin placement): the same channels, the two position halves - their loads of
-    // the shared patch rows hit the same lines
-    if (wv < 2 * NW) wino_wrw_wave<0, NW>(x, dy, part, B, H, W, Cin, Cout, n_split, wv & 1, (wv >> 1) & (NW - 1));
-    else wino_wrw_wave<1, NW>(x, dy, part, B, H, W, Cin, Cout, n_split, wv & 1, (wv >> 1) & (NW - 1));
+    // waves w and w + MW NW share a SIMD (round-robin placement) where the workgroup has 8: the same channels, the two position
+    // halves - their loads of the shared patch rows hit the same lines
+    const int q = wv % (MW * NW);
+    if (wv < MW * NW) wino_wrw_wave<0, MW, NW>(x, dy, part, B, H, W, Cin, Cout, n_split, q % MW, q / MW);
+    else wino_wrw_wave<1, MW, NW>(x, dy, part, B, H, W, Cin, Cout, n_split, q % MW, q / MW);
 }
 
 // First stage of the sum over many splits (layers with few channel blocks: 256 splits of a 64 x 64 layer), in place: split g < G
@@ -291,16 +293,17 @@ __global__ __launch_bounds__(4 * CB) void k_wino_wrw_reduce(const float* __restr
 
 // workgroups of 64 cout x (64 or 32) cin; as many splits of the tile rows as fill every SIMD with two waves
 static int wino_wrw_cin_block(int cin) { return (cin % 64) ? 32 : 64; }
+static int wino_wrw_cout_block(int cout) { return (cout % 64) ? 32 : 64; }
 static size_t wino_wrw_splits(int batch, int height, int cin, int cout, int n_cu) {
-    const int cbk = wino_wrw_cin_block(cin), want = n_cu * (64 / cbk);
-    const int n_bp = (cin / cbk) * (cout / 64), n_rows = batch * ((height + 1) / 2);
+    const int cbk = wino_wrw_cin_block(cin), obk = wino_wrw_cout_block(cout), want = n_cu * (64 / cbk) * (64 / obk);
+    const int n_bp = (cin / cbk) * (cout / obk), n_rows = batch * ((height + 1) / 2);
     return (size_t)std::max(1, std::min(n_rows, want / std::max(1, std::min(n_bp, want))));
 }
 
 // floats of workspace iris_conv3x3_wino_wrw needs for this geometry (partial sums of the tile-row splits)
 extern "C" size_t iris_wino_wrw_workspace_len(int batch, int height, int width, int cin, int cout) {
     (void)width;
-    if (batch <= 0 || height <= 0 || cin <= 0 || cout <= 0 || (cin % 32) || (cout % 64)) return 0;
+    if (batch <= 0 || height <= 0 || cin <= 0 || cout <= 0 || (cin % 32) || (cout % 32)) return 0;
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     return wino_wrw_splits(batch, height, cin, cout, n_cu) * 16 * (size_t)cin * cout;
@@ -314,20 +317,23 @@ extern "C" int iris_conv3x3_wino_wrw(const float* x, const float* dy, float* dw,
                                      float* workspace, size_t workspace_len, void* stream) {
     if (!x || !dy || !dw || !workspace) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_wrw: NULL argument");
     if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_wrw: empty tensor");
-    if (cin <= 0 || cout <= 0 || (cin % 32) || (cout % 64))
-        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_wrw: cin %d must be a multiple of 32, cout %d of 64", cin, cout);
+    if (cin <= 0 || cout <= 0 || (cin % 32) || (cout % 32))
+        return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_wrw: cin %d and cout %d must be multiples of 32", cin, cout);
     if ((long long)batch * height * width * std::max(cin, cout) * 4 >= 2147483648LL)
         return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_wino_wrw: tensor of 2^31 bytes or more");
     int dev = 0, n_cu = 256;
     HIP_TRY(hipGetDevice(&dev));
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const size_t n_split = wino_wrw_splits(batch, height, cin, cout, n_cu);
-    const int cbk = wino_wrw_cin_block(cin), n_bp = (cin / cbk) * (cout / 64);
+    const int cbk = wino_wrw_cin_block(cin), obk = wino_wrw_cout_block(cout), n_bp = (cin / cbk) * (cout / obk);
     if (workspace_len < n_split * 16 * (size_t)cin * cout)
         return fail(IRIS_E_INVALID, "iris_conv3x3_wino_wrw: workspace of %zu floats, %zu needed", workspace_len, n_split * 16 * (size_t)cin * cout);
     const hipStream_t st = (hipStream_t)stream;
-    if (cbk == 64) k_wino_wrw<2><<<(unsigned)(n_bp * n_split), 512, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
-    else k_wino_wrw<1><<<(unsigned)(n_bp * n_split), 256, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
+    const unsigned grid = (unsigned)(n_bp * n_split);
+    if (obk == 64 && cbk == 64) k_wino_wrw<2, 2><<<grid, 512, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
+    else if (obk == 64) k_wino_wrw<2, 1><<<grid, 256, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
+    else if (cbk == 64) k_wino_wrw<1, 2><<<grid, 256, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
+    else k_wino_wrw<1, 1><<<grid, 128, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
     HIP_TRY(hipGetLastError());
     int n_left = (int)n_split;
     if (n_left > 16) {

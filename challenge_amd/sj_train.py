@@ -777,7 +777,7 @@ def _is_first_layer_conv(conv, x) -> bool:
 WINO_TRAIN = os.environ.get("IRIS_WINO_TRAIN", "1") != "0"
 WINO_TRAIN_MIN_C_FWD = int(os.environ.get("IRIS_WINO_TRAIN_MIN_C_FWD", "64"))
 WINO_TRAIN_MIN_C_BWD = int(os.environ.get("IRIS_WINO_TRAIN_MIN_C_BWD", "64"))
-# the weight gradient of the same layers as Winograd on the fp32 MFMA too (k_conv_wino_wrw.h; cin % 32 == 0, cout % 64 == 0):
+# the weight gradient of the same layers as Winograd on the fp32 MFMA too (k_conv_wino_wrw.h; channel counts multiples of 32):
 # 1.5-1.7x MIOpen's weight-gradient kernels on the step's shapes, deterministic; IRIS_WINO_TRAIN_WRW=0 keeps MIOpen's
 WINO_TRAIN_WRW = WINO_TRAIN and os.environ.get("IRIS_WINO_TRAIN_WRW", "1") != "0"
 
@@ -833,7 +833,7 @@ def _wino_train_conv(conv: nn.Conv2d, x: torch.Tensor):
     ci, co, big = conv.in_channels, conv.out_channels, max(conv.in_channels, conv.out_channels)
     fwd = ci % 8 == 0 and co % 64 == 0 and big >= WINO_TRAIN_MIN_C_FWD
     bwd = co % 8 == 0 and ci % 64 == 0 and big >= WINO_TRAIN_MIN_C_BWD
-    wrw = WINO_TRAIN_WRW and ci % 32 == 0 and co % 64 == 0 and x.shape[0] * x.shape[2] * x.shape[3] * big < (1 << 29)
+    wrw = WINO_TRAIN_WRW and ci % 32 == 0 and co % 32 == 0 and x.shape[0] * x.shape[2] * x.shape[3] * big < (1 << 29)
     return (fwd, bwd, wrw) if (fwd or bwd or wrw) else None
 
 

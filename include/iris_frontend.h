@@ -383,7 +383,7 @@ int iris_conv3x3_wino(const float* x, const float* packed, const float* bias, fl
  * 16 instead of 36 multiplies per 2 x 2 tile and channel pair.  Both free dimensions of that GEMM are channels, so with
  * channels-last activations a lane loads its channel's patch straight from memory into the MFMA operand layout (no LDS).
  * Deterministic (the tile rows are split over workgroups whose partial sums are added in a fixed order); against an fp64
- * gradient the error is that of a direct fp32 one (2e-7 .. 6e-7 of the gradient's peak).  cin % 32 == 0, cout % 64 == 0.
+ * gradient the error is that of a direct fp32 one (2e-7 .. 6e-7 of the gradient's peak).  cin % 32 == 0, cout % 32 == 0.
  *   x, dy      channels-last [batch][height][width][cin] / [...][cout], DEVICE, fewer than 2^31 bytes each
  *   dw         the gradient, element strides stride_o / _i / _h / _w over [cout][cin][3][3] (a channels_last parameter's
  *              gradient is written as it lies); accumulate != 0 adds to what is there

@@ -315,11 +315,11 @@ def test_winograd_weight_gradient_kernel_fits_two_waves_per_simd(device_asm):
     tile and position half) and a tile costs 8 MFMAs and 10 loads."""
     import re
     text = open(device_asm).read()
-    m = re.search(r"\.amdhsa_kernel _Z10k_wino_wrwILi2EEvPKfS1_Pfiiiiii\s(.*?)\.end_amdhsa_kernel", text, re.S)
+    m = re.search(r"\.amdhsa_kernel _Z10k_wino_wrwILi2ELi2EEvPKfS1_Pfiiiiii\s(.*?)\.end_amdhsa_kernel", text, re.S)
     assert m
     assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(1)).group(1)) == 0
     assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(1)).group(1)) <= 256
-    body = text.split("\n_Z10k_wino_wrwILi2EEvPKfS1_Pfiiiiii:", 1)[1].split("s_endpgm")[0]
+    body = text.split("\n_Z10k_wino_wrwILi2ELi2EEvPKfS1_Pfiiiiii:", 1)[1].split("s_endpgm")[0]
     assert not re.search(r"\bscratch_", body)
     blocks, cur = [], []
     for ln in body.split("\n"):
@@ -350,7 +350,7 @@ def test_winograd_weight_gradient_argument_checks():
     assert lib.iris_conv3x3_wino_wrw(None, p, p, 1, 1, 1, 1, 1, 4, 4, 64, 64, 0, p, 16, None) == -1
     assert lib.iris_conv3x3_wino_wrw(p, p, p, 1, 1, 1, 1, 0, 4, 4, 64, 64, 0, p, 16, None) == -1
     assert lib.iris_conv3x3_wino_wrw(p, p, p, 1, 1, 1, 1, 1, 4, 4, 16, 64, 0, p, 16, None) == -2
-    assert lib.iris_conv3x3_wino_wrw(p, p, p, 1, 1, 1, 1, 1, 4, 4, 64, 96, 0, p, 16, None) == -2
+    assert lib.iris_conv3x3_wino_wrw(p, p, p, 1, 1, 1, 1, 1, 4, 4, 64, 48, 0, p, 16, None) == -2
     assert lib.iris_conv3x3_wino_wrw(p, p, p, 1, 1, 1, 1, 4096, 64, 64, 64, 64, 0, p, 16, None) == -2   # 2^32 bytes
 
 
