@@ -1920,8 +1920,8 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
     best-val-loss checkpoint, early stopping, TerminateOnNaN (sj_train.py:489-519).
     `graph` (default: IRIS_GRAPH_STEP=1): run the training step as ONE replayed hipGraph (GraphedTrainStep) - single GPU
     without DDP, a capturable optimiser (make_optimizer(..., capturable=True)), batches of one shape; a batch of another
-    shape (a ragged last one) takes the eager step.  The step then costs what its kernels cost (10.4 ms per batch of 64)
-    however slow the host is at launching ~330 kernels."""
+    shape (a ragged last one) takes the eager step.  The step then costs what its kernels cost (10.05 ms per batch of 64)
+    however slow the host is at launching ~260 kernels."""
     best, bad, history = math.inf, 0, []
     coll = collectives_on(world)  # world > 1, or a forced process group at world 1 (IRIS_FORCE_PG=1)
     it = iter(train_set)
