@@ -25,7 +25,8 @@
 #ifndef IRIS_WINO_WRW_DEPTH
 #define IRIS_WINO_WRW_DEPTH 4   // tiles in flight per lane: a tile's loads are issued DEPTH batches ahead of its transform
 #endif
-// timing experiments only (results wrong when non-zero): 1 no loads in the loop, 2 no transform
+// timing experiments only (results wrong when non-zero): 1 no loads in the loop, 2 no transform, 4 every tile row reads image rows 0-3 of
+// image 0 (the loads stay, their data comes from the L2), 8 no partial stores
 #ifndef IRIS_WRW_ABLATE
 #define IRIS_WRW_ABLATE 0
 #endif
@@ -50,6 +51,9 @@ WRW_PK(wrw_sumdiff, "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]")                
 // whole patch
 #ifndef IRIS_WRW_SLIDE
 #define IRIS_WRW_SLIDE 1
+#endif
+#ifndef IRIS_WRW_INTERLEAVE
+#define IRIS_WRW_INTERLEAVE 1
 #endif
 struct WrwRaw {
     wrw_f2 x[3][2];   // the three patch rows this wave's position half needs x (columns 0 1, columns 2 3)
@@ -77,15 +81,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wrw_row_rsrc(const float* base
 // bookkeeping (five row descriptors) runs once per tile row under a uniform branch.
 template <int PH, int MW, int NW>
 __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
-                                              int B, int H, int W, int Cin, int Cout, int n_split, int wm, int wn) {
+                                              int B, int H, int W, int Cin, int Cout, int n_split, int wm, int wn, int wk) {
     constexpr int D = IRIS_WINO_WRW_DEPTH;
     const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;  // channel of the wave's 32, tile parity
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1, hn = (TW + 1) >> 1;  // tiles per half-wave and tile row
     const int n_rows = B * TH;
-    const int cin_blocks = Cin / (32 * NW), n_bp = cin_blocks * (Cout / (32 * MW)), total = n_bp * n_split;
-    // workgroups of one XCD (blockIdx mod 8) take neighbouring work: the same tile rows for different channel blocks
-    int wk = blockIdx.x;
-    if ((total & 7) == 0) wk = (wk & 7) * (total >> 3) + (wk >> 3);
+    const int cin_blocks = Cin / (32 * NW), n_bp = cin_blocks * (Cout / (32 * MW));
     const int split = wk / n_bp, bp = wk - split * n_bp;
     const int cb = bp / cin_blocks, ib = bp - cb * cin_blocks;
     const int R_lo = (int)(((long long)n_rows * split) / n_split), R_hi = (int)(((long long)n_rows * (split + 1)) / n_split);
@@ -112,18 +113,18 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
         for (int r = 0; r < 3; ++r) {
             const int hh = 2 * ld_th - 1 + PH + r;
             const int ok = live & ((unsigned)hh < (unsigned)H);
-            rxr[r] = wrw_row_rsrc(x, ok ? (long long)(ld_b * H + hh) * W * Cin : 0, ok ? xrow_bytes : 0);
+            rxr[r] = wrw_row_rsrc(x, ok ? (long long)(WRW_ABL(4) ? r : ld_b * H + hh) * W * Cin : 0, ok ? xrow_bytes : 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int hh = 2 * ld_th + i;
             const int ok = live & (hh < H);
-            rdr[i] = wrw_row_rsrc(dy, ok ? (long long)(ld_b * H + hh) * W * Cout : 0, ok ? drow_bytes : 0);
+            rdr[i] = wrw_row_rsrc(dy, ok ? (long long)(WRW_ABL(4) ? i : ld_b * H + hh) * W * Cout : 0, ok ? drow_bytes : 0);
         }
     };
     set_cols();
     set_rows();
-    auto issue = [&](WrwRaw& raw) {
+    auto issue_first = [&](WrwRaw& raw) {   // the two left patch columns: only for the first tile of a tile row
         raw.first = !IRIS_WRW_SLIDE || ld_j == 0;
         if (raw.first) {   // uniform
 #pragma unroll
@@ -131,6 +132,8 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
 #pragma unroll
                 for (int c = 0; c < 2; ++c) raw.x[r][0][c] = wrw_ld(rxr[r], col[c]);
         }
+    };
+    auto issue_loads = [&](WrwRaw& raw) {   // 6 + 4 loads, no control flow: they share a basic block with the tile's MFMAs
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -139,6 +142,8 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) raw.d[i][j] = wrw_ld(rdr[i], dcol[j]);
+    };
+    auto advance = [&]() {
         if (++ld_j == hn) {   // uniform: next tile row
             ld_j = 0;
             ++ld_R;
@@ -154,6 +159,11 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
 #pragma unroll
             for (int j = 0; j < 2; ++j) dcol[j] += 2u * dpix;
         }
+    };
+    auto issue = [&](WrwRaw& raw) {
+        issue_first(raw);
+        issue_loads(raw);
+        advance();
     };
     // rows 2 PH, 2 PH + 1 of V = B^T d B and of dM' = |A| dY |A|^T (see the header for the signs): 8 + 8 values, as pairs
     // V[i][0] = (V_i0, V_i1), V[i][1] = (V_i2, V_i3); M likewise
@@ -209,10 +219,20 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
 #pragma unroll
         for (int q = 0; q < D; ++q) {   // tile it + q: transform, reload its registers with tile it + q + D, 8 MFMAs
             if (!WRW_ABL(2) || it == 0) xform(raw[q], V, M);
-            if (!WRW_ABL(1)) issue(raw[q]);
+            if (!WRW_ABL(1)) issue_first(raw[q]);
+            if (!WRW_ABL(1)) issue_loads(raw[q]);
 #pragma unroll
             for (int p = 0; p < 8; ++p)
                 acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(M[p >> 2][(p >> 1) & 1][p & 1], V[p >> 2][(p >> 1) & 1][p & 1], acc[p], 0, 0, 0);
+#if IRIS_WRW_INTERLEAVE
+            // the tile's loads spread between its MFMAs instead of in one burst in front of them
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            }
+#endif
+            if (!WRW_ABL(1)) advance();
         }
     }
     // partial dU' of this split: [split][p][cout][cin]; D register r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
@@ -221,21 +241,30 @@ __device__ __forceinline__ void wino_wrw_wave(const float* __restrict__ x, const
     for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            out[(size_t)p * Cout * Cin + (size_t)((r & 3) + 8 * (r >> 2)) * Cin] = acc[p][r];
+            if (!WRW_ABL(8) || acc[p][r] == 12345.f) out[(size_t)p * Cout * Cin + (size_t)((r & 3) + 8 * (r >> 2)) * Cin] = acc[p][r];
 }
 
 // MW x NW = halves of 32 output / input channels of a workgroup's block: 2 x 2 = 8 waves, 64 x 64 (cout % 64 == 0, cin % 64 == 0);
 // 2 x 1 (1 x 2) = 4 waves, 64 cout x 32 cin (the 32 -> 64 layer) or 32 x 64; 1 x 1 = 2 waves, 32 x 32 (block 1's 32 -> 32 layer).  Several of
 // the smaller workgroups share a CU, so every SIMD still holds two waves.
 template <int MW, int NW>
-__global__ __launch_bounds__(128 * MW * NW, 2) void k_wino_wrw(const float* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ part, int B, int H, int W, int Cin, int Cout, int n_split) {
+__global__ __launch_bounds__(512, 2) void k_wino_wrw(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     float* __restrict__ part, int B, int H, int W, int Cin, int Cout, int n_split) {
+    // Always 8 waves = two per SIMD: 4 / (MW NW) blocks of the decomposition share a workgroup (2-wave workgroups of their own
+    // were placed unevenly over the SIMDs: a bare MFMA loop ran at 3/4 of its rate).  Waves w and w + 4 share a SIMD
+    // (round-robin placement): the same block and channels, the two position halves - their loads of the shared patch rows
+    // hit the same lines.
+    constexpr int kGroups = 4 / (MW * NW);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // waves w and w + MW NW share a SIMD (round-robin placement) where the workgroup has 8: the same channels, the two position
-    // halves - their loads of the shared patch rows hit the same lines
-    const int q = wv % (MW * NW);
-    if (wv < MW * NW) wino_wrw_wave<0, MW, NW>(x, dy, part, B, H, W, Cin, Cout, n_split, q % MW, q / MW);
-    else wino_wrw_wave<1, MW, NW>(x, dy, part, B, H, W, Cin, Cout, n_split, q % MW, q / MW);
+    const int lg = (wv & 3) / (MW * NW), q = (wv & 3) % (MW * NW);
+    const int total = (Cin / (32 * NW)) * (Cout / (32 * MW)) * n_split;
+    // workgroups of one XCD (blockIdx mod 8) take neighbouring work: the same tile rows for different channel blocks
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
+    const int wk = wg * kGroups + lg;
+    if (wk >= total) return;   // (no barrier anywhere in the kernel)
+    if ((wv >> 2) == 0) wino_wrw_wave<0, MW, NW>(x, dy, part, B, H, W, Cin, Cout, n_split, q % MW, q / MW, wk);
+    else wino_wrw_wave<1, MW, NW>(x, dy, part, B, H, W, Cin, Cout, n_split, q % MW, q / MW, wk);
 }
 
 // First stage of the sum over many splits (layers with few channel blocks: 256 splits of a 64 x 64 layer), in place: split g < G
@@ -329,11 +358,12 @@ extern "C" int iris_conv3x3_wino_wrw(const float* x, const float* dy, float* dw,
     if (workspace_len < n_split * 16 * (size_t)cin * cout)
         return fail(IRIS_E_INVALID, "iris_conv3x3_wino_wrw: workspace of %zu floats, %zu needed", workspace_len, n_split * 16 * (size_t)cin * cout);
     const hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)(n_bp * n_split);
+    const unsigned groups = 4u / ((unsigned)(obk / 32) * (unsigned)(cbk / 32));   // blocks of the decomposition per 8-wave workgroup
+    const unsigned grid = ((unsigned)(n_bp * n_split) + groups - 1) / groups;
     if (obk == 64 && cbk == 64) k_wino_wrw<2, 2><<<grid, 512, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
-    else if (obk == 64) k_wino_wrw<2, 1><<<grid, 256, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
-    else if (cbk == 64) k_wino_wrw<1, 2><<<grid, 256, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
-    else k_wino_wrw<1, 1><<<grid, 128, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
+    else if (obk == 64) k_wino_wrw<2, 1><<<grid, 512, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
+    else if (cbk == 64) k_wino_wrw<1, 2><<<grid, 512, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
+    else k_wino_wrw<1, 1><<<grid, 512, 0, st>>>(x, dy, workspace, batch, height, width, cin, cout, (int)n_split);
     HIP_TRY(hipGetLastError());
     int n_left = (int)n_split;
     if (n_left > 16) {

@@ -172,13 +172,25 @@ def _rccl_world1_worker(rank, port, out_dir):
     # (3) Five full training steps (AGC + clipvalue + Adam on the reduced gradients): Adam's normalised update turns every
     # flipped decision into a parameter difference of the order of the learning rate, between two PLAIN runs already - the
     # DDP run must stay within what plain runs differ by among themselves
+    # (With the Winograd weight gradient - deterministic, unlike MIOpen's atomics - plain runs of this small model repeat bit
+    # for bit, while a DDP run still differs from them in last bits (its gradients pass through bucket views), and one flipped
+    # decision is a difference of the order of the learning rate.  The scale of that chaos is therefore calibrated on plain runs
+    # that include two with MIOpen's weight gradient: a legitimate last-bit perturbation of the same step.)
     ddp_model = fresh(True)
     tables = run(ddp_model)
-    plains = [fresh(False) for _ in range(3)]
+    plains = [fresh(False) for _ in range(2)]
     for m in plains:
         run(m)
+    wrw_default = S.WINO_TRAIN_WRW
+    try:
+        S.WINO_TRAIN_WRW = False
+        for _ in range(2):
+            plains.append(fresh(False))
+            run(plains[-1])
+    finally:
+        S.WINO_TRAIN_WRW = wrw_default
     ps = [_state(m) for m in plains]
-    self_drift = max(_max_rel_diff(ps[i], ps[j])[0] for i in range(3) for j in range(i))
+    self_drift = max(_max_rel_diff(ps[i], ps[j])[0] for i in range(len(ps)) for j in range(i))
     drift, where = min(_max_rel_diff(_state(ddp_model), p_) for p_ in ps)
     assert drift <= max(1e-6, 4.0 * self_drift), (drift, where, self_drift)
     assert tables[-1] == tables[2] and tables[-1] <= 2, tables  # FusedAGC: no new table after the first steps
