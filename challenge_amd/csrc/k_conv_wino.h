@@ -101,7 +101,7 @@ struct WinoWave {
 // TC: tile columns of a workgroup's block (64 / TC tile rows): min(ceil(W / 2), 64) rounded up to a power of two
 // in_nhwc: x is channels-last [B][H][W][Cin] (a chunk of a pixel = 32 bytes at a stride of Cin x 4: every gather touches 64
 // cache lines instead of 16 - 14 % slower over the CRNN's layers, what a training pass pays for keeping its activations where
-// MIOpen's weight-gradient kernels read them); relu == 0 and bias == nullptr: the bare convolution (training: BatchNorm follows)
+// the weight-gradient kernel (k_conv_wino_wrw.h: lane = channel) reads them); relu == 0 and bias == nullptr: the bare convolution (training: BatchNorm follows)
 template <bool POOL, int TC, bool IN_NHWC>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict__ x, const float* __restrict__ u,
                                                          const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,

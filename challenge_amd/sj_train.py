@@ -768,8 +768,8 @@ def _is_first_layer_conv(conv, x) -> bool:
 
 
 # Training: the bare 3x3 convolutions of blocks 2-5 - forward and backward-data - as Winograd F(2x2, 3x3) on the fp32 matrix
-# cores (iris_conv3x3_wino) instead of MIOpen's implicit GEMMs, reading and writing channels_last where MIOpen's weight-gradient
-# kernel keeps reading it (that layout costs the kernel 14 % against its own chunked one).  Wherever the kernel's shape rule
+# cores (iris_conv3x3_wino) instead of MIOpen's implicit GEMMs, reading and writing channels_last where the weight-gradient
+# kernel and the BatchNorm passes read it (that layout costs the kernel 14 % against its own chunked one).  Wherever the kernel's shape rule
 # holds (8 | input channels, 64 | output channels - per direction, the backward-data pass swaps them) and the wider side has
 # >= 64 channels: every layer of blocks 2-5 forward, all but block 2's first backward.  Thresholds per direction by environment
 # (the measured step is flat within noise between 64 and 128: profiles/r5/c4_wino_train_ab.log); IRIS_WINO_TRAIN=0 keeps MIOpen
@@ -778,7 +778,7 @@ WINO_TRAIN = os.environ.get("IRIS_WINO_TRAIN", "1") != "0"
 WINO_TRAIN_MIN_C_FWD = int(os.environ.get("IRIS_WINO_TRAIN_MIN_C_FWD", "64"))
 WINO_TRAIN_MIN_C_BWD = int(os.environ.get("IRIS_WINO_TRAIN_MIN_C_BWD", "64"))
 # the weight gradient of the same layers as Winograd on the fp32 MFMA too (k_conv_wino_wrw.h; channel counts multiples of 32):
-# 1.5-1.7x MIOpen's weight-gradient kernels on the step's shapes, deterministic; IRIS_WINO_TRAIN_WRW=0 keeps MIOpen's
+# 1.6-2.0x MIOpen's weight-gradient kernels on the step's shapes, deterministic; IRIS_WINO_TRAIN_WRW=0 keeps MIOpen's
 WINO_TRAIN_WRW = WINO_TRAIN and os.environ.get("IRIS_WINO_TRAIN_WRW", "1") != "0"
 
 
