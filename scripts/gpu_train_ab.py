@@ -16,8 +16,8 @@ src = S.synthetic_wave_sources(2, 3, 256, n_bg=16, n_voice=64, n_noise=32, seed=
 
 
 def run(fused: bool):
-    for name in ("FUSED_BN_RELU", "FUSED_BN_POOL", "FUSED_CONV0", "FUSED_LSTM", "FUSED_FC_BN"):
-        setattr(S, name, fused)
+    for name in ("FUSED_BN_RELU", "FUSED_BN_POOL", "FUSED_CONV0", "FUSED_LSTM", "FUSED_FC_BN", "WINO_TRAIN", "WINO_TRAIN_WRW", "ZERO_POOL"):
+        setattr(S, name, fused)   # (round 5: the Winograd convolutions - forward, backward-data, weight gradient - and the zero pool too)
     model = copy.deepcopy(base)
     model.compile(S.make_optimizer(cfg, model.parameters()), S.binary_crossentropy, clipvalue=cfg.clipvalue)
     data = iter(S.make_wave_dataset(cfg, True, sources=src, device=dev, seed=7, n_fft=1024, hop=256))
@@ -30,6 +30,8 @@ def run(fused: bool):
 
 
 a, b = run(True), run(False)
+a2 = run(True)
+print("HIP passes, second run bit-identical to the first:", a2 == a)
 print("step      " + " ".join(f"{i * 10:7d}" for i in range(len(a))))
 print("HIP passes" + " ".join(f"{v:7.4f}" for v in a))
 print("stock ops " + " ".join(f"{v:7.4f}" for v in b))
