@@ -1837,12 +1837,15 @@ class GraphedTrainStep:
         opt = make_optimizer(config, model.parameters(), capturable=True)      # learning rate held in a device tensor
         model.compile(opt, loss, clipvalue=...)
         step = GraphedTrainStep(model, (x, y))                                   # 3 eager warm-up steps (they train), then the capture
+                                                                                 # (preserve_state=True: the warm-up leaves no trace)
         for x, y in data: loss = step((x, y))['loss']                            # inputs are copied into the static buffers
         step.set_lr(value)                                                       # schedulers write the tensor
 
     MIOpen must already know its kernels for these shapes (the warm-up steps see to that).  Not under DDP."""
 
-    def __init__(self, model: "CustomModel", example, warmup: int = 3):
+    def __init__(self, model: "CustomModel", example, warmup: int = 3, preserve_state: bool = False):
+        """`preserve_state`: parameters, buffers and the optimiser's state are put back after the warm-up steps, so that the
+        first replay is the FIRST update the example batch causes (what `fit` wants: one update per batch, as the reference)."""
         x, y = example
         if not x.is_cuda:
             raise RuntimeError("GraphedTrainStep: a GPU tensor is required (hipGraph capture; no CPU fallback)")
@@ -1852,6 +1855,12 @@ class GraphedTrainStep:
         if not all(g.get('capturable', False) for g in opt.param_groups):
             raise ValueError("GraphedTrainStep: the optimiser must be capturable - make_optimizer(config, params, capturable=True)")
         self.model, self.x, self.y = model, x.clone(), y.clone()
+        saved = None
+        if preserve_state:
+            tensors = list(model.parameters()) + list(model.buffers())
+            saved = ([t.detach().clone() for t in tensors], tensors,
+                     {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in opt.state.get(p, {}).items()}
+                      for g in opt.param_groups for p in g['params']})
         # `warmup` eager steps in all (they train the model): all but the last on the current stream - without them the
         # capture was invalidated on this stack (some first-use initialisation that a side stream alone does not trigger) -
         # and the last one on a side stream, as torch's capture recipe asks
@@ -1866,6 +1875,18 @@ class GraphedTrainStep:
         torch.cuda.synchronize(x.device)
         object.__setattr__(model, '_fused_agc', None)  # its table holds the eager gradients' addresses
         opt.zero_grad(set_to_none=True)
+        if saved is not None:   # undo the warm-up in place (the graph will be captured on these very tensors)
+            with torch.no_grad():
+                for t, old in zip(saved[1], saved[0]):
+                    t.copy_(old)
+                for g in opt.param_groups:
+                    for p in g['params']:
+                        before, now = saved[2][id(p)], opt.state.get(p, {})
+                        for k, v in now.items():
+                            if torch.is_tensor(v):   # moments and the step count: back to their old values, or to a fresh 0
+                                v.copy_(before[k]) if k in before else v.zero_()
+            model.bump_generation()
+            torch.cuda.synchronize(x.device)
         # The captured AGC launch reads a table whose pinned staging buffer is the source of a captured copy node: this
         # object owns both for as long as the graph lives, and the model's own `_fused_agc` stays None - an eager
         # `model.train_step` later (e.g. a ragged last batch) builds a SEPARATE FusedAGC instead of rebuilding - and
@@ -1910,7 +1931,9 @@ class GraphedTrainStep:
 _PLAN_CHECK_ON_CPU = False  # test hook (tests/test_ddp_gloo.py): consult the frontend plans' status for a CPU-resident loss too
 
 
-GRAPH_STEP = os.environ.get("IRIS_GRAPH_STEP", "0") == "1"
+# fit / main run the training step as ONE replayed hipGraph wherever that is possible (one GPU without DDP, Adam, batches of one
+# shape): the step then costs what its kernels cost however slow the host is at launching ~260 of them.  IRIS_GRAPH_STEP=0: eager.
+GRAPH_STEP = os.environ.get("IRIS_GRAPH_STEP", "1") != "0"
 
 
 def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=None, validation_steps=16,
@@ -1918,7 +1941,7 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
         swa=None, graph: Optional[bool] = None):
     """Minimal Keras-fit equivalent for this path: per-epoch LR schedule, CSV log,
     best-val-loss checkpoint, early stopping, TerminateOnNaN (sj_train.py:489-519).
-    `graph` (default: IRIS_GRAPH_STEP=1): run the training step as ONE replayed hipGraph (GraphedTrainStep) - single GPU
+    `graph` (default: on, IRIS_GRAPH_STEP=0 switches it off): run the training step as ONE replayed hipGraph (GraphedTrainStep) - single GPU
     without DDP, a capturable optimiser (make_optimizer(..., capturable=True)), batches of one shape; a batch of another
     shape (a ragged last one) takes the eager step.  The step then costs what its kernels cost (10.05 ms per batch of 64)
     however slow the host is at launching ~260 kernels."""
@@ -1935,8 +1958,13 @@ def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=
         if not (graph and x.is_cuda):
             return model.train_step(data)
         if gstep is None:
-            gstep = GraphedTrainStep(model, data)   # its warm-up steps train on this batch
-        if x.shape == gstep.x.shape and y.shape == gstep.y.shape and x.dtype == gstep.x.dtype:
+            try:   # the warm-up steps run on this batch and are undone: the first replay is its first update
+                gstep = GraphedTrainStep(model, data, preserve_state=True)
+            except Exception as exc:   # a capture that fails must not take the training run down: eager from here on
+                if verbose and rank == 0:
+                    print(f"fit: the training step could not be captured as a hipGraph ({exc!r:.200}); running it eagerly")
+                gstep = False
+        if gstep and x.shape == gstep.x.shape and y.shape == gstep.y.shape and x.dtype == gstep.x.dtype:
             return gstep(data)
         return model.train_step(data)
 
@@ -2030,7 +2058,7 @@ def main(argv=None):
         print(config)
     NAME = run_name(config)
     model = get_model(config).to(device).to(memory_format=torch.channels_last)
-    # IRIS_GRAPH_STEP=1 (one GPU, Adam): the step as one replayed hipGraph - the optimiser then keeps its rate on the device
+    # one GPU, Adam (and not IRIS_GRAPH_STEP=0): the step as one replayed hipGraph - the optimiser then keeps its rate on the device
     opt = make_optimizer(config, model.parameters(),
                          capturable=GRAPH_STEP and world == 1 and device.type == 'cuda' and config.optimizer == 'adam')
     loss = binary_crossentropy if config.loss == 'BCE' else \

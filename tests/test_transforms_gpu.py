@@ -656,9 +656,10 @@ def test_sj_train_main_two_epochs(dev, tmp_path, monkeypatch):
     with open(tmp_path / 'pywave_vad_v9_lr0.001_batch8_opt_adam_mel32_chan2_BCE_framelen128.csv') as f:
         rows = list(csv.DictReader(f))
     assert len(rows) == 1 and math.isfinite(float(rows[0]['loss'])) and math.isfinite(float(rows[0]['val_loss']))
-    # ... and with the training step as one replayed hipGraph (IRIS_GRAPH_STEP=1: fit builds a GraphedTrainStep on the first
-    # batch, the scheduler writes the learning rate into the optimiser's device tensor)
-    monkeypatch.setattr(S, 'GRAPH_STEP', True)
+    # (the runs above trained on a replayed hipGraph - the default on one GPU with Adam: fit builds a GraphedTrainStep on the first
+    # batch, the scheduler writes the learning rate into the optimiser's device tensor.)  The same with IRIS_GRAPH_STEP=0: eager
+    assert S.GRAPH_STEP
+    monkeypatch.setattr(S, 'GRAPH_STEP', False)
     S.main(['--synthetic', '--epochs', '3', '--steps_per_epoch', '4', '--validation_steps', '1', '--batch_size', '8',
             '--n_frame', '128', '--v', '9', '--n_mels', '32', '--name', 'pygraph'])
     with open(tmp_path / 'pygraph_vad_v9_lr0.001_batch8_opt_adam_mel32_chan2_BCE_framelen128.csv') as f:
@@ -666,7 +667,7 @@ def test_sj_train_main_two_epochs(dev, tmp_path, monkeypatch):
     assert [int(r['epoch']) for r in rows] == [0, 1, 2]
     assert all(math.isfinite(float(r['loss'])) and math.isfinite(float(r['val_loss'])) for r in rows)
     lrs = [float(r['lr']) for r in rows]
-    assert lrs[0] > 0 and len(set(lrs)) == 3          # custom_scheduler's per-epoch rate reached the captured optimiser
+    assert lrs[0] > 0 and len(set(lrs)) == 3          # custom_scheduler's per-epoch rate
     assert all(0.0 < float(r['loss']) < 2.0 for r in rows)   # (rate 0.008 on 12 random batches: the loss wanders, it must not blow up)
 
 
@@ -1292,6 +1293,44 @@ def test_hip_bilstm_training_matches_torch(dev):
     # no autograd: the plain launch
     with torch.no_grad():
         assert float((S.bilstm128(lstm, x) - ref(x)[0]).abs().max()) <= 2e-6
+
+
+def test_fit_on_a_hipgraph_trains_as_the_eager_fit(dev):
+    """sj_train.fit with the step as one replayed hipGraph (the default on one GPU with a capturable Adam) against fit with
+    graph=False from the same initial state and the same batches: the warm-up steps GraphedTrainStep needs are undone
+    (preserve_state), so every batch causes exactly one update - after 2 epochs x 3 steps the two models hold the same
+    parameters, BatchNorm statistics and batch counters (the step is bit-reproducible with the Winograd passes; a warm-up that
+    left a trace would show as differences of the order of the learning rate), and the CSV rows carry the scheduler's rates."""
+    import copy
+    from challenge_amd import sj_train as S
+    S.configure_miopen()
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '32', '--n_frame', '64', '--n_chan', '1', '--batch_size', '8'])
+    g = torch.Generator().manual_seed(5)
+    batches = [(torch.rand(8, 32, 64, 1, generator=g).to(dev), (torch.rand(8, 2, 3, generator=g) < 0.2).float().to(dev)) for _ in range(6)]
+
+    def forever():
+        i = 0
+        while True:
+            yield batches[i % len(batches)]
+            i += 1
+    torch.manual_seed(1)
+    base = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    out = []
+    for graph in (True, False):
+        m = copy.deepcopy(base)
+        m.compile(S.make_optimizer(cfg, m.parameters(), capturable=True), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+        S.fit(m, forever(), epochs=2, steps_per_epoch=3, scheduler=S.custom_scheduler(4096, 2 / 12, 2), verbose=False, graph=graph)
+        torch.cuda.synchronize()
+        out.append(({n: p.detach().clone() for n, p in m.named_parameters()}, {n: b.detach().clone() for n, b in m.named_buffers()}))
+    (pg, bg), (pe, be) = out
+    assert any(not torch.equal(pg[n], p) for n, p in base.named_parameters())          # it trained
+    worst = max((float((pg[n] - pe[n]).abs().max()) / (float(pe[n].abs().max()) + 1e-12), n) for n in pe)
+    assert worst[0] <= 1e-5, worst
+    for n in be:
+        if be[n].dtype.is_floating_point:
+            assert float((bg[n] - be[n]).abs().max()) <= 1e-5 * float(be[n].abs().max()) + 1e-7, n
+        else:
+            assert torch.equal(bg[n], be[n]), n           # num_batches_tracked: 6 batches, not 6 + warm-up
 
 
 def test_graphed_train_step_equals_eager(dev):
