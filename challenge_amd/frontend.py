@@ -365,7 +365,7 @@ class CapturedStep:
             self.out = plan.wav_to_logmel(wav, out=out, **kwargs)
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             plan.wav_to_logmel(wav, out=self.out, **kwargs)
 
     def replay(self) -> torch.Tensor:

@@ -1453,7 +1453,7 @@ class InferenceEngine:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             feats = fe.plan.wav_to_logmel(self.wav, minmax=fe.do_minmax, log=True, t_bands=self._tb, f_bands=self._fb)
             self.out = self.model(feats)
 
@@ -1896,7 +1896,9 @@ class GraphedTrainStep:
             self._agc.reserve()
             torch.cuda.synchronize(x.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # (thread_local: another thread's harmless queries - RCCL's watchdog polling the events of earlier collectives when a
+        # process group is alive in this process - must not invalidate the capture, nor be killed by it)
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             model.train()
             if ZERO_POOL:
                 _ZERO_POOL.begin_step(x.device)
