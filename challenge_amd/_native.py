@@ -59,6 +59,7 @@ SIGNATURES = {
     "iris_bn_relu_pool_bwd_reduce": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_pool_bwd_dx": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "iris_conv3x3_c32_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "iris_conv3x3_c32": (_i, [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _vp, _i, _i, _i, _vp]),
     "iris_wino_packed_len": (_sz, [_i, _i]),
     "iris_wino_pack_weights": (_i, [_vp, _i, _i, _vp]),
     "iris_wino_pack_weights_device": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _vp, _vp]),

@@ -64,10 +64,13 @@ __device__ __forceinline__ void c32_groups(float (&abuf)[2][8], const float (&br
 }
 
 // CHUNKED: y in the channel-chunked layout [B][4][Ho][Wo][8] the Winograd layers read (k_conv_wino.h) instead of channels-last
-template <bool POOL, bool CHUNKED = false>
+// RAW: the bare convolution of a TRAINING pass (BatchNorm follows: no bias, no ReLU), channels-last out, the weight read with its
+// own element strides (so / si / sh / sw over [cout][cin][3][3]: a channels_last parameter as it is) and, with `transposed`, as
+// the backward-data pass needs it: W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]
+template <bool POOL, bool CHUNKED = false, bool RAW = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int H,
-                                                        int W) {
+                                                        int W, long so = 0, long si = 0, long sh = 0, long sw = 0, int transposed = 0) {
     extern __shared__ float halo[];  // [6][66][33 (+ row padding)]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hl = lane >> 5, i = lane & 31;
@@ -76,10 +79,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int cp = 0; cp < 16; ++cp) breg[tap][cp] = w[((size_t)i * kC32 + 2 * cp + hl) * 9 + tap];
+        for (int cp = 0; cp < 16; ++cp) {
+            if constexpr (RAW) {   // output channel i, input channel 2 cp + hl, tap (ky, kx) of the convolution being computed
+                const int c = 2 * cp + hl, ky = tap / 3, kx = tap % 3;
+                breg[tap][cp] = transposed ? w[(long)c * so + (long)i * si + (long)(2 - ky) * sh + (long)(2 - kx) * sw]
+                                           : w[(long)i * so + (long)c * si + (long)ky * sh + (long)kx * sw];
+            } else {
+                breg[tap][cp] = w[((size_t)i * kC32 + 2 * cp + hl) * 9 + tap];
+            }
+        }
     // this lane's pixel inside a 2 x 16 patch: MFMA row i = 4 (col >> 1) + 2 row + (col & 1)
     const int pr = (i >> 1) & 1, pc = 2 * (i >> 2) + (i & 1);
-    const float bj = bias[i];  // output channel j = lane & 31 of every accumulator register
+    const float bj = RAW ? 0.f : bias[i];  // output channel j = lane & 31 of every accumulator register
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const int tiles_w = (W + kC32TileW - 1) / kC32TileW, tiles_h = (H + kC32TileH - 1) / kC32TileH;
     const int n_tiles = B * tiles_h * tiles_w;
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
                     const int orow = h0 + 2 * t + ((row_i >> 1) & 1), ocol = w0 + 16 * wv + 2 * (row_i >> 2) + (row_i & 1);
                     if (orow < H && ocol < W)
                         y[CHUNKED ? ((((size_t)b * 4 + (i >> 3)) * H + orow) * W + ocol) * 8 + (i & 7)
-                                  : (((size_t)b * H + orow) * W + ocol) * kC32 + i] = fmaxf(acc[r] + bj, 0.f);
+                                  : (((size_t)b * H + orow) * W + ocol) * kC32 + i] = RAW ? acc[r] : fmaxf(acc[r] + bj, 0.f);
                 }
             } else {
                 const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
@@ -155,6 +166,31 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
             }
         }
     }
+}
+
+// The bare 32 -> 32 convolution for the training step (forward: transposed = 0; backward-data on dz: transposed = 1), y and x
+// channels-last [B, H, W, 32], the weight [32, 32, 3, 3] with element strides
+extern "C" int iris_conv3x3_c32(const float* x, const float* weight, long stride_o, long stride_i, long stride_h, long stride_w,
+                                int transposed, float* y, int batch, int height, int width, void* stream) {
+    if (!x || !weight || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_c32: NULL argument");
+    if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_c32: empty tensor");
+    if ((reinterpret_cast<uintptr_t>(x) & 15)) return fail(IRIS_E_INVALID, "iris_conv3x3_c32: x must be 16-byte aligned");
+    int dev = 0, n_cu = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    static std::atomic<unsigned> attr_set[64];
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c32<false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC32LdsBytes));
+        if (dev >= 0 && dev < 64) attr_set[dev].store(1u, std::memory_order_release);
+    }
+    const long long n_tiles = (long long)((width + kC32TileW - 1) / kC32TileW) * ((height + kC32TileH - 1) / kC32TileH) * batch;
+    if (n_tiles >= 2147483647LL) return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_c32: too many tiles");
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+    const unsigned grid = (unsigned)std::min<long long>(n_tiles, 2LL * n_cu);
+    k_conv3x3_c32<false, false, true><<<grid, 256, kC32LdsBytes, (hipStream_t)stream>>>(x, weight, nullptr, y, batch, height, width, stride_o,
+                                                                                         stride_i, stride_h, stride_w, transposed);
+    HIP_TRY(hipGetLastError());
+    return IRIS_OK;
 }
 
 extern "C" int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, const float* bias, float* y, int batch, int height,

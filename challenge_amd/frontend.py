@@ -483,6 +483,23 @@ def conv3x3_c32_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Ten
     return y
 
 
+def conv3x3_c32(x: torch.Tensor, weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """The bare conv2d(x, weight, padding=1) of a 32 -> 32 layer on the fp32 matrix cores (iris_conv3x3_c32: the inference
+    kernel without bias / ReLU) for a channels_last [B, 32, H, W] input and a [32, 32, 3, 3] weight in any dense layout;
+    `transposed`: the backward-data pass, conv2d(x, weight.flip(2, 3).transpose(0, 1), padding=1) with x = dz."""
+    if (x.dim() != 4 or x.shape[1] != 32 or not x.is_contiguous(memory_format=torch.channels_last) or not x.is_cuda
+            or x.dtype != torch.float32 or tuple(weight.shape) != (32, 32, 3, 3) or weight.dtype != torch.float32):
+        raise ValueError("conv3x3_c32: x must be a float32 channels_last device tensor [B, 32, H, W], weight a float32 [32, 32, 3, 3]")
+    b, _, h, w = (int(v) for v in x.shape)
+    y = torch.empty((b, 32, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    so, si, sh, sw = (int(v) for v in weight.stride())
+    with torch.cuda.device(x.device):
+        rc = N.lib().iris_conv3x3_c32(x.data_ptr(), weight.data_ptr(), so, si, sh, sw, 1 if transposed else 0, y.data_ptr(), b, h, w,
+                                      _stream_ptr(x.device))
+    N.check(rc, "iris_conv3x3_c32")
+    return y
+
+
 def wino_pack_weights(weight: torch.Tensor) -> torch.Tensor:
     """U = G g G^T of a [Cout, Cin, 3, 3] convolution weight in the Winograd kernel's LDS order (iris_wino_pack_weights, on the
     host, once per layer); returns a device tensor of 16 Cin Cout floats on the weight's device."""

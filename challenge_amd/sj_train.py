@@ -780,21 +780,28 @@ WINO_TRAIN_MIN_C_BWD = int(os.environ.get("IRIS_WINO_TRAIN_MIN_C_BWD", "64"))
 # the weight gradient of the same layers as Winograd on the fp32 MFMA too (k_conv_wino_wrw.h; channel counts multiples of 32):
 # 1.6-2.0x MIOpen's weight-gradient kernels on the step's shapes, deterministic; IRIS_WINO_TRAIN_WRW=0 keeps MIOpen's
 WINO_TRAIN_WRW = WINO_TRAIN and os.environ.get("IRIS_WINO_TRAIN_WRW", "1") != "0"
+# block 1's 32 -> 32 layer: forward and backward-data by the inference engine's implicit-GEMM kernel (k_conv_c32.h) without
+# bias / ReLU instead of CK's / MIOpen's kernels (431 + ~470 us per step); IRIS_C32_TRAIN=0 keeps those
+C32_TRAIN = WINO_TRAIN and os.environ.get("IRIS_C32_TRAIN", "1") != "0"
 
 
 class _WinoConv3x3(torch.autograd.Function):
     """z = conv2d(x, weight, padding=1) for channels_last fp32 tensors.  forward (`fwd`): iris_conv3x3_wino on the weights packed
     on the device this step, else MIOpen; backward: dx (`bwd`) by the same kernel on the transposed / flipped weights, else
-    MIOpen; dW (`wrw`) by iris_conv3x3_wino_wrw, else MIOpen's weight-gradient kernel (aten.convolution_backward)."""
+    MIOpen; dW (`wrw`) by iris_conv3x3_wino_wrw, else MIOpen's weight-gradient kernel (aten.convolution_backward).
+    `fwd` / `bwd` == 'c32': the 32 -> 32 layer of block 1 - forward and backward-data by the implicit-GEMM kernel of the
+    inference engine without its bias / ReLU (iris_conv3x3_c32; the backward pass reads the weight transposed and flipped)."""
 
     @staticmethod
     def forward(ctx, x, weight, fwd=True, bwd=True, wrw=False):
-        if fwd:
+        if fwd == 'c32':
+            z = _fe.conv3x3_c32(x, weight)
+        elif fwd:
             z = _fe.conv3x3_wino(x, _fe.wino_pack_weights_device(weight), None, int(weight.shape[0]), out_nhwc=True, relu=False)
         else:
             z = torch.nn.functional.conv2d(x, weight, None, 1, 1)
         ctx.save_for_backward(x, weight)
-        ctx.wino_bwd = bool(bwd)
+        ctx.wino_bwd = bwd if bwd == 'c32' else bool(bwd)
         ctx.wino_wrw = bool(wrw)
         return z
 
@@ -806,7 +813,9 @@ class _WinoConv3x3(torch.autograd.Function):
             dz = dz.contiguous(memory_format=torch.channels_last)
         dx = dw = None
         wino_dx = ctx.needs_input_grad[0] and ctx.wino_bwd
-        if wino_dx:
+        if wino_dx and ctx.wino_bwd == 'c32':
+            dx = _fe.conv3x3_c32(dz, weight, transposed=True)
+        elif wino_dx:
             dx = _fe.conv3x3_wino(dz, _fe.wino_pack_weights_device(weight, transposed=True), None, cin, out_nhwc=True, relu=False)
         wino_dw = ctx.needs_input_grad[1] and ctx.wino_wrw
         if wino_dw:
@@ -834,6 +843,8 @@ def _wino_train_conv(conv: nn.Conv2d, x: torch.Tensor):
     fwd = ci % 8 == 0 and co % 64 == 0 and big >= WINO_TRAIN_MIN_C_FWD
     bwd = co % 8 == 0 and ci % 64 == 0 and big >= WINO_TRAIN_MIN_C_BWD
     wrw = WINO_TRAIN_WRW and ci % 32 == 0 and co % 32 == 0 and x.shape[0] * x.shape[2] * x.shape[3] * big < (1 << 29)
+    if C32_TRAIN and ci == 32 and co == 32:   # block 1's second layer: the inference engine's fp32-MFMA kernel, bare
+        fwd = bwd = 'c32'
     return (fwd, bwd, wrw) if (fwd or bwd or wrw) else None
 
 

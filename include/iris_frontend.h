@@ -347,6 +347,12 @@ int iris_bn_relu_pool_bwd_dx(const float* z, const float* dp, float* dz, int bat
  */
 int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, const float* bias, float* y, int batch, int height, int width,
                                int pool, int out_chunked, void* stream);
+/* The same kernel as the bare convolution of a TRAINING pass (BatchNorm follows: no bias, no ReLU, no pooling): y = conv3x3_same(x, w)
+ * with transposed == 0 (forward) or y = conv3x3_same(x, w') with w'[ci][co][ky][kx] = w[co][ci][2 - ky][2 - kx] (transposed != 0:
+ * the backward-data pass, x = dz).  x, y channels-last [batch, height, width, 32]; weight [32, 32, 3, 3] with element strides
+ * stride_o / _i / _h / _w (a channels_last parameter as it is). */
+int iris_conv3x3_c32(const float* x, const float* weight, long stride_o, long stride_i, long stride_h, long stride_w, int transposed,
+                     float* y, int batch, int height, int width, void* stream);
 
 /*
  * Conv2D(cin -> cout, 3x3 'same', stride 1) as a Winograd F(2x2, 3x3) transform on the fp32 matrix cores: 16 instead of 36

@@ -1167,7 +1167,7 @@ def test_winograd_convolution_matches_fp64(dev, b, h, w, cin, cout):
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout", [(4, 8, 64, 128, 256), (3, 8, 64, 256, 256), (5, 4, 32, 256, 512), (2, 4, 32, 512, 512),
-                                            (3, 5, 9, 64, 128), (2, 6, 10, 24, 64), (2, 6, 10, 32, 64), (2, 6, 10, 32, 32)])
+                                            (3, 5, 9, 64, 128), (2, 6, 10, 24, 64), (2, 6, 10, 32, 64), (2, 6, 10, 32, 32), (3, 9, 70, 32, 32)])
 def test_winograd_training_convolution_matches_torch(dev, b, h, w, cin, cout):
     """The training step's deep convolutions (sj_train._WinoConv3x3): forward z = conv(x, W) and backward-data dx by the
     Winograd kernel on channels_last tensors with the weights packed on the device (plain and transposed / flipped), dW by
@@ -1189,7 +1189,8 @@ def test_winograd_training_convolution_matches_torch(dev, b, h, w, cin, cout):
         flipped = wt.detach().flip(2, 3).transpose(0, 1).contiguous()
         assert float((FE.wino_pack_weights_device(wt.detach(), transposed=True) - FE.wino_pack_weights(flipped)).abs().max()) <= 4e-7 * wmax
     wrw = cin % 32 == 0 and cout % 32 == 0
-    z = S._WinoConv3x3.apply(x, wt, cout % 64 == 0, cout % 8 == 0 and cin % 64 == 0, wrw)   # (32 -> 32: only dW is Winograd)
+    c32 = 'c32' if (cin, cout) == (32, 32) else None   # 32 -> 32: forward / backward-data by the bare implicit-GEMM kernel
+    z = S._WinoConv3x3.apply(x, wt, c32 or cout % 64 == 0, c32 or (cout % 8 == 0 and cin % 64 == 0), wrw)
     assert z.is_contiguous(memory_format=torch.channels_last)
     dz = torch.randn(z.shape, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
     z.backward(dz)
