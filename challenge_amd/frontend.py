@@ -580,7 +580,8 @@ def _wrw_workspace(device: torch.device, floats: int) -> torch.Tensor:
 def conv3x3_wino_wrw(x: torch.Tensor, dy: torch.Tensor, like: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The weight gradient of z = conv2d(x, weight, padding=1) given dy = dL/dz, as Winograd F(2x2, 3x3) on the fp32 matrix
     cores (iris_conv3x3_wino_wrw).  x [B, Cin, H, W] and dy [B, Cout, H, W]: channels_last float32 device tensors, Cin and
-    Cout multiples of 32.  Returns dW [Cout, Cin, 3, 3] with the strides of `like` (the weight) or channels_last."""
+    Cout multiples of 32.  Returns dW [Cout, Cin, 3, 3] with the strides of `like` (the weight) or channels_last.
+    The partial sums go through ONE scratch buffer per device: calls on different streams of a device must not overlap."""
     if not (x.is_cuda and x.dtype == torch.float32 and dy.dtype == torch.float32 and dy.device == x.device):
         raise ValueError("conv3x3_wino_wrw: x and dy must be float32 tensors on one device (no CPU fallback)")
     if not (x.dim() == 4 and dy.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
