@@ -581,7 +581,7 @@ def _is_pool_2x2_same(pool):
 class _ZeroPool:
     """Zero-initialised device scratch for the fused passes (the shifted sums of the BatchNorm passes, the first layer's
     weight-gradient copies, the identically-zero bias gradients): `take` hands out slices of one buffer per dtype and
-    `begin_step` re-zeroes what the previous step used with ONE fill per dtype - 58 fill launches per training step fewer
+    `begin_step` re-zeroes what the previous step used with ONE fill per buffer (three) - 55 fill launches per training step fewer
     (profiles/r5/c4_step_kernel_stats.csv).  Outside a step `take` keeps handing out untouched zeros and falls back to
     torch.zeros when the buffer is exhausted.  Buffers are only ever replaced by larger ones and the old ones kept: a captured
     hipGraph (GraphedTrainStep) replays with their addresses.  A slice stays valid until the next `begin_step` on its device;
@@ -591,8 +591,10 @@ class _ZeroPool:
         self._state = {}   # (device index, dtype) -> [buffer, offset, wanted]
         self._old = []
 
-    def take(self, n: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
-        key = (device.index, dtype)
+    def take(self, n: int, dtype: torch.dtype, device: torch.device, kind: str = "scratch") -> torch.Tensor:
+        """`kind`: 'scratch' - sums the kernels accumulate into; 'grad' - identically-zero gradients handed to autograd.  The two
+        never share a buffer: a gradient a model still holds cannot be overwritten by another model's sums (only re-zeroed)."""
+        key = (device.index, dtype, kind)
         st = self._state.get(key)
         step = -(-n // 8) * 8   # 32- / 64-byte granules: every slice 16-byte aligned
         if st is None:
@@ -605,7 +607,7 @@ class _ZeroPool:
         return out
 
     def begin_step(self, device: torch.device) -> None:
-        for (index, dtype), st in self._state.items():
+        for (index, dtype, _kind), st in self._state.items():
             if index != device.index:
                 continue
             if st[0] is None or st[2] > st[0].numel():   # the last step wanted more than there is: grow (already zero)
@@ -633,8 +635,8 @@ _ZERO_POOL = _ZeroPool()
 ZERO_POOL = os.environ.get("IRIS_ZERO_POOL", "1") != "0"
 
 
-def _zeros(n: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
-    return _ZERO_POOL.take(int(n), dtype, device) if ZERO_POOL else torch.zeros(int(n), dtype=dtype, device=device)
+def _zeros(n: int, dtype: torch.dtype, device: torch.device, kind: str = "scratch") -> torch.Tensor:
+    return _ZERO_POOL.take(int(n), dtype, device, kind) if ZERO_POOL else torch.zeros(int(n), dtype=dtype, device=device)
 
 
 class _FusedBiasBNReLU(torch.autograd.Function):
@@ -701,7 +703,7 @@ class _FusedBiasBNReLU(torch.autograd.Function):
                 N.check(lib.iris_bn_relu_bwd_reduce(z.data_ptr(), dy.data_ptr(), rows, c, *stats, stream), "iris_bn_relu_bwd_reduce")
                 N.check(lib.iris_bn_relu_bwd_dx(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, c, *stats,
                                                 dgamma.data_ptr(), dbeta.data_ptr(), stream), "iris_bn_relu_bwd_dx")
-        dbias = _zeros(c, torch.float32, dev) if ctx.has_bias else None
+        dbias = _zeros(c, torch.float32, dev, "grad") if ctx.has_bias else None
         return dz, dbias, dgamma, dbeta, None, None, None, None, None
 
 
@@ -761,7 +763,7 @@ class _FusedConv0BNReLU(torch.autograd.Function):
                                                     sums.data_ptr(), dw64.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream),
                     "iris_conv0_bn_relu_backward")
         dw = dw64.view(-1, cout, cin, 3, 3).sum(0).to(torch.float32).contiguous(memory_format=ctx.weight_format)
-        dbias = _zeros(cout, torch.float32, dev) if ctx.has_bias else None
+        dbias = _zeros(cout, torch.float32, dev, "grad") if ctx.has_bias else None
         return None, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
