@@ -1298,6 +1298,34 @@ def test_hip_bilstm_training_matches_torch(dev):
         assert float((S.bilstm128(lstm, x) - ref(x)[0]).abs().max()) <= 2e-6
 
 
+def test_training_step_is_bit_reproducible(dev):
+    """With the three convolution passes on the Winograd / implicit-GEMM kernels (no atomics in any of them; the weight
+    gradient's partial sums are added in a fixed order) the training step is a deterministic function of its inputs: two fresh
+    models from one seed, three steps each on the same batches - every parameter and every BatchNorm buffer bit-equal.  (With
+    MIOpen's convolutions the same comparison gives the discrete 1e-2 states of profiles/r5/grad_reproducibility.log.)"""
+    from challenge_amd import sj_train as S
+    S.configure_miopen()
+    assert S.WINO_TRAIN and S.WINO_TRAIN_WRW and S.C32_TRAIN
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '64', '--n_frame', '128', '--n_chan', '1', '--batch_size', '8'])
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.rand(8, 64, 128, 1, generator=g).to(dev), (torch.rand(8, 4, 3, generator=g) < 0.2).float().to(dev)) for _ in range(3)]
+    states = []
+    for _ in range(2):
+        torch.manual_seed(4)
+        m = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+        m.compile(S.make_optimizer(cfg, m.parameters()), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+        losses = [float(m.train_step(b)['loss']) for b in batches]
+        torch.cuda.synchronize()
+        states.append((losses, {n: t.detach().clone() for n, t in list(m.named_parameters()) + list(m.named_buffers())}))
+    diff = [n for n in states[0][1] if not torch.equal(states[0][1][n], states[1][1][n])]
+    if diff or states[0][0] != states[1][0]:
+        # (the BatchNorm sums are fp64 atomics: a different order can, once in ~1e5 runs, round a mean differently - that is a
+        # last-bit difference, not the 1e-2 states of atomically accumulated convolutions)
+        worst = max(float((states[0][1][n].double() - states[1][1][n].double()).abs().max()) / (float(states[1][1][n].double().abs().max()) + 1e-12)
+                    for n in diff) if diff else 0.0
+        assert worst <= 1e-5 and max(abs(a - b) for a, b in zip(*[st[0] for st in states])) <= 1e-6, (worst, diff[:5])
+
+
 def test_fit_on_a_hipgraph_trains_as_the_eager_fit(dev):
     """sj_train.fit with the step as one replayed hipGraph (the default on one GPU with a capturable Adam) against fit with
     graph=False from the same initial state and the same batches: the warm-up steps GraphedTrainStep needs are undone
