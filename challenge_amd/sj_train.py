@@ -738,6 +738,7 @@ class _FusedConv0BNReLU(torch.autograd.Function):
         ctx.has_bias = conv_bias is not None
         ctx.weight_format = (torch.channels_last if weight.is_contiguous(memory_format=torch.channels_last)
                              and not weight.is_contiguous() else torch.contiguous_format)
+        ctx.weight_strides = tuple(weight.stride())
         ctx.mark_non_differentiable(running_mean, running_var)
         return y
 
@@ -763,6 +764,10 @@ class _FusedConv0BNReLU(torch.autograd.Function):
                                                     sums.data_ptr(), dw64.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream),
                     "iris_conv0_bn_relu_backward")
         dw = dw64.view(-1, cout, cin, 3, 3).sum(0).to(torch.float32).contiguous(memory_format=ctx.weight_format)
+        if cin == 1 and tuple(dw.stride()) != ctx.weight_strides:
+            # one input channel: both memory formats are the same bytes, only the stride of the size-1 axis differs - hand the
+            # gradient back with the parameter's own strides (DDP's bucket views follow those, and warn otherwise)
+            dw = dw.as_strided(dw.shape, ctx.weight_strides)
         dbias = _zeros(cout, torch.float32, dev, "grad") if ctx.has_bias else None
         return None, dw, dbias, dgamma, dbeta, None, None, None, None
 
