@@ -43,13 +43,17 @@ def from_chunked(y, cout):
     return y.permute(0, 2, 3, 1, 4).reshape(b, h, w, cout)
 
 
-def wino(x_chunked, packed, bias, cout, pool, out_nhwc=False):
-    b, cbk, h, w, _ = x_chunked.shape
-    cin = 8 * cbk
+def wino(x_chunked, packed, bias, cout, pool, out_nhwc=False, in_nhwc=False):
+    """x_chunked: [B, C / 8, H, W, 8], or with in_nhwc a contiguous [B, H, W, C] tensor (the training step's layout)."""
+    if in_nhwc:
+        b, h, w, cin = x_chunked.shape
+    else:
+        b, cbk, h, w, _ = x_chunked.shape
+        cin = 8 * cbk
     ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
     y = torch.empty((b, ho, wo, cout) if out_nhwc else (b, cout // 8, ho, wo, 8), device=dev)
     rc = lib.iris_conv3x3_wino(x_chunked.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w,
-                               cin, cout, (1 if pool else 0) | (2 if out_nhwc else 0) | 8,
+                               cin, cout, (1 if pool else 0) | (2 if out_nhwc else 0) | (4 if in_nhwc else 0) | 8,
                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     assert rc == 0, lib.wino_last_error()
     return y
@@ -117,10 +121,13 @@ if __name__ == "__main__":
         wcl = wt.contiguous(memory_format=torch.channels_last)
         xch = to_chunked(x)
         t_w = timeit(lambda: wino(xch, pk, bias, cout, pool))
+        t_n = timeit(lambda: wino(x, pk, bias, cout, pool, out_nhwc=True, in_nhwc=True)) if not pool else float("nan")
+        t_i = timeit(lambda: wino(x, pk, bias, cout, pool, in_nhwc=True)) if not pool else float("nan")
+        t_o = timeit(lambda: wino(xch, pk, bias, cout, pool, out_nhwc=True)) if not pool else float("nan")
         t_m = timeit(lambda: torch.nn.functional.conv2d(xn, wcl, None, padding=1))
         gf = 2.0 * 64 * h * w * cin * cout * 9 / 1e9
         tot_w += t_w
         tot_m += t_m
         print(f"  {h}x{w} {cin}->{cout} pool {int(pool)}: wino {t_w:7.1f} ({gf / t_w * 1e3 / 2.25:6.1f} TF on the MFMA) | miopen conv alone {t_m:7.1f} "
-              f"({gf / t_m * 1e3:6.1f} TF) | x{t_m / t_w:.2f}", flush=True)
+              f"({gf / t_m * 1e3:6.1f} TF) | x{t_m / t_w:.2f} | channels-last in / out {t_n:7.1f} (+{100 * (t_n / t_w - 1):4.1f} %), in only +{100 * (t_i / t_w - 1):4.1f} %, out only +{100 * (t_o / t_w - 1):4.1f} %", flush=True)
     print(f"  sum of the 12 layers: wino {tot_w:.0f} us, miopen convolutions alone {tot_m:.0f} us (+ its epilogue passes in the engine)")
