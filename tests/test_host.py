@@ -598,3 +598,35 @@ def test_main_pretrain_accepts_keras_npz(tmp_path, monkeypatch):
     assert 'model' in seen
     assert np.allclose(seen['model'].td.weight.detach().cpu().numpy(), ws[[i for i, sh in enumerate(S.keras_weight_shapes(model))
                                                                       if len(sh) == 2 and sh[1] == 1024][0]].T)
+
+
+def test_zero_pool_hands_out_zeros_and_keeps_gradients_apart():
+    """sj_train._ZeroPool (host logic, CPU tensors): slices are zero and 16-byte aligned; `begin_step` re-zeroes what was used;
+    a step that wanted more than the buffer holds makes the next `begin_step` grow it (the old buffer stays alive for a captured
+    hipGraph); identically-zero gradients ('grad') never share a buffer with the sums kernels write ('scratch')."""
+    import torch
+    from challenge_amd import sj_train as S
+    pool, cpu = S._ZeroPool(), torch.device("cpu")
+    a = pool.take(10, torch.float64, cpu)                  # no buffer yet: a plain torch.zeros, the demand is recorded
+    assert a.numel() == 10 and not a.any()
+    pool.begin_step(cpu)                                   # grows to 2 x the recorded demand (at least 4096)
+    s1 = pool.take(10, torch.float64, cpu)
+    s2 = pool.take(3, torch.float64, cpu)
+    g1 = pool.take(5, torch.float32, cpu, "grad")
+    assert s1.data_ptr() % 16 == 0 and s2.data_ptr() % 16 == 0 and s2.data_ptr() - s1.data_ptr() == 16 * 8   # 10 -> 16 elements
+    assert not s1.any() and not s2.any() and not g1.any()
+    s1.fill_(7.0)
+    s2.fill_(3.0)
+    pool.begin_step(cpu)                                   # 'grad' had no buffer in the step before: it gets one now
+    t1 = pool.take(10, torch.float64, cpu)
+    assert t1.data_ptr() == s1.data_ptr() and not t1.any() and not s2.any()      # the same memory, zero again
+    g2 = pool.take(5, torch.float32, cpu, "grad")
+    scratch32 = pool.take(5, torch.float32, cpu)           # same dtype, other kind: another buffer
+    scratch32.fill_(1.0)
+    assert not g2.any() and abs(g2.data_ptr() - scratch32.data_ptr()) >= 4096 * 4 or g2.untyped_storage().data_ptr() != scratch32.untyped_storage().data_ptr()
+    big = pool.take(10000, torch.float64, cpu)             # beyond the buffer: falls back to torch.zeros for now ...
+    assert big.numel() == 10000 and not big.any() and big.untyped_storage().data_ptr() != t1.untyped_storage().data_ptr()
+    old = t1.untyped_storage().data_ptr()
+    pool.begin_step(cpu)                                   # ... and the buffer grows; the old one is kept
+    fresh = pool.take(10000, torch.float64, cpu)
+    assert fresh.untyped_storage().data_ptr() != old and not fresh.any() and len(pool._old) >= 1
