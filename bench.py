@@ -168,6 +168,17 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
             dt = float(t.item())
         return dt / n
 
+    def checker_leg(fn):
+        """A parity leg of the side measurements: never takes the line down, but a leg that fails - or cannot run - makes the
+        process exit non-zero (main)."""
+        try:
+            from oracle import crnn_parity as P
+            return fn(P)
+        except Exception as exc:
+            import traceback
+            traceback.print_exc()
+            return {"ok": False, "error": repr(exc)[:300]}
+
     def fwd():
         model.eval()
         with torch.no_grad():
@@ -181,6 +192,14 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
     t_fwd = timed(fwd, steps)
     t_fwd_folded = timed(infer.eager, steps)
     t_fwd_graph = timed(infer.replay, steps) if infer.graph_ok else None
+    # checker leg for c3 (before the training steps below move the weights the engine was folded from): what one more replay
+    # of the TIMED graph returns - fresh SpecAugment bands, drawn on the device - against oracle.crnn_ref.RefCRNN on the same
+    # features (the frontend half of c3 is covered by `parity` above and tests/test_transforms_gpu.py at this size)
+    def c3_leg(P):
+        rep = infer.replay().clone() if infer.graph_ok else None       # leaves the bands it drew in infer._tb / _fb
+        feats = fe.plan.wav_to_logmel(wav, minmax=fe.do_minmax, log=True, t_bands=infer._tb, f_bands=infer._fb)
+        return P.c3_parity(model, infer, feats, replay_out=rep)
+    c3_parity = checker_leg(c3_leg)
     t_train = timed(train, steps)
 
     # where the training step goes: device time per phase from events on the stream (one extra pass, untimed)
@@ -262,6 +281,11 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         except Exception as exc:  # an optimisation on top of the eager step: never takes the line down
             graphed = {"error": repr(exc)[:200]}
 
+    # checker leg for c4: one training-mode forward / backward / AGC + clipvalue on the timed batch (this step's features and
+    # labels, the model where the timed steps left it), every HIP pass on, against the fp64 reference taking the same ReLU /
+    # max-pool decisions (oracle/crnn_parity.py; why decisions must be matched at this size: oracle.crnn_ref.Decisions)
+    c4_parity = checker_leg(lambda P: P.c4_parity(model, fe(wav), y, clipvalue=cfg.clipvalue))
+
     # input side of the reference's own training loop (spectra in, sj_train.py:74-130) at its default
     # shape: whole batches synthesised on the device (iris_mix_specs + mel kernel with bands)
     dbatch = 64
@@ -316,6 +340,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                     "c3_direct_bound_ms the engine now runs BELOW); 157.3 TFLOP/s is the MFMA peak at 2.4 GHz - a bare MFMA "
                     "loop sustains ~131 on this chip (scripts/gpu_wino_bench.py ablation)"}
     c3 = {"audio_s_per_s": round(world * audio_s / t_fwd, 1), "ms_per_step": round(1e3 * t_fwd, 3), "batch_per_gpu": batch,
+          "parity": c3_parity,
           "what": "training-mode model object in eval(): BatchNorm kernels, separate bias / ReLU kernels (the literal module)",
           "inference_engine": {
               "what": "same function for inference (sj_train.InferenceEngine): BatchNorm folded into the convolutions, every "
@@ -341,6 +366,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         "crnn_matrix_core_bound": mfma,
         "c4_train_step": {"audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3),
                           "batch_per_gpu": batch, "n_gpus": world, "params": sum(p.numel() for p in model.parameters()),
+                          "parity": c4_parity,
                           "hipgraph": graphed, "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if ddp is not None else "none", "device_ms_per_phase": breakdown,
                           "allreduce": comm},
         "autocast_bf16_smoke_stock_ops": bf16,
@@ -895,11 +921,17 @@ def main():
             extras["c2_cache_resident_replay"] = {"k1_us": round(1e3 * float(kr.mean()), 2) if len(kr) else None,
                                                   "step_us": round(1e6 * dt, 2)}
     timer.cancel()
+    if extras and not args.only_sweep:  # the c3 / c4 checker legs count like the c2 one: a failed leg is a failed run
+        for key in ("c3_frontend_specaug_crnn_fwd", "c4_train_step"):
+            leg = (extras.get(key) or {}).get("parity")
+            if leg is not None:
+                parity_ok.append(bool(leg.get("ok")))
     finish(extras)
     if coll:
         dist.destroy_process_group()
     if parity_ok and not all(parity_ok):  # a fast kernel whose results differ from the reference's is not done
-        print("bench.py: parity check against the oracle FAILED (see the `parity` field)", file=sys.stderr)
+        print("bench.py: a parity check against the oracle FAILED (see `parity`, `extra.c3_frontend_specaug_crnn_fwd.parity`, "
+              "`extra.c4_train_step.parity`)", file=sys.stderr)
         sys.exit(3)
 
 

@@ -1,0 +1,441 @@
+"""Optimiser, run name, MIOpen configuration, the training step as one replayed hipGraph (`GraphedTrainStep`, also under
+DistributedDataParallel over RCCL) and the Keras-fit equivalent of sj_train.py:489-519 upstream (`fit`)."""
+from __future__ import annotations
+
+import csv
+import math
+import os
+import time
+from typing import Optional
+
+import torch
+
+from . import frontend as _fe
+from . import switches as SW
+from .distributed import _gradient_buckets, average_bn_statistics, collectives_on
+from .hip_autograd import FusedAGC, _IN_STEP, _ZERO_POOL
+from .model import CustomModel
+
+
+def make_optimizer(config, params, capturable: bool = False):
+    """`capturable`: Adam with its step count and learning rate in device tensors, for `GraphedTrainStep`."""
+    params = list(params)
+    if capturable:
+        if config.optimizer != 'adam' or not (params and params[0].is_cuda):
+            raise ValueError("make_optimizer(capturable=True): Adam on a GPU")
+        return torch.optim.Adam(params, lr=torch.tensor(float(config.lr), device=params[0].device), eps=1e-7, fused=True,
+                                capturable=True)
+    # foreach=True on a GPU: the update AND zero_grad run as a handful of multi-tensor kernels instead of one per
+    # parameter (86 fills of ~3.6 us each per step otherwise)
+    fe = bool(params) and params[0].is_cuda
+    if config.optimizer == 'adam':
+        if fe and os.environ.get("IRIS_ADAM_FUSED", "1") != "0":  # the whole update in one multi-tensor launch
+            return torch.optim.Adam(params, lr=config.lr, eps=1e-7, fused=True)
+        return torch.optim.Adam(params, lr=config.lr, eps=1e-7, foreach=fe)  # Keras Adam epsilon
+    if config.optimizer == 'sgd':
+        return torch.optim.SGD(params, lr=config.lr, momentum=0.9, foreach=fe)
+    if config.optimizer == 'rmsprop':
+        return torch.optim.RMSprop(params, lr=config.lr, momentum=0.9, alpha=0.9, eps=1e-7, foreach=fe)
+    raise ValueError('adabelief is deprecated')
+
+
+def run_name(config) -> str:
+    """Run name encoding of sj_train.py:416-429."""
+    name = (config.name + '_') if config.name != '' else ''
+    first = {'eff': f'B{config.model}', 'se': 'se', 'vad': 'vad'}[config.model_type]
+    name += '_'.join([first, f'v{config.v}', f'lr{config.lr}', f'batch{config.batch_size}',
+                      f'opt_{config.optimizer}', f'mel{config.n_mels}', f'chan{config.n_chan}',
+                      f'{config.loss.upper()}', f'framelen{config.n_frame}'])
+    return name if name.endswith('.h5') else name + '.h5'
+
+
+def configure_miopen() -> None:
+    """MIOpen defaults for this model's fp32 conv shapes (only set when the user has not):
+    NORMAL find benchmarks the applicable solvers once per shape - the FAST heuristic picks a CK
+    backward-weight kernel that is ~60x slower here - and the naive reference solvers (hundreds of
+    ms per call, never the winner) are kept out of that benchmark."""
+    os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL")
+    for d in ("FWD", "BWD", "WRW"):
+        os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + d, "0")
+    _use_shipped_miopen_db()
+
+
+def _use_shipped_miopen_db() -> None:
+    """challenge_amd/miopen_db/ holds MIOpen's user perf-db / find-db after an exhaustive search (MIOPEN_FIND_ENFORCE=3,
+    scripts/gpu_miopen_tune.sh) over this model's convolution shapes at batch 64 on an MI355X: tuned kernel parameters for
+    the solvers MIOpen already has, 16.2 -> 15.1 ms per training step (profiles/r3/miopen_tune.log).  MIOpen also WRITES to
+    its user db, so a per-user, per-rank copy (miopen_db/_run/, named after the shipped content) is what MIOPEN_USER_DB_PATH points at.
+    Skipped when the user has set MIOPEN_USER_DB_PATH, or with IRIS_MIOPEN_DB=0; the files are keyed by MIOpen build and
+    GPU, so any other build / GPU simply does not find them."""
+    if "MIOPEN_USER_DB_PATH" in os.environ or os.environ.get("IRIS_MIOPEN_DB", "1") == "0":
+        return
+    import hashlib
+    import shutil
+    import tempfile
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+    try:
+        files = sorted(f for f in os.listdir(src) if f.endswith("db.txt"))
+        if not files:
+            return
+        digest = hashlib.sha256()
+        for f in files:
+            with open(os.path.join(src, f), "rb") as fh:
+                digest.update(f.encode() + b"\0" + fh.read())
+        uid = os.getuid() if hasattr(os, "getuid") else 0
+        name = f"u{uid}_r{os.environ.get('LOCAL_RANK', '0')}_{digest.hexdigest()[:12]}"
+        dst = os.path.join(src, "_run", name)  # beside the shipped files (git- and gpurun-ignored) ...
+        try:
+            os.makedirs(dst, exist_ok=True)
+        except OSError:  # ... or, for a read-only installation, in the temp dir
+            dst = os.path.join(tempfile.gettempdir(), "iris_miopen_db_" + name)
+            os.makedirs(dst, exist_ok=True)
+        for f in files:
+            if not os.path.exists(os.path.join(dst, f)):
+                tmp = os.path.join(dst, f + f".{os.getpid()}.tmp")
+                shutil.copyfile(os.path.join(src, f), tmp)
+                os.replace(tmp, os.path.join(dst, f))
+        os.environ["MIOPEN_USER_DB_PATH"] = dst
+    except OSError:
+        pass  # no shipped db / unwritable temp dir: MIOpen's own defaults
+
+
+def miopen_db_status() -> str:
+    """Did MIOpen pick up the shipped perf-db / find-db (`_use_shipped_miopen_db`)?  Call AFTER the model's convolutions have
+    run once.  The files are keyed by MIOpen's build string and the GPU (arch + CU count) in their NAMES: a matching MIOpen
+    reads and appends to the shipped names, any other build ignores them and - having had to search - writes files under its
+    own name next to them.  'used' / 'ignored: ...' / 'off: ...' (bench.py records it as extra.miopen_db: the tuned db is
+    worth 13.7 vs 15.1 ms per training step, so a line must say which of the two it measured)."""
+    path = os.environ.get("MIOPEN_USER_DB_PATH")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+    if os.environ.get("IRIS_MIOPEN_DB", "1") == "0":
+        return "off: IRIS_MIOPEN_DB=0"
+    try:
+        shipped = {f for f in os.listdir(src) if f.endswith("db.txt")}
+    except OSError:
+        shipped = set()
+    if not path or not shipped:
+        return "off: no shipped db in use"
+    if not (os.path.basename(os.path.dirname(path)) == "_run" or os.path.basename(path).startswith("iris_miopen_db_")):
+        return "off: MIOPEN_USER_DB_PATH set by the user"
+    try:
+        present = {f for f in os.listdir(path) if f.endswith("db.txt")}
+    except OSError:
+        return "off: " + path + " unreadable"
+    foreign = sorted(present - shipped)
+    if foreign:
+        return ("ignored: this MIOpen build wrote " + ", ".join(foreign[:2]) + " - its build string / GPU differs from the shipped "
+                + sorted(shipped)[-1])
+    return "used"
+
+
+class GraphCaptureError(RuntimeError):
+    """The training step could not be captured as a hipGraph.  Raised by GraphedTrainStep on EVERY rank of a job alike (the ranks
+    agree on the outcome before anyone replays) and with the model's state as it was before the attempt: the caller may go on
+    with the eager step."""
+
+
+class GraphedTrainStep:
+    """`model.train_step` (forward, loss, backward, gradient all-reduce, AGC + clipvalue, optimiser) as ONE replayed hipGraph -
+    fixed batch shape.  The gradients live in the graph's memory pool and are dropped inside the capture, so the replay has
+    neither the zero fills nor autograd's accumulate launches; the host enqueues two copies and one graph launch per step
+    however many kernels the step has (~260), which is what keeps eight ranks sharing one host off each other's toes.
+
+        opt = make_optimizer(config, model.parameters(), capturable=True)      # learning rate held in a device tensor
+        model.compile(opt, loss, clipvalue=..., ddp=wrap_ddp(...))
+        step = GraphedTrainStep(model, (x, y))                                   # 3 eager warm-up steps (they train), then the capture
+                                                                                 # (preserve_state=True: the warm-up leaves no trace)
+        for x, y in data: loss = step((x, y))['loss']                            # inputs are copied into the static buffers
+        step.set_lr(value)                                                       # schedulers write the tensor
+
+    MIOpen must already know its kernels for these shapes (the warm-up steps see to that).
+    **Under DistributedDataParallel** (round 6; RCCL only) the capture does not go through DDP's reducer - host-side bucket
+    bookkeeping that a replay would skip - but issues the same exchange itself: the plain module runs forward and backward, a
+    post-accumulate hook per parameter copies each finished gradient bucket (DDP's own bucket order and size, `_gradient_buckets`)
+    into a flat buffer, pre-divides it by the world size and starts `all_reduce` on it asynchronously (RCCL's stream joins the
+    capture as a parallel branch: the collective of one bucket overlaps the backward kernels of the layers below, as under DDP);
+    after backward the capture waits for the collectives, the gradients become views of the flat buffers, and AGC, clipvalue and
+    Adam act on the averaged gradients - identically on every rank.  Whether the capture succeeded is agreed on by ALL ranks
+    (one MIN all-reduce of a flag) before anyone replays: a rank never replays a graph while another one runs eager DDP."""
+
+    def __init__(self, model: "CustomModel", example, warmup: int = 3, preserve_state: bool = False):
+        """`preserve_state`: parameters, buffers and the optimiser's state are put back after the warm-up steps - also when a
+        warm-up step or the capture fails -, so that the first replay (or the first eager step of the fallback) is the FIRST
+        update the example batch causes (what `fit` wants: one update per batch, as the reference)."""
+        x, y = example
+        if not x.is_cuda:
+            raise RuntimeError("GraphedTrainStep: a GPU tensor is required (hipGraph capture; no CPU fallback)")
+        opt = model.optimizer
+        if not all(g.get('capturable', False) for g in opt.param_groups):
+            raise ValueError("GraphedTrainStep: the optimiser must be capturable - make_optimizer(config, params, capturable=True)")
+        self.world = 0   # > 0: the capture holds the gradient all-reduce of that many ranks
+        if model._ddp is not None:
+            dist = torch.distributed
+            if dist.get_backend() != 'nccl':
+                raise GraphCaptureError(f"GraphedTrainStep: under DistributedDataParallel only with RCCL (backend 'nccl'); the "
+                                        f"'{dist.get_backend()}' backend's collectives cannot be captured into a hipGraph")
+            self.world = dist.get_world_size()
+        self.model, self.x, self.y = model, x.clone(), y.clone()
+        dev = x.device
+        saved = None
+        if preserve_state:
+            tensors = list(model.parameters()) + list(model.buffers())
+            saved = ([t.detach().clone() for t in tensors], tensors,
+                     {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in opt.state.get(p, {}).items()}
+                      for g in opt.param_groups for p in g['params']})
+
+        def restore():
+            opt.zero_grad(set_to_none=True)
+            if saved is None:
+                return
+            with torch.no_grad():   # undo the warm-up in place (the graph is captured on these very tensors)
+                for t, old in zip(saved[1], saved[0]):
+                    t.copy_(old)
+                for g in opt.param_groups:
+                    for p in g['params']:
+                        before, now = saved[2][id(p)], opt.state.get(p, {})
+                        for k, v in now.items():
+                            if torch.is_tensor(v):   # moments and the step count: back to their old values, or to a fresh 0
+                                v.copy_(before[k]) if k in before else v.zero_()
+            model.bump_generation()
+            torch.cuda.synchronize(dev)
+
+        # `warmup` eager steps in all (they train the model; under DDP they go through DDP): all but the last on the current
+        # stream - without them the capture was invalidated on this stack (some first-use initialisation that a side stream
+        # alone does not trigger) - and the last one on a side stream, as torch's capture recipe asks
+        try:
+            for _ in range(max(warmup, 2) - 1):
+                model.train_step((self.x, self.y))
+            torch.cuda.synchronize(dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                model.train_step((self.x, self.y))
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+        finally:
+            object.__setattr__(model, '_fused_agc', None)  # its table holds the eager gradients' addresses
+            restore()
+        # The captured AGC launch reads a table whose pinned staging buffer is the source of a captured copy node: this
+        # object owns both for as long as the graph lives, and the model's own `_fused_agc` stays None - an eager
+        # `model.train_step` later (e.g. a ragged last batch) builds a SEPARATE FusedAGC instead of rebuilding - and
+        # freeing - the buffers the graph replays from.
+        self._agc = FusedAGC(list(model.parameters())) if model.use_agc else None
+        if self._agc is not None:
+            self._agc.reserve()
+        self._flats, self._buckets = [], []
+        if self.world:
+            self._buckets = _gradient_buckets(model.parameters(), SW.DDP_BUCKET_MB << 20)
+            self._flats = [torch.zeros(sum(p.numel() for p in b), dtype=b[0].dtype, device=dev) for b in self._buckets]
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        self._pool_marks = {}
+        ok, error = True, None
+        try:
+            # (thread_local: another thread's harmless queries - RCCL's watchdog polling the events of earlier collectives when
+            # a process group is alive in this process - must not invalidate the capture, nor be killed by it)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self._capture_body(model, opt, dev)
+            torch.cuda.synchronize(dev)
+        except Exception as exc:   # nothing of the capture has RUN: the model is where `restore` left it
+            ok, error = False, exc
+            opt.zero_grad(set_to_none=True)
+        if self.world:   # every rank replays, or none does
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if ok and not int(flag.item()):
+                ok, error = False, RuntimeError("the capture failed on another rank of this job")
+        if not ok:
+            self.graph = None
+            raise GraphCaptureError(f"GraphedTrainStep: {error!r:.300}") from error
+
+    def _capture_body(self, model, opt, dev):
+        model.train()
+        if SW.ZERO_POOL:
+            _ZERO_POOL.begin_step(dev)
+        handles, works = [], []
+        if self.world:
+            # the exchange DDP's reducer would do, issued from inside the capture (see the class docstring)
+            world, index, left = self.world, {}, [len(b) for b in self._buckets]
+            views = []
+            for k, (bucket, flat) in enumerate(zip(self._buckets, self._flats)):
+                off, vs = 0, []
+                for p in bucket:
+                    n = p.numel()
+                    dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)
+                    vs.append(flat[off:off + n].as_strided(p.shape, p.stride()) if dense else flat[off:off + n].view(p.shape))
+                    index[id(p)] = k
+                    off += n
+                views.append(vs)
+
+            def ready(p):
+                k = index[id(p)]
+                left[k] -= 1
+                if left[k]:
+                    return
+                bucket, flat = self._buckets[k], self._flats[k]
+                torch._foreach_copy_(views[k], [q.grad for q in bucket])
+                if world > 1:
+                    flat.div_(world)          # DDP's order: divide, then sum over the ranks
+                for q, v in zip(bucket, views[k]):
+                    q.grad = v                # AGC and the optimiser read (and AGC rewrites) the averaged gradients in place
+                works.append(torch.distributed.all_reduce(flat, async_op=True))
+            handles = [p.register_post_accumulate_grad_hook(ready) for b in self._buckets for p in b]
+        was_in_step, _IN_STEP[0] = _IN_STEP[0], True
+        try:
+            loss = model.loss_fn(self.y, model(self.x))   # the plain module: DDP's reducer stays out of the capture
+            loss.backward()
+        finally:
+            _IN_STEP[0] = was_in_step
+            for h in handles:
+                h.remove()
+        if self.world:
+            if any(n for n in left):
+                raise RuntimeError("GraphedTrainStep: a parameter received no gradient - its bucket was never exchanged")
+            for w in works:
+                w.wait()                      # the capture stream joins RCCL's stream again
+        if model.use_agc:
+            self._agc(0.01, 1e-3, model.clipvalue)
+            self._agc.freeze()
+        elif model.clipvalue:
+            torch.nn.utils.clip_grad_value_([p for p in model.parameters() if p.grad is not None], model.clipvalue)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        self.loss = loss.detach()
+        self._pool_marks = _ZERO_POOL.marks(dev) if SW.ZERO_POOL else {}
+
+    def __call__(self, data):
+        x, y = data
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        self.graph.replay()
+        if self._pool_marks:
+            _ZERO_POOL.mark_dirty(self._pool_marks)   # the replay has written into the zero pool behind its back
+        self.model.bump_generation()  # a replay moves parameters and BatchNorm statistics behind ATen's back
+        return {'loss': self.loss}
+
+    def set_lr(self, value: float) -> None:
+        for g in self.model.optimizer.param_groups:
+            if torch.is_tensor(g['lr']):
+                g['lr'].fill_(float(value))
+            else:
+                g['lr'] = float(value)
+
+
+def graph_step_possible(model: "CustomModel") -> bool:
+    """Can `fit` try GraphedTrainStep for this compiled model?  A capturable optimiser, and - under DDP - the RCCL backend."""
+    if model.optimizer is None or not all(g.get('capturable', False) for g in model.optimizer.param_groups):
+        return False
+    return model._ddp is None or torch.distributed.get_backend() == 'nccl'
+
+
+def fit(model: CustomModel, train_set, epochs, steps_per_epoch, validation_data=None, validation_steps=16,
+        scheduler=None, csv_path=None, checkpoint_path=None, patience=None, rank=0, world=1, verbose=True,
+        swa=None, graph: Optional[bool] = None):
+    """Minimal Keras-fit equivalent for this path: per-epoch LR schedule, CSV log,
+    best-val-loss checkpoint, early stopping, TerminateOnNaN (sj_train.py:489-519).
+    `graph` (default: on, IRIS_GRAPH_STEP=0 switches it off): run the training step as ONE replayed hipGraph (GraphedTrainStep) - a
+    capturable optimiser (make_optimizer(..., capturable=True)), batches of one shape, under DDP the RCCL backend; a batch of
+    another shape (a ragged last one) takes the eager step.  The step then costs what its kernels cost (10 ms per batch of 64)
+    however slow the host is at launching ~260 kernels.  A capture that fails is reported ONCE (warnings.warn, every rank) and
+    the run goes on eagerly - on every rank alike, from the state the model had before the attempt."""
+    best, bad, history = math.inf, 0, []
+    coll = collectives_on(world)  # world > 1, or a forced process group at world 1 (IRIS_FORCE_PG=1)
+    it = iter(train_set)
+    graph = SW.GRAPH_STEP if graph is None else bool(graph)
+    graph = graph and graph_step_possible(model)
+    gstep = None
+
+    def one_step(data):
+        nonlocal gstep
+        x, y = data
+        if not (graph and x.is_cuda):
+            return model.train_step(data)
+        if gstep is None:
+            try:   # the warm-up steps run on this batch and are undone: the first replay is its first update
+                gstep = GraphedTrainStep(model, data, preserve_state=True)
+            except GraphCaptureError as exc:   # must not take the training run down: eager from here on (all ranks alike)
+                import warnings
+                warnings.warn(f"fit (rank {rank}): the training step could not be captured as a hipGraph ({exc!s:.300}); "
+                              "running it eagerly", RuntimeWarning, stacklevel=2)
+                gstep = False
+        if gstep and x.shape == gstep.x.shape and y.shape == gstep.y.shape and x.dtype == gstep.x.dtype:
+            return gstep(data)
+        return model.train_step(data)
+
+    for epoch in range(epochs):
+        if scheduler is not None:
+            lr = scheduler(epoch)
+            for g in model.optimizer.param_groups:
+                if torch.is_tensor(g['lr']):
+                    g['lr'].fill_(float(lr))   # capturable optimiser: the rate lives in a device tensor (a graph reads it)
+                else:
+                    g['lr'] = lr
+        t0, losses = time.time(), []
+        for _ in range(steps_per_epoch):
+            losses.append(one_step(next(it))['loss'].clone() if graph else one_step(next(it))['loss'])
+        loss = torch.stack(losses).mean()
+        # The one place per epoch where the frontend plans' status words are read for certain (the hot path also reports a
+        # failed earlier launch at the plan's next call, without a sync): EpilogueTimeout naming the plan instead of training
+        # on NaN features.  Under DDP the failure of ONE rank must not leave the others waiting in the collectives below, so
+        # the verdict rides along with the epoch loss in the same all-reduce and every rank raises after it.
+        plan_failure = None
+        if loss.is_cuda or SW._PLAN_CHECK_ON_CPU:
+            try:
+                _fe.check_plans(loss.device)
+            except _fe.N.EpilogueTimeout as exc:
+                plan_failure = exc
+        if coll:
+            pack = torch.stack([loss, loss.new_tensor(1.0 if plan_failure is not None else 0.0)])
+            torch.distributed.all_reduce(pack)  # two scalars per epoch
+            loss, failed_ranks = pack[0] / world, int(round(float(pack[1])))
+            if failed_ranks and plan_failure is None:
+                plan_failure = _fe.N.EpilogueTimeout(f"{failed_ranks} other rank(s) of this job reported a failed fused min-max / "
+                                                     "log epilogue (NaN features); stopping with them")
+        if plan_failure is not None:
+            raise plan_failure
+        row = {'epoch': epoch, 'loss': float(loss), 'lr': float(model.optimizer.param_groups[0]['lr']),
+               'time': time.time() - t0}
+        if coll:
+            average_bn_statistics(model, world)
+        if not math.isfinite(row['loss']):
+            if verbose and rank == 0:
+                print('NaN loss, terminating')
+            break
+        if validation_data is not None:
+            vit = iter(validation_data)
+            vl = torch.stack([model.test_step(next(vit))['loss'] for _ in range(validation_steps)]).mean()
+            if coll:  # every rank validates its own shard: the monitored value is the mean over ranks
+                torch.distributed.all_reduce(vl)
+                vl = vl / world
+            row['val_loss'] = float(vl)
+        history.append(row)
+        if swa is not None:
+            swa.on_epoch_end(epoch, model)
+        # The monitored value is identical on every rank (all-reduced above), so best / bad / stop are
+        # computed by all ranks alike and they leave the loop together; only file I/O is rank 0's.
+        monitor = row.get('val_loss', row['loss'])
+        improved = monitor < best
+        if improved:
+            best, bad = monitor, 0
+        else:
+            bad += 1
+        if rank == 0:
+            if verbose:
+                print(row)
+            if csv_path:
+                new = not os.path.exists(csv_path)
+                with open(csv_path, 'a', newline='') as f:
+                    w = csv.DictWriter(f, fieldnames=list(row))
+                    if new:
+                        w.writeheader()
+                    w.writerow(row)
+            if improved and checkpoint_path:
+                torch.save(model.state_dict(), checkpoint_path)
+        stop = patience is not None and not improved and bad >= patience  # Keras EarlyStopping: wait >= patience, tested on a non-improving epoch
+        if coll:  # belt and braces: one int per epoch, rank 0's decision wins
+            flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=loss.device)
+            torch.distributed.broadcast(flag, src=0)
+            stop = bool(int(flag.item()))
+        if stop:
+            break
+    return history

@@ -567,11 +567,14 @@ def conv3x3_wino(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch.Ten
     return y
 
 
-_WRW_WORKSPACES = {}   # device index -> scratch tensors of conv3x3_wino_wrw (grow-only: a captured hipGraph keeps its pointers)
+# (device index, stream) -> scratch tensors of conv3x3_wino_wrw.  Grow-only: a captured hipGraph keeps its pointers.  One set per
+# STREAM: the partial sums of two backward passes running on different streams of a device (a graph replay beside an eager
+# step, two models on side streams) must not share a buffer; calls on one stream are ordered by the stream.
+_WRW_WORKSPACES = {}
 
 
 def _wrw_workspace(device: torch.device, floats: int) -> torch.Tensor:
-    held = _WRW_WORKSPACES.setdefault(device.index, [])
+    held = _WRW_WORKSPACES.setdefault((device.index, int(torch.cuda.current_stream(device).cuda_stream)), [])
     if not held or held[-1].numel() < floats:
         held.append(torch.empty(max(floats, 1 << 24), dtype=torch.float32, device=device))
     return held[-1]
@@ -581,7 +584,8 @@ def conv3x3_wino_wrw(x: torch.Tensor, dy: torch.Tensor, like: Optional[torch.Ten
     """The weight gradient of z = conv2d(x, weight, padding=1) given dy = dL/dz, as Winograd F(2x2, 3x3) on the fp32 matrix
     cores (iris_conv3x3_wino_wrw).  x [B, Cin, H, W] and dy [B, Cout, H, W]: channels_last float32 device tensors, Cin and
     Cout multiples of 32.  Returns dW [Cout, Cin, 3, 3] with the strides of `like` (the weight) or channels_last.
-    The partial sums go through ONE scratch buffer per device: calls on different streams of a device must not overlap."""
+    The partial sums go through one scratch buffer per (device, stream): calls on one stream are ordered by it, calls on
+    different streams do not share a buffer."""
     if not (x.is_cuda and x.dtype == torch.float32 and dy.dtype == torch.float32 and dy.device == x.device):
         raise ValueError("conv3x3_wino_wrw: x and dy must be float32 tensors on one device (no CPU fallback)")
     if not (x.dim() == 4 and dy.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)

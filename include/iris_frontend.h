@@ -151,8 +151,9 @@ int iris_plan_set_mel_precision(iris_plan* plan, int precision);
 #define IRIS_EPILOGUE_TWO_KERNELS 1
 #define IRIS_EPILOGUE_IN_PLACE 2
 int iris_plan_set_epilogue(iris_plan* plan, int mode);
-/* form the plan's last iris_wav_to_logmel call took: IRIS_EPILOGUE_* (a FUSED plan reports IN_PLACE or TWO_KERNELS where it
- * fell back by itself), -1 before the first call or when neither min-max nor log was asked for */
+/* form the plan's last iris_wav_to_logmel call took: IRIS_EPILOGUE_* (a FUSED plan reports TWO_KERNELS where it fell back by
+ * itself - a chunk tile beyond the LDS, a capture in progress, an earlier epilogue timeout; IN_PLACE is only ever taken when it
+ * was asked for), -1 before the first call or when neither min-max nor log was asked for */
 int iris_plan_last_epilogue(const iris_plan* plan, int* form_out);
 int iris_plan_status(iris_plan* plan, int* status_out);
 int iris_plan_set_epilogue_timeout(iris_plan* plan, unsigned long long microseconds);

@@ -1,0 +1,169 @@
+"""Parity legs for the CRNN half of c3 / c4 at whatever size the caller runs - TEST / BENCH INFRASTRUCTURE, NOT PRODUCT CODE.
+
+`c3_parity`: an `InferenceEngine` (BatchNorm folded, every convolution a HIP kernel) against `RefCRNN` (oracle/crnn_ref.py: the
+network of sj_train.py:214-255 on stock torch layers) in eval mode, fp32 and fp64.
+`c4_parity`: one training-mode forward / backward / AGC + clipvalue of the product's module with every HIP pass on (what
+CustomModel.train_step runs, sj_train.py:158-188) against the fp64 `RefCRNN` taking the SAME ReLU / max-pool decisions
+(`crnn_ref.Decisions` explains why a gradient comparison at batch 64 x 512 frames needs that), plus the bit-reproducibility of
+the product's step.  Used by tests/test_fullsize_gpu.py and by bench.py's `extra.c3_*.parity` / `extra.c4_train_step.parity`
+on the timed batch.  Bounds (measured values: profiles/r6/fullsize_parity.log):
+
+    c3  sigmoid outputs <= 1e-4 abs, pre-sigmoid activations <= 2e-5 of their peak          (measured 6e-8, 2.5e-7)
+    c4  loss <= 1e-6; outputs <= 2e-5 abs; BatchNorm running statistics <= 1e-6 of their peak (measured 1e-8, 6.6e-6, 8.5e-8)
+        every gradient, raw and after AGC + clipvalue, <= 3e-5 of its peak                   (measured 2.0e-5, on the LSTM biases;
+                                                                                              stock fp32 ops on flip-free layers 1.9e-5)
+        biases in front of a BatchNorm (true gradient exactly 0): <= 1e-6 of the layer's weight-gradient peak
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+
+from . import crnn_ref as R
+
+BOUNDS = {"c3_sigmoid_abs": 1e-4, "c3_pre_sigmoid_rel": 2e-5, "c4_loss_abs": 1e-6, "c4_outputs_abs": 2e-5, "c4_bn_buffers_rel": 1e-6,
+          "c4_gradient_rel": 3e-5, "c4_zero_gradient_rel": 1e-6}
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max()) / (float(b.double().abs().max()) + 1e-300)
+
+
+def clone_module(model):
+    """A deep copy of a product CustomModel without what must stay with the original (optimiser, DDP wrapper, AGC tables)."""
+    keep = {k: model.__dict__.get(k) for k in ('optimizer', '_ddp', '_fused_agc', '_predict_engine')}
+    try:
+        for k in keep:
+            if k in model.__dict__:
+                object.__setattr__(model, k, None)
+        return copy.deepcopy(model)
+    finally:
+        for k, v in keep.items():
+            if k in model.__dict__:
+                object.__setattr__(model, k, v)
+
+
+def _ref_like(model, feats, dtype):
+    n_mels, n_frame, n_chan = int(feats.shape[1]), int(feats.shape[2]), int(feats.shape[3])
+    ref = R.RefCRNN(n_mels, n_frame, n_chan, model.config_v, model.model_type).to(feats.device)
+    if dtype == torch.float64:
+        ref = ref.double()
+    return ref.load_from(model)
+
+
+@torch.no_grad()
+def c3_parity(model, engine, feats, replay_out=None) -> dict:
+    """`engine(feats)` (and, if given, what a graph replay returned for the same features) against RefCRNN in eval mode."""
+    pre = {}
+    hook = engine.model.head.fc.register_forward_hook(lambda m, i, o: pre.__setitem__('z', o.detach().clone()))
+    try:
+        got = engine(feats).clone()
+    finally:
+        hook.remove()
+    ref32, ref64 = _ref_like(model, feats, torch.float32).eval(), _ref_like(model, feats, torch.float64).eval()
+    w32, z32 = ref32(feats), ref32.pre_activation
+    w64, z64 = ref64(feats.double()), ref64.pre_activation
+    out = {"checked": f"InferenceEngine forward on the timed batch {tuple(feats.shape)} vs oracle.crnn_ref.RefCRNN (stock torch layers, "
+                      "eval mode) in fp32 and fp64",
+           "sigmoid_abs_vs_fp64": float((got.double() - w64).abs().max()), "sigmoid_abs_vs_fp32_stock": float((got - w32).abs().max()),
+           "pre_sigmoid_rel_vs_fp64": _rel(pre['z'], z64), "pre_sigmoid_rel_vs_fp32_stock": _rel(pre['z'], z32),
+           "stock_fp32_vs_fp64": {"sigmoid_abs": float((w32.double() - w64).abs().max()), "pre_sigmoid_rel": _rel(z32, z64)},
+           "bounds": {"sigmoid_abs": BOUNDS["c3_sigmoid_abs"], "pre_sigmoid_rel": BOUNDS["c3_pre_sigmoid_rel"]}}
+    ok = (max(out["sigmoid_abs_vs_fp64"], out["sigmoid_abs_vs_fp32_stock"]) <= BOUNDS["c3_sigmoid_abs"]
+          and max(out["pre_sigmoid_rel_vs_fp64"], out["pre_sigmoid_rel_vs_fp32_stock"]) <= BOUNDS["c3_pre_sigmoid_rel"])
+    if replay_out is not None:
+        out["replay_abs_vs_fp64"] = float((replay_out.double() - w64).abs().max())
+        out["replay_equals_eager"] = bool(torch.equal(replay_out, got))
+        ok = ok and out["replay_abs_vs_fp64"] <= BOUNDS["c3_sigmoid_abs"]
+    out["ok"] = bool(ok)
+    return {k: (float(f"{v:.3e}") if isinstance(v, float) else v) for k, v in out.items()}
+
+
+def _bn_fed_bias(name: str) -> bool:
+    """Conv / Dense biases in front of a BatchNorm: the batch mean is subtracted, their true gradient is exactly zero."""
+    return (name.endswith(".0.bias") and name.startswith("features.")) or (name.endswith("fc.bias") and not name.startswith("head."))
+
+
+def c4_parity(model, feats, y, clipvalue=0.01, unmatched: bool = True, stock_fp32: bool = False) -> dict:
+    """One training-mode forward / backward of (a copy of) `model` on (feats, y) with every HIP pass as the switches have it,
+    against the decision-matched fp64 reference.  `model` itself is not touched.  `unmatched`: also report the distance to the fp64
+    reference taking its OWN decisions (the flips); `stock_fp32`: and the stock fp32 layers' distance to it (slow: MIOpen find)."""
+    from challenge_amd.hip_autograd import record_activations   # the checker reads the product's activations, never the reverse
+    from challenge_amd.model import binary_crossentropy
+    dev = feats.device
+    names = [n for n, _ in model.named_parameters()]
+
+    def product_pass(tap):
+        m = clone_module(model).train()
+        for p in m.parameters():
+            p.grad = None
+        td = {}
+        hook = m.td.register_forward_hook(lambda mod, i, o: td.__setitem__('z', o.detach()))
+        try:
+            if tap:
+                with record_activations() as acts:
+                    out = m(feats)
+            else:
+                acts, out = None, m(feats)
+        finally:
+            hook.remove()
+        loss = binary_crossentropy(y, out)
+        loss.backward()
+        torch.cuda.synchronize(dev)
+        return m, loss.detach(), out.detach(), [p.grad.detach().clone() for p in m.parameters()], (R.Decisions(acts, td['z']) if tap else None)
+
+    m_a, loss_a, out_a, g_a, decisions = product_pass(True)
+    _, loss_b, out_b, g_b, _ = product_pass(False)
+    reproducible = bool(torch.equal(loss_a, loss_b) and torch.equal(out_a, out_b) and all(torch.equal(a, b) for a, b in zip(g_a, g_b)))
+    run_to_run = max(_rel(a, b) for a, b in zip(g_a, g_b))
+    r64 = _ref_like(model, feats, torch.float64)
+    q = R.reference_step(r64, feats, y, clipvalue=clipvalue, decisions=decisions)
+
+    def worst(mine, theirs):
+        rows = [(_rel(a, b), n) for n, a, b in zip(names, mine, theirs) if not _bn_fed_bias(n)]
+        return max(rows)
+
+    # biases in front of a BatchNorm: exactly zero in exact arithmetic; against the peak of the same layer's weight gradient
+    zero_rows = []
+    for k, n in enumerate(names):
+        if _bn_fed_bias(n):
+            zero_rows.append((float(g_a[k].abs().max()) / (float(g_a[k - 1].abs().max()) + 1e-300), n))
+    grad_err, grad_where = worst(g_a, q['raw'])
+    # the whole train_step at learning rate 0: what AGC + clipvalue leave in p.grad
+    m_c = clone_module(model)
+    m_c.compile(torch.optim.Adam(m_c.parameters(), lr=0.0, eps=1e-7), binary_crossentropy, clipvalue=clipvalue)
+    step_loss = m_c.train_step((feats, y))['loss']
+    torch.cuda.synchronize(dev)
+    clip_err, clip_where = worst([p.grad for p in m_c.parameters()], q['clipped'])
+    bufs = [(_rel(a, b), n) for (n, a), b in zip(m_a.named_buffers(), r64.buffers()) if a.dtype.is_floating_point]
+    counters_ok = all(torch.equal(a.cpu(), b.cpu().to(a.dtype)) for (n, a), b in zip(m_a.named_buffers(), r64.buffers())
+                      if not a.dtype.is_floating_point)
+    out = {"checked": f"one training-mode forward / backward / AGC + clipvalue of the module on the timed batch {tuple(feats.shape)}, "
+                      "every HIP pass on, vs oracle.crnn_ref.RefCRNN in fp64 taking the same ReLU / max-pool decisions",
+           "loss": float(loss_a), "loss_abs": abs(float(loss_a) - float(q['loss'])), "train_step_loss_abs": abs(float(step_loss) - float(q['loss'])),
+           "outputs_abs": float((out_a.double() - q['out']).abs().max()),
+           "gradient_rel_worst": grad_err, "gradient_rel_worst_where": grad_where,
+           "gradient_after_agc_clip_rel_worst": clip_err, "gradient_after_agc_clip_where": clip_where,
+           "zero_gradient_rel_worst": max(zero_rows)[0] if zero_rows else 0.0,
+           "bn_buffers_rel_worst": max(bufs)[0], "bn_buffers_where": max(bufs)[1], "bn_counters_equal": bool(counters_ok),
+           "bit_reproducible": reproducible, "run_to_run_gradient_rel": run_to_run,
+           "decisions": {"relu_masks": len(decisions.conv_masks) + len(decisions.fc_masks) + 1, "pool_maps": len(decisions.pool_slots),
+                         "rederived_and_verified_bitwise": decisions.rederived},
+           "bounds": {"loss_abs": BOUNDS["c4_loss_abs"], "outputs_abs": BOUNDS["c4_outputs_abs"], "gradient_rel": BOUNDS["c4_gradient_rel"],
+                      "zero_gradient_rel": BOUNDS["c4_zero_gradient_rel"], "bn_buffers_rel": BOUNDS["c4_bn_buffers_rel"]}}
+    ok = (out["loss_abs"] <= BOUNDS["c4_loss_abs"] and out["train_step_loss_abs"] <= BOUNDS["c4_loss_abs"]
+          and out["outputs_abs"] <= BOUNDS["c4_outputs_abs"] and grad_err <= BOUNDS["c4_gradient_rel"]
+          and clip_err <= BOUNDS["c4_gradient_rel"] and out["zero_gradient_rel_worst"] <= BOUNDS["c4_zero_gradient_rel"]
+          and out["bn_buffers_rel_worst"] <= BOUNDS["c4_bn_buffers_rel"] and counters_ok
+          and run_to_run <= 1e-5)   # (bit-reproducible up to the BatchNorm sums' fp64 atomics: a last-bit event once in ~1e5 runs)
+    if unmatched:   # for the record: the same comparison WITHOUT matching decisions - the flips, not an error of either side
+        r_own = _ref_like(model, feats, torch.float64)
+        q_own = R.reference_step(r_own, feats, y, clipvalue=clipvalue)
+        out["unmatched_fp64_gradient_rel_worst"] = worst(g_a, q_own['raw'])[0]
+        if stock_fp32:
+            r32 = _ref_like(model, feats, torch.float32)
+            q32 = R.reference_step(r32, feats, y, clipvalue=clipvalue)
+            out["stock_fp32_vs_unmatched_fp64_gradient_rel_worst"] = worst(q32['raw'], q_own['raw'])[0]
+    out["ok"] = bool(ok)
+    return {k: (float(f"{v:.3e}") if isinstance(v, float) else v) for k, v in out.items()}

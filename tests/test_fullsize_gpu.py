@@ -1,0 +1,124 @@
+"""BASELINE configs[2] / [3] at the size bench.py times them - batch 64 x 130,816 samples (8.176 s) -> 512 frames, 64 mel, v9 CRNN:
+the InferenceEngine forward (c3) and the training step (c4) against oracle/crnn_ref.RefCRNN, the network of the reference's
+define_keras_model (/root/reference sj_train.py:214-255) and train_step (:158-188) on stock torch layers, in fp32 and fp64.
+Round-5 verdict, item 1: until now the engine and the step were compared with anything only at B <= 8, T = 128."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BATCH, N_FRAME, N_MEL = 64, 512, 64
+LENGTH = (N_FRAME - 1) * 256   # 130,816 samples: T = 1 + L // hop = 512 frames
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def setup(dev):
+    from challenge_amd import sj_train as S
+    S.configure_miopen()
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', str(N_MEL), '--n_frame', str(N_FRAME), '--n_chan', '1', '--batch_size', str(BATCH)])
+    torch.manual_seed(0)
+    model = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():  # non-trivial BatchNorm statistics and affine maps (a fresh model's are 0 / 1 / 1 / 0)
+        for mod in model.modules():
+            if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                mod.running_mean.uniform_(-0.2, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.2, 0.2)
+    fe = S.WaveFrontend(1024, 256, N_MEL, 16000, 1, BATCH, LENGTH, dev, training=False)
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    wav = torch.randn(BATCH, 1, LENGTH, generator=gen, device=dev) * 0.1
+    y = (torch.rand(BATCH, N_FRAME // 32, 3, generator=gen, device=dev) < 0.1).float()
+    feats = fe(wav)
+    assert tuple(feats.shape) == (BATCH, N_MEL, N_FRAME, 1)
+    return S, cfg, model, fe, wav, y, feats
+
+
+def test_c3_engine_full_size_matches_reference(setup, monkeypatch):
+    """InferenceEngine - eager and as one replayed hipGraph (frontend + forward) - at batch 64 x 512 frames against (1) RefCRNN in
+    fp64, (2) RefCRNN in fp32 on stock torch / MIOpen ops, (3) the product's own module in eval() with every HIP pass off:
+    <= 1e-4 on the sigmoid outputs, <= 2e-5 of the peak on the pre-sigmoid activations (measured 6e-8 / 2.5e-7)."""
+    from oracle import crnn_parity as P
+    S, cfg, model, fe, wav, y, feats = setup
+    eng = S.InferenceEngine(model, fe, wav)
+    assert eng.hip_convs == 14 and eng.wino_convs == 12 and eng.fused_lstm   # every convolution of the forward is a HIP kernel
+    assert eng.graph_ok, eng.graph_error
+    replay = eng.replay().clone()                      # frontend (no bands: training=False) + forward, one graph launch
+    res = P.c3_parity(model, eng, feats, replay_out=replay)
+    print("c3 full size:", res)
+    assert res["ok"], res
+    assert res["replay_equals_eager"]                  # the captured kernels are the eager ones: same bits
+    # (3) the literal module, evaluated with the stock ops only
+    for flag in ("FUSED_BN_RELU", "FUSED_FC_BN", "FUSED_BN_POOL", "FUSED_CONV0", "FUSED_LSTM", "WINO_TRAIN", "WINO_TRAIN_WRW", "C32_TRAIN"):
+        monkeypatch.setattr(S, flag, False)
+    model.eval()
+    with torch.no_grad():
+        want = model(feats)
+    assert float((replay - want).abs().max()) <= P.BOUNDS["c3_sigmoid_abs"]
+
+
+def test_c4_train_step_full_size_matches_reference(setup):
+    """One training-mode forward / backward / AGC + clipvalue at batch 64 x 512 frames with every HIP pass on (Winograd forward,
+    backward-data and weight gradient, the 32 -> 32 MFMA kernel, BatchNorm / ReLU / MaxPool passes, first-layer recompute, LSTM
+    launches, fused AGC) against the fp64 RefCRNN taking the same ReLU / max-pool decisions: loss <= 1e-6, outputs <= 2e-5,
+    BatchNorm statistics <= 1e-6, EVERY gradient - raw and after AGC + clipvalue - <= 3e-5 of its peak (measured 2.0e-5 on the LSTM
+    biases, 1.2 - 1.8e-5 elsewhere; the stock fp32 layers read the same 1.2 - 1.9e-5 where no decision flips), biases in front
+    of a BatchNorm exactly zero; and the step is bit-reproducible at this size.  Without matching decisions BOTH this step and the
+    stock fp32 step sit 2.7e-2 from the fp64 step (profiles/r6/fullsize_parity.log): ~50 of the ~1e8 ReLU / pooling decisions
+    fall within rounding of their boundary, each worth ~1e-2 of a gradient peak - printed below for the record."""
+    from oracle import crnn_parity as P
+    S, cfg, model, fe, wav, y, feats = setup
+    assert S.FUSED_BN_RELU and S.FUSED_BN_POOL and S.FUSED_CONV0 and S.FUSED_LSTM and S.FUSED_FC_BN
+    assert S.WINO_TRAIN and S.WINO_TRAIN_WRW and S.C32_TRAIN
+    res = P.c4_parity(model, feats, y, clipvalue=cfg.clipvalue, unmatched=True, stock_fp32=True)
+    print("c4 full size:", res)
+    assert res["decisions"] == {"relu_masks": 19, "pool_maps": 5, "rederived_and_verified_bitwise": 5}
+    assert res["ok"], res
+    assert res["bit_reproducible"] or res["run_to_run_gradient_rel"] <= 1e-5, res
+
+
+def test_decision_matching_is_what_it_claims(dev):
+    """The checker itself, at a size where flips are rare: with the product's decisions the fp64 reference's loss and outputs stay
+    where its own decisions put them (the forced forward only differs on units within rounding of a boundary), and a WRONG
+    decision map is noticed - one pooling window per map taken from the wrong element moves the gradients far beyond the bound."""
+    from challenge_amd import sj_train as S
+    from challenge_amd.hip_autograd import record_activations
+    from oracle import crnn_parity as P, crnn_ref as R
+    S.configure_miopen()
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '64', '--n_frame', '128', '--n_chan', '1', '--batch_size', '4'])
+    torch.manual_seed(2)
+    model = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last).train()
+    x = torch.rand(4, 64, 128, 1, device=dev)
+    y = (torch.rand(4, 4, 3, device=dev) < 0.2).float()
+    td = {}
+    h = model.td.register_forward_hook(lambda m, i, o: td.__setitem__('z', o.detach()))
+    with record_activations() as acts:
+        out = model(x)
+    h.remove()
+    S.binary_crossentropy(y, out).backward()
+    d = R.Decisions(acts, td['z'])
+    assert len(d.conv_masks) == 14 and len(d.pool_slots) == 5 and len(d.fc_masks) == 4 and d.rederived == 5
+    ref = R.RefCRNN(64, 128, 1, 9).to(dev).double().load_from(model)
+    own = R.reference_step(ref, x, y)
+    ref2 = R.RefCRNN(64, 128, 1, 9).to(dev).double().load_from(model)
+    forced = R.reference_step(ref2, x, y, decisions=d)
+    assert abs(float(own['loss']) - float(forced['loss'])) <= 1e-6 and float((own['out'] - forced['out']).abs().max()) <= 2e-5
+    names = [n for n, _ in model.named_parameters()]
+    err = max(P._rel(p.grad, g) for n, p, g in zip(names, model.parameters(), forced['raw']) if not P._bn_fed_bias(n))
+    assert err <= P.BOUNDS["c4_gradient_rel"], err
+    # sabotage: every pooling map's first window takes its NEXT element
+    for s in d.pool_slots:
+        s[0, 0, 0, 0] = (s[0, 0, 0, 0] + 1) % 4
+    for m in d.conv_masks:
+        m[0, :8, 0, 0] = ~m[0, :8, 0, 0]
+    ref3 = R.RefCRNN(64, 128, 1, 9).to(dev).double().load_from(model)
+    bad = R.reference_step(ref3, x, y, decisions=d)
+    err_bad = max(P._rel(p.grad, g) for n, p, g in zip(names, model.parameters(), bad['raw']) if not P._bn_fed_bias(n))
+    assert err_bad > 10 * P.BOUNDS["c4_gradient_rel"], err_bad

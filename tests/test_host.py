@@ -630,3 +630,48 @@ def test_zero_pool_hands_out_zeros_and_keeps_gradients_apart():
     pool.begin_step(cpu)                                   # ... and the buffer grows; the old one is kept
     fresh = pool.take(10000, torch.float64, cpu)
     assert fresh.untyped_storage().data_ptr() != old and not fresh.any() and len(pool._old) >= 1
+
+
+def test_zero_pool_clears_what_a_graph_replay_dirtied():
+    """Advisor finding of round 5: a hipGraph replay writes into the prefix its capture took without the pool seeing a `take`.
+    Sequence: a capture-like step uses N elements and records its marks; a SMALLER eager step follows (high-water mark < N); the
+    graph replays (the prefix [0, N) is dirty again, reported by `mark_dirty`); the next step's `begin_step` must clear all of
+    [0, N), so that a larger take is all zero.  Without the marks only the smaller step's prefix would be cleared."""
+    import torch
+    from challenge_amd import sj_train as S
+    pool, cpu = S._ZeroPool(), torch.device("cpu")
+    pool.take(1024, torch.float64, cpu)
+    pool.begin_step(cpu)                                   # buffer of >= 4096 elements
+    a = pool.take(1000, torch.float64, cpu)                # "capture" of model A: 1000 elements
+    marks = pool.marks(cpu)
+    assert marks and list(marks.values())[0][1] == 1000
+    pool.begin_step(cpu)                                   # eager step of a smaller model C
+    c = pool.take(100, torch.float64, cpu)
+    c.fill_(1.0)
+    a.fill_(5.0)                                           # A replays: its whole prefix is dirty behind the pool's back ...
+    pool.mark_dirty(marks)                                 # ... and GraphedTrainStep.__call__ says so
+    pool.begin_step(cpu)
+    b = pool.take(2000, torch.float64, cpu)                # a larger model B (or A's eager fallback)
+    assert b.data_ptr() == a.data_ptr() and not b.any()
+    # a buffer that has been replaced since the capture is the graph's alone: marks for it change nothing
+    pool.take(100000, torch.float64, cpu)
+    pool.begin_step(cpu)                                   # grows: new buffer
+    pool.mark_dirty(marks)
+    key = next(iter(marks))
+    assert pool._state[key][1] == 0
+
+
+def test_zero_pool_demand_does_not_add_up_over_passes_outside_a_step():
+    """Advisor finding of round 5 (low): training-mode forward / backward passes outside train_step never called begin_step, so
+    the pool's demand added up over them and the next step allocated twice the SUM.  CustomModel.forward now opens a pool step
+    of its own for such a pass (host logic checked here through the bookkeeping a CPU pass leaves untouched: the hook is
+    GPU-only, so the rule is exercised on the pool directly)."""
+    import torch
+    from challenge_amd import sj_train as S
+    pool, cpu = S._ZeroPool(), torch.device("cpu")
+    for _ in range(50):                                    # 50 "passes", each its own step as forward now makes them
+        pool.begin_step(cpu)
+        pool.take(3000, torch.float64, cpu)
+    pool.begin_step(cpu)
+    key = (cpu.index, torch.float64, "scratch")
+    assert pool._state[key][0].numel() <= 2 * 3008 and len(pool._old) <= 1
