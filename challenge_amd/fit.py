@@ -252,37 +252,49 @@ class GraphedTrainStep:
         model.train()
         if SW.ZERO_POOL:
             _ZERO_POOL.begin_step(dev)
-        handles, works = [], []
+        handles, works, aliases = [], [], None
         if self.world:
-            # the exchange DDP's reducer would do, issued from inside the capture (see the class docstring)
+            # The exchange DDP's reducer would do, issued from inside the capture (see the class docstring).  The forward runs on
+            # ALIASES of the parameters - fresh leaves on the same storage (torch.func.functional_call): DDP's reducer keeps the
+            # real parameters' AccumulateGrad nodes alive, and those belong to the stream DDP was constructed on (the default
+            # stream, whose implicit synchronisation a capture forbids: a capture through them dies inside capture_end on this
+            # stack); an alias gets its node inside the capture, on the capture stream, like the parameters of a model without DDP.
             world, index, left = self.world, {}, [len(b) for b in self._buckets]
-            views = []
+            alias_of = {id(p): p.detach().requires_grad_(True) for p in model.parameters()}
+            aliases = {n: alias_of[id(p)] for n, p in model.named_parameters()}
+            views, alias_buckets = [], []
             for k, (bucket, flat) in enumerate(zip(self._buckets, self._flats)):
                 off, vs = 0, []
                 for p in bucket:
                     n = p.numel()
                     dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)
                     vs.append(flat[off:off + n].as_strided(p.shape, p.stride()) if dense else flat[off:off + n].view(p.shape))
-                    index[id(p)] = k
+                    index[id(alias_of[id(p)])] = k
                     off += n
                 views.append(vs)
+                alias_buckets.append([alias_of[id(p)] for p in bucket])
 
-            def ready(p):
-                k = index[id(p)]
+            def ready(a):
+                k = index[id(a)]
                 left[k] -= 1
                 if left[k]:
                     return
-                bucket, flat = self._buckets[k], self._flats[k]
-                torch._foreach_copy_(views[k], [q.grad for q in bucket])
+                flat = self._flats[k]
+                torch._foreach_copy_(views[k], [q.grad for q in alias_buckets[k]])
                 if world > 1:
                     flat.div_(world)          # DDP's order: divide, then sum over the ranks
-                for q, v in zip(bucket, views[k]):
+                for q, a_, v in zip(self._buckets[k], alias_buckets[k], views[k]):
                     q.grad = v                # AGC and the optimiser read (and AGC rewrites) the averaged gradients in place
+                    a_.grad = None            # the alias's own gradient goes back to the graph's pool
                 works.append(torch.distributed.all_reduce(flat, async_op=True))
-            handles = [p.register_post_accumulate_grad_hook(ready) for b in self._buckets for p in b]
+            handles = [a.register_post_accumulate_grad_hook(ready) for b in alias_buckets for a in b]
         was_in_step, _IN_STEP[0] = _IN_STEP[0], True
         try:
-            loss = model.loss_fn(self.y, model(self.x))   # the plain module: DDP's reducer stays out of the capture
+            if aliases is None:
+                out = model(self.x)
+            else:   # the plain module on the aliases: DDP's reducer stays out of the capture
+                out = torch.func.functional_call(model, aliases, (self.x,))
+            loss = model.loss_fn(self.y, out)
             loss.backward()
         finally:
             _IN_STEP[0] = was_in_step

@@ -30,3 +30,4 @@ extern "C" const char* wino_last_error(void) { return g_err; }
 #define IRIS_WINO_STANDALONE 1
 #include "../../challenge_amd/csrc/k_conv_wino.h"
 #include "../../challenge_amd/csrc/k_conv_wino_wrw.h"
+#include "../../challenge_amd/csrc/k_conv_wino_b3.h"

@@ -193,9 +193,16 @@ def _rccl_world1_worker(rank, port, out_dir):
     self_drift = max(_max_rel_diff(ps[i], ps[j])[0] for i in range(len(ps)) for j in range(i))
     drift, where = min(_max_rel_diff(_state(ddp_model), p_) for p_ in ps)
     assert drift <= max(1e-6, 4.0 * self_drift), (drift, where, self_drift)
-    # the calibration itself is capped (advisor finding, round 5): one flipped decision moves a parameter by about the learning
-    # rate (1e-3, relative to max|p| ~ 0.1 - 1); a calibration set that blew up must fail the test, not loosen it
-    assert self_drift <= 5e-2, self_drift
+    # the calibration itself is capped (advisor finding, round 5), in ABSOLUTE terms - the relative figure is dominated by tensors
+    # that start at zero (BatchNorm's beta: after 5 steps every value is O(learning rate), so two runs that took one decision
+    # differently are ~1 apart relative to max|p|): Adam moves a parameter by at most ~lr per step, so two correct runs cannot
+    # be further apart than 2 x 5 steps x lr; a calibration set beyond that must fail the test, not loosen it
+    params_only = [{n: v for n, v in st.items() if n in dict(plains[0].named_parameters())} for st in ps]
+    self_abs = max(float((params_only[i][n] - params_only[j][n]).abs().max()) for i in range(len(ps)) for j in range(i) for n in params_only[0])
+    assert self_abs <= 2 * 5 * 1e-3 * 1.05, self_abs
+    ddp_params = {n: p_.detach() for n, p_ in ddp_model.named_parameters()}
+    ddp_abs = min(max(float((ddp_params[n] - po[n]).abs().max()) for n in po) for po in params_only)
+    assert ddp_abs <= 2 * 5 * 1e-3 * 1.05, ddp_abs
     assert tables[-1] == tables[2] and tables[-1] <= 2, tables  # FusedAGC: no new table after the first steps
 
     # (4) `fit` on the real backend: epoch loss + plan status in one all-reduce, BatchNorm averaging, validation loss, stop flag
@@ -246,13 +253,36 @@ def _rccl_world1_worker(rank, port, out_dir):
         le = [float(e.train_step(b_)['loss']) for b_ in batches[:3]]
         lg = [float(gstep(b_)['loss']) for b_ in batches[:3]]
         torch.cuda.synchronize(device)
-        d_state, w_state = _max_rel_diff(_state(gm), _state(e))
-        graph_ddp[lr] = (max(abs(a - b_) for a, b_ in zip(le, lg)), d_state, w_state)
-        assert graph_ddp[lr][0] <= 1e-5 and d_state <= 1e-5, (lr, le, lg, d_state, w_state)
+        d_loss = max(abs(a - b_) for a, b_ in zip(le, lg))
+        assert d_loss <= 1e-5, (lr, le, lg)
         if lr == 0.0:
+            # same state at every step: BatchNorm statistics equal, parameters untouched, and the gradients the graph's own
+            # exchange left in its flat buckets (averaged, AGC + clipvalue applied in place) = what the eager step through
+            # DDP's reducer left in p.grad
+            d_state, w_state = _max_rel_diff(_state(gm), _state(e))
+            assert d_state <= 1e-5, (d_state, w_state)
             torch.manual_seed(0)
             init = S.get_model(cfg).to(device).to(memory_format=torch.channels_last)
             assert all(torch.equal(a, b_) for a, b_ in zip(init.parameters(), gm.parameters()))
+            eager_grads = {id(q): q.grad for q in e.parameters()}
+            pairs = dict(zip((id(q) for q in gm.parameters()), e.parameters()))
+            d_grad = 0.0
+            for bucket, flat in zip(gstep._buckets, gstep._flats):
+                off = 0
+                for q in bucket:
+                    want = pairs[id(q)].grad
+                    got = flat[off:off + q.numel()].as_strided(q.shape, q.stride())
+                    d_grad = max(d_grad, float((got - want).abs().max()) / (float(want.abs().max()) + 1e-12))
+                    off += q.numel()
+            assert d_grad <= 1e-4, d_grad
+            graph_ddp[lr] = (d_loss, d_state, d_grad)
+        else:
+            # both train; Adam's normalised update turns last-bit differences of near-zero gradients (the GEMMs' algorithm choice
+            # under capture) into steps of up to the learning rate on those elements: the parameters stay within a fraction of
+            # what ONE corrupted or missing bucket would cost (lr per element and step)
+            d_abs = max(float((a - b_).abs().max()) for a, b_ in zip(gm.parameters(), e.parameters()))
+            assert d_abs <= 0.1 * lr * 3, d_abs
+            graph_ddp[lr] = (d_loss, d_abs)
     # `fit` picks the graph by default under DDP over RCCL, and one epoch leaves the same collectives as before + the capture's
     calls2 = {"replays": 0}
     real_call = S.GraphedTrainStep.__call__

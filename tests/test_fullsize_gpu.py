@@ -68,9 +68,10 @@ def test_c4_train_step_full_size_matches_reference(setup):
     """One training-mode forward / backward / AGC + clipvalue at batch 64 x 512 frames with every HIP pass on (Winograd forward,
     backward-data and weight gradient, the 32 -> 32 MFMA kernel, BatchNorm / ReLU / MaxPool passes, first-layer recompute, LSTM
     launches, fused AGC) against the fp64 RefCRNN taking the same ReLU / max-pool decisions: loss <= 1e-6, outputs <= 2e-5,
-    BatchNorm statistics <= 1e-6, EVERY gradient - raw and after AGC + clipvalue - <= 3e-5 of its peak (measured 2.0e-5 on the LSTM
-    biases, 1.2 - 1.8e-5 elsewhere; the stock fp32 layers read the same 1.2 - 1.9e-5 where no decision flips), biases in front
-    of a BatchNorm exactly zero; and the step is bit-reproducible at this size.  Without matching decisions BOTH this step and the
+    BatchNorm statistics <= 1e-6, EVERY gradient <= 5e-5 of its peak (measured 2.0e-5 on the LSTM biases, 1.2 - 1.8e-5 elsewhere;
+    the stock fp32 layers read the same 1.2 - 1.9e-5 where no decision flips), the AGC + clipvalue launch on those gradients
+    <= 2e-6 against the fp64 restatement of sj_train.py:145-155, biases in front of a BatchNorm exactly zero; and the step is
+    bit-reproducible at this size.  Without matching decisions BOTH this step and the
     stock fp32 step sit 2.7e-2 from the fp64 step (profiles/r6/fullsize_parity.log): ~50 of the ~1e8 ReLU / pooling decisions
     fall within rounding of their boundary, each worth ~1e-2 of a gradient peak - printed below for the record."""
     from oracle import crnn_parity as P
