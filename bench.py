@@ -286,6 +286,51 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
     # max-pool decisions (oracle/crnn_parity.py; why decisions must be matched at this size: oracle.crnn_ref.Decisions)
     c4_parity = checker_leg(lambda P: P.c4_parity(model, fe(wav), y, clipvalue=cfg.clipvalue))
 
+    # opt-in (IRIS_WINO_SPLIT_BF16): the same c3 forward and c4 step with blocks 2-5 on the BF16 matrix cores - both operands of
+    # the Winograd GEMMs split into three bf16 terms, six partial products accumulated in fp32 (k_conv_wino_b3.h) - with their own
+    # parity legs under the bounds of the exact-fp32 kernels.  The headline c3 / c4 above stay on the exact-fp32 kernels.
+    split = None
+    try:
+        was = S.WINO_SPLIT_BF16
+        S.WINO_SPLIT_BF16 = True
+        infer3 = S.InferenceEngine(model, fe, wav)
+        t3_eager = timed(infer3.eager, steps)
+        t3_graph = timed(infer3.replay, steps) if infer3.graph_ok else None
+
+        def c3_split_leg(P):
+            rep = infer3.replay().clone() if infer3.graph_ok else None
+            feats = fe.plan.wav_to_logmel(wav, minmax=fe.do_minmax, log=True, t_bands=infer3._tb, f_bands=infer3._fb)
+            return P.c3_parity(model, infer3, feats, replay_out=rep)
+        p3 = checker_leg(c3_split_leg)
+        t4 = timed(train, steps)
+        g4 = None
+        if world == 1:
+            gm = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+            gm.load_state_dict(model.state_dict())
+            gm.compile(S.make_optimizer(cfg, gm.parameters(), capturable=True), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+            gs = S.GraphedTrainStep(gm, (fe(wav), y))
+            g4 = timed(lambda: gs((fe(wav), y)), steps)
+            del gs, gm
+        p4 = checker_leg(lambda P: P.c4_parity(model, fe(wav), y, clipvalue=cfg.clipvalue, unmatched=False))
+        best3 = min(t for t in (t3_eager, t3_graph) if t is not None)
+        split = {"what": "blocks 2-5 (12 layers forward; in training forward + backward-data) as Winograd F(2x2, 3x3) with the GEMMs on "
+                         "v_mfma_f32_32x32x16_bf16: every fp32 operand = the exact sum of three bf16 terms, 6 of the 9 partial products "
+                         "(all down to 2^-24) accumulated in fp32; error against fp64 0.65 - 1.14x the exact-fp32 kernel's per layer "
+                         "(profiles/r6/wino_b3_check.log); opt-in: IRIS_WINO_SPLIT_BF16=1",
+                 "c3_split_bf16": {"ms_per_step_eager": round(1e3 * t3_eager, 3),
+                                   "ms_per_step_hipgraph": None if t3_graph is None else round(1e3 * t3_graph, 3),
+                                   "audio_s_per_s": round(world * audio_s / best3, 1), "split_bf16_convolutions": infer3.split_bf16_convs,
+                                   "parity": p3},
+                 "c4_split_bf16": {"ms_per_step": round(1e3 * t4, 3), "ms_per_step_hipgraph": None if g4 is None else round(1e3 * g4, 3),
+                                   "audio_s_per_s": round(world * audio_s / (min(t4, g4) if g4 else t4), 1), "parity": p4}}
+        del infer3
+    except Exception as exc:   # an opt-in extra never takes the line down
+        import traceback
+        traceback.print_exc()
+        split = {"error": repr(exc)[:300]}
+    finally:
+        S.WINO_SPLIT_BF16 = was
+
     # input side of the reference's own training loop (spectra in, sj_train.py:74-130) at its default
     # shape: whole batches synthesised on the device (iris_mix_specs + mel kernel with bands)
     dbatch = 64
@@ -369,6 +414,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
                           "parity": c4_parity,
                           "hipgraph": graphed, "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if ddp is not None else "none", "device_ms_per_phase": breakdown,
                           "allreduce": comm},
+        "split_bf16_matrix_cores": split,
         "autocast_bf16_smoke_stock_ops": bf16,
         # whether the c3 / c4 numbers above ran on the shipped, tuned MIOpen perf-db or on this build's own defaults
         "miopen_db": S.miopen_db_status(),
@@ -924,6 +970,10 @@ def main():
     if extras and not args.only_sweep:  # the c3 / c4 checker legs count like the c2 one: a failed leg is a failed run
         for key in ("c3_frontend_specaug_crnn_fwd", "c4_train_step"):
             leg = (extras.get(key) or {}).get("parity")
+            if leg is not None:
+                parity_ok.append(bool(leg.get("ok")))
+        for key in ("c3_split_bf16", "c4_split_bf16"):
+            leg = ((extras.get("split_bf16_matrix_cores") or {}).get(key) or {}).get("parity")
             if leg is not None:
                 parity_ok.append(bool(leg.get("ok")))
     finish(extras)

@@ -64,6 +64,9 @@ SIGNATURES = {
     "iris_wino_pack_weights": (_i, [_vp, _i, _i, _vp]),
     "iris_wino_pack_weights_device": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _vp, _vp]),
     "iris_conv3x3_wino": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "iris_wino_b3_packed_len": (_sz, [_i, _i]),
+    "iris_wino_b3_pack_weights_device": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _vp, _vp]),
+    "iris_conv3x3_wino_b3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "iris_wino_wrw_workspace_len": (_sz, [_i, _i, _i, _i, _i]),
     "iris_conv3x3_wino_wrw": (_i, [_vp, _vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "iris_conv0_dweight_len": (_sz, [_i, _i]),

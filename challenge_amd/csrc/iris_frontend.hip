@@ -20,6 +20,7 @@
 //   k_conv_c32.h     the 32 -> 32 convolution of block 1 on the fp32 matrix cores, bias + ReLU (+ MaxPool) fused (inference)
 //   k_conv_wino.h    blocks 2-5 (64 ... 512 channels) as Winograd F(2x2, 3x3) on the fp32 matrix cores (inference; the training
 //                    step's forward and backward-data passes)
+//   k_conv_wino_b3.h   the same convolution on the BF16 matrix cores at fp32 accuracy: three-term split of both operands (opt-in)
 //   k_conv_wino_wrw.h  the same layers' weight gradient as Winograd F(2x2, 3x3) on the fp32 matrix cores (training)
 //   host_plan.h      mel matrix, constant tables, plan create / destroy
 //   host_ops.h       the operators' C-ABI entry points
@@ -39,4 +40,5 @@
 #include "k_conv0_bn.h"
 #include "k_conv_c32.h"
 #include "k_conv_wino.h"
+#include "k_conv_wino_b3.h"
 #include "k_conv_wino_wrw.h"

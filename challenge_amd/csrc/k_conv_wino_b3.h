@@ -36,6 +36,12 @@ typedef unsigned b3_u32x4 __attribute__((ext_vector_type(4)));
 // (f32x16 comes from common.h in the library build)
 #endif
 
+// timing experiments only (results wrong when non-zero): 1 no U loads / waits in the K loop, 2 no preparation (row stage, column
+// stage, split), 4 no MFMAs, 8 no barrier / LDS-DMA in the K loop
+#ifndef IRIS_B3_ABLATE
+#define IRIS_B3_ABLATE 0
+#endif
+#define B3_ABL(bit) ((IRIS_B3_ABLATE & (bit)) != 0)
 constexpr int kB3KC = 16;                       // input channels per chunk = one K-step of v_mfma_f32_32x32x16_bf16
 constexpr int kB3Rows = 4 * 4;                  // staged pixel rows per chunk at most: 4 per strip, up to 4 strips (TC = 16)
 constexpr int kB3BufSlots = 2304;               // 16-byte pieces per chunk buffer (>= 16 rows x 4 quarters x 2 parities x 17; 36 KiB)
@@ -138,6 +144,24 @@ extern "C" int iris_wino_b3_pack_weights_device(const float* weight, long stride
     return IRIS_OK;
 }
 
+#ifdef IRIS_B3_STAMPS
+// timing experiments only: wave 0 of every workgroup records (s_memrealtime [100 MHz], s_memtime [shader clock]) at six points of its
+// FIRST two work items into this buffer: [workgroup][item 2][point 6][2]
+__device__ unsigned long long g_b3_stamps[256 * 2 * 6 * 2];
+extern "C" int iris_b3_read_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_b3_stamps), sizeof(g_b3_stamps));
+}
+#define B3_STAMP(item, point)                                                                                  \
+    do {                                                                                                       \
+        if (tid == 0 && (item) < 2 && blockIdx.x < 256) {                                                      \
+            g_b3_stamps[((blockIdx.x * 2 + (item)) * 6 + (point)) * 2 + 0] = __builtin_amdgcn_s_memrealtime(); \
+            g_b3_stamps[((blockIdx.x * 2 + (item)) * 6 + (point)) * 2 + 1] = __builtin_amdgcn_s_memtime();     \
+        }                                                                                                      \
+    } while (0)
+#else
+#define B3_STAMP(item, point) do { } while (0)
+#endif
+
 // ---- the convolution --------------------------------------------------------------------------------------------------------
 template <bool POOL, int TC, bool IN_NHWC>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restrict__ x, const uint4* __restrict__ u3,
@@ -161,34 +185,58 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
     const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float row_sign = xi == 1 ? 1.f : -1.f;
 
-    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+    int item = 0;
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x, ++item) {
         const int cb = work % cout_blocks, blk = work / cout_blocks;
         const int cbk = blk % col_blocks, rbk = blk / col_blocks;
         const int R0 = rbk * TR, tc0 = cbk * TC;
+        B3_STAMP(item, 0);
         // ---- this lane's LDS-DMA pieces: slot i = 64 (4 k + xi) + lane of a chunk buffer, the same for every chunk -------------
+        // per strip (uniform): image, tile row, does the strip exist - ONE integer division per strip and work item
+        int s_b[TR], s_th[TR];
+        bool s_ok[TR];
+#pragma unroll
+        for (int st = 0; st < TR; ++st) {
+            const int R = R0 + st;
+            s_b[st] = R / TH;
+            s_th[st] = R - s_b[st] * TH;
+            s_ok[st] = R < n_rows;
+        }
         unsigned poff[kDma];
         unsigned long long pmask[kDma];
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
         __syncthreads();   // every wave has left the previous work item's exchange
 #pragma unroll
         for (int k = 0; k < kDma; ++k) {
-            const int i = 64 * (4 * k + xi) + lane;
+            // slot i = 64 (4 k + xi) + lane of a chunk buffer -> (pixel column, patch row, strip, channel quarter): re-derived per
+            // work item from an OPAQUE lane id - the first version let the compiler hoist the decode out of the work loop, where the
+            // K loop's register demand spilled it: 119 scratch reloads, each waited for, = 16 us per work item
+            const int i = 64 * (4 * k + xi) + lane_o;
             const int pxh = i % PH, t1 = i / PH, par = t1 & 1, q = (t1 >> 1) & 3, r = t1 >> 3;
-            const int strip = r >> 2, pr = r & 3, px = 2 * pxh + par;
-            const int R = R0 + strip, b_ = R / TH, th = R - b_ * TH;
+            const int px = 2 * pxh + par, pr = r & 3, strip = (r >> 2) & 3;
+            const unsigned d = i < kSlots ? 1u << 14 : 0u;
+            int b_ = s_b[0], th = s_th[0];
+            bool sok = s_ok[0];
+#pragma unroll
+            for (int st = 1; st < TR; ++st)
+                if (strip == st) b_ = s_b[st], th = s_th[st], sok = s_ok[st];
             const int hh = 2 * th - 1 + pr, ww = 2 * tc0 - 1 + px;
-            const bool ok = i < kSlots && R < n_rows && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            // channel 4 q + {0..3} of the chunk's 16: plane q >> 1, floats 4 (q & 1) .. + 3 of the pixel's 8
-            poff[k] = !ok ? 0u : IN_NHWC ? ((unsigned)(((size_t)b_ * H + hh) * W + ww) * (unsigned)Cin + 4u * q) * 4u
-                                         : ((unsigned)((((size_t)b_ * (Cin / 8) + (q >> 1)) * H + hh) * W + ww) * 8u + 4u * (q & 1)) * 4u;
+            const bool ok = (d >> 14) && sok && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            // channel 4 q + {0..3} of the chunk's 16: plane q >> 1, floats 4 (q & 1) .. + 3 of the pixel's 8 (32-bit arithmetic:
+            // the host side keeps the tensor below 2^30 elements)
+            const unsigned pix = (unsigned)hh * (unsigned)W + (unsigned)ww;
+            poff[k] = !ok ? 0u : IN_NHWC ? (((unsigned)b_ * (unsigned)H * (unsigned)W + pix) * (unsigned)Cin + 4u * q) * 4u
+                                         : ((((unsigned)b_ * (unsigned)(Cin / 8) + (unsigned)(q >> 1)) * (unsigned)H * (unsigned)W + pix) * 8u + 4u * (q & 1)) * 4u;
             pmask[k] = __ballot(ok);
             if (!ok && i < kB3BufSlots) {   // out-of-image pixels: zero in all three buffers, never requested
 #pragma unroll
                 for (int bf = 0; bf < kB3Bufs; ++bf) reinterpret_cast<float4*>(b3_lds)[bf * kB3BufSlots + i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        auto dma_x = [&](int chunk) {
+        auto dma_into = [&](int bufi, int chunk) {   // this wave's pieces of `chunk` into chunk buffer `bufi`
             const float* xc = x + (size_t)chunk * (IN_NHWC ? (size_t)kB3KC : 2 * plane);   // uniform
-            const unsigned base = lds0 + (unsigned)((chunk % kB3Bufs) * kB3BufSlots * 16);
+            const unsigned base = lds0 + (unsigned)(bufi * kB3BufSlots * 16);
 #pragma unroll
             for (int k = 0; k < kDma; ++k) wino_dma16_gather(xc, poff[k], pmask[k], base + 1024u * (4 * k + xi));
         };
@@ -224,90 +272,176 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zeros are in place before a request can land beside them
         __syncthreads();
-        dma_x(0);
-        if (n_chunks > 1) dma_x(1);
+        // ================= the K loop: a software pipeline written out as SLOTS ==================================================
+        // One wave per SIMD: nothing but this wave's own instruction order hides anything.  A chunk (16 input channels) is four
+        // BLOCKS, one per position of this wave's row in the order nu = 0, 3, 1, 2; a block is 24 slots, each ONE MFMA of the
+        // current position (operands av[cur], ub[cur]) followed by its share of the NEXT position's preparation - column stage and
+        // three-term split into av[cur ^ 1], 13 instructions per channel pair - fenced by a scheduling barrier:
+        //   block 0 (nu 0): + row stage of this chunk's patch columns 1, 3 (16 LDS reads, 32 FMAs), prepares nu 3 (columns 1, 3)
+        //   block 1 (nu 3): prepares nu 1 (columns 1, 2)          block 2 (nu 1): prepares nu 2 (columns 1, 2)
+        //   block 3 (nu 2): the workgroup barrier for chunk + 1's staged input, its LDS-DMA request for chunk + 3, the row stage
+        //                   of chunk + 1's columns 0, 2 (w of this chunk is dead by now) and nu 0 of chunk + 1
+        // U of the next position is requested at the top of every block, one block (~0.4 us) ahead.  Vector-memory requests
+        // complete in order, every count below is static: past the last chunk the requests repeat the last chunk (valid memory,
+        // unused results) instead of being skipped.
+        float w[2][4][8];
+        unsigned av[2][2][3][4];
         b3_u32x4 ub[2][2][3];   // [buffer][channel block][term]
-        load_u(ub[0], 0, 0);
-
-        for (int chunk = 0; chunk < n_chunks; ++chunk) {
-            // the chunk's own pieces have landed (requests of chunk + 1 may still be in flight), then everybody's
-            if (chunk + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma + 6) : "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __syncthreads();
-            // Order of this wave's vector-memory requests from here (they complete in order): U(chunk, 3), DMA(chunk + 2), U(chunk, 1),
-            // U(chunk, 2), U(chunk + 1, 0) - each U is waited for with exactly the younger requests left outstanding, so the DMA
-            // is only forced to land half a chunk after it was issued.
-            load_u(ub[1], chunk, 3);
-            const bool more = chunk + 2 < n_chunks;
-            if (more) dma_x(chunk + 2);   // into the buffer chunk - 1 used: every wave has passed its reads
-            const float4* const buf = reinterpret_cast<const float4*>(b3_lds) + (chunk % kB3Bufs) * kB3BufSlots;
-            // ---- row stage: w[tb][c][8] = d[ra][c] -/+ d[rb][c] for the lane's 8 channels
-            float w[2][4][8];
+        float raw[4][4];        // [(column a, row ra), (a, rb), (column b, ra), (b, rb)][4 channels]: one group's reads
+        float pv0 = 0.f, pv1 = 0.f, pf0 = 0.f, pf1 = 0.f, pr0 = 0.f, pr1 = 0.f;
+        // float4 index of (row ra / rb, this lane's quarter pair, tile column) in a chunk buffer, per tile block
+        unsigned la[2], lb[2];
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
+        for (int tb = 0; tb < 2; ++tb) {
+            la[tb] = (unsigned)((((4 * t_strip[tb] + ra) * 4 + 2 * hl) * 2) * PH + t_col[tb]);
+            lb[tb] = (unsigned)((((4 * t_strip[tb] + rb) * 4 + 2 * hl) * 2) * PH + t_col[tb]);
+        }
+        const float4* const lds4 = reinterpret_cast<const float4*>(b3_lds);
+        auto col_value = [&](int nu, int tb, int ch) {
+            return nu == 0 ? w[tb][0][ch] - w[tb][2][ch] : nu == 1 ? w[tb][1][ch] + w[tb][2][ch]
+                 : nu == 2 ? w[tb][2][ch] - w[tb][1][ch] : w[tb][1][ch] - w[tb][3][ch];
+        };
+        // one of the 13 instructions that turn channels (2 k, 2 k + 1) of position `nu` into three packed bf16 pairs
+        auto unit_op = [&](int dst, int nu, int tb, int k, int o) {
+            unsigned(&t)[3][4] = av[dst][tb];
+            if (o == 0) pv0 = col_value(nu, tb, 2 * k);
+            else if (o == 1) pv1 = col_value(nu, tb, 2 * k + 1);
+            else if (o == 2) t[0][k] = b3_cvt_pk(pv0, pv1);
+            else if (o == 3) pf0 = __uint_as_float(t[0][k] << 16);
+            else if (o == 4) pf1 = __uint_as_float(t[0][k] & 0xffff0000u);
+            else if (o == 5) pr0 = pv0 - pf0;
+            else if (o == 6) pr1 = pv1 - pf1;
+            else if (o == 7) t[1][k] = b3_cvt_pk(pr0, pr1);
+            else if (o == 8) pf0 = __uint_as_float(t[1][k] << 16);
+            else if (o == 9) pf1 = __uint_as_float(t[1][k] & 0xffff0000u);
+            else if (o == 10) pv0 = pr0 - pf0;
+            else if (o == 11) pv1 = pr1 - pf1;
+            else t[2][k] = b3_cvt_pk(pv0, pv1);
+        };
+        // group g = (tile block g >> 1, channel half g & 1) of a row stage over patch columns (ca, cb): four reads ...
+        auto group_reads = [&](const float4* buf, int g, int ca, int cb_) {
+            const int tb = g >> 1, h = g & 1;
+            const int oa = (h * 2 + (ca & 1)) * PH + (ca >> 1), ob = (h * 2 + (cb_ & 1)) * PH + (cb_ >> 1);
+            const float4 r0 = buf[la[tb] + oa], r1 = buf[lb[tb] + oa], r2 = buf[la[tb] + ob], r3 = buf[lb[tb] + ob];
+            raw[0][0] = r0.x, raw[0][1] = r0.y, raw[0][2] = r0.z, raw[0][3] = r0.w;
+            raw[1][0] = r1.x, raw[1][1] = r1.y, raw[1][2] = r1.z, raw[1][3] = r1.w;
+            raw[2][0] = r2.x, raw[2][1] = r2.y, raw[2][2] = r2.z, raw[2][3] = r2.w;
+            raw[3][0] = r3.x, raw[3][1] = r3.y, raw[3][2] = r3.z, raw[3][3] = r3.w;
+        };
+        // ... and eight FMAs: w = d[ra] +/- d[rb]
+        auto group_fma = [&](int g, int ca, int cb_, int i) {
+            const int tb = g >> 1, h = g & 1, col = (i >> 2) ? cb_ : ca, e = i & 3;
+            w[tb][col][4 * h + e] = fmaf(raw[2 * (i >> 2) + 1][e], row_sign, raw[2 * (i >> 2)][e]);
+        };
+        auto mfma_slot = [&](int cur, int nu, int j) {
+            const int pr = j >> 2, tb = (j >> 1) & 1, nb = j & 1;
+            const int ta = pr == 0 ? 2 : (pr == 1 || pr == 3) ? 1 : 0;               // (2,0) (1,1) (0,2) (1,0) (0,1) (0,0): small terms first
+            const int tu = pr == 0 ? 0 : pr == 1 ? 1 : pr == 2 ? 2 : pr == 3 ? 0 : pr == 4 ? 1 : 0;
+            if (!B3_ABL(4))
+                acc[nu][tb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(b3_bf16x8, b3_u32x4{av[cur][tb][ta][0], av[cur][tb][ta][1], av[cur][tb][ta][2], av[cur][tb][ta][3]}),
+                    __builtin_bit_cast(b3_bf16x8, ub[cur][nb][tu]), acc[nu][tb][nb], 0, 0, 0);
+        };
+        // a HEAVY block: 24 MFMAs of (cur, nu) beside a row stage over columns (ca, cb) of `buf` + the preparation of nu_next:
+        // 4 groups x (8 FMAs + 2 units x 13) = 136 instructions over slots 1 .. 23, the reads of group g one group ahead
+        auto heavy_block = [&](int cur, int nu, int nu_next, const float4* buf, int ca, int cb_, auto pre_slot1) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int pxh = t_col[tb] + (c >> 1), par = c & 1;
+            for (int j = 0; j < 24; ++j) {
+                mfma_slot(cur, nu, j);
+                if (j == 0) pre_slot1();
+                if (j == 0 && !B3_ABL(2)) group_reads(buf, 0, ca, cb_);
+                if (j == 5 && !B3_ABL(2)) group_reads(buf, 1, ca, cb_);
+                if (j == 11 && !B3_ABL(2)) group_reads(buf, 2, ca, cb_);
+                if (j == 17 && !B3_ABL(2)) group_reads(buf, 3, ca, cb_);
+                if (j >= 1 && !B3_ABL(2)) {
+                    const int lo = (136 * (j - 1)) / 23, hi = (136 * j) / 23;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int q = 2 * hl + h;
-                        const float4 a = buf[(((4 * t_strip[tb] + ra) * 4 + q) * 2 + par) * PH + pxh];
-                        const float4 b = buf[(((4 * t_strip[tb] + rb) * 4 + q) * 2 + par) * PH + pxh];
-                        w[tb][c][4 * h + 0] = fmaf(b.x, row_sign, a.x);   // a + b (xi 1) or a - b: exact either way
-                        w[tb][c][4 * h + 1] = fmaf(b.y, row_sign, a.y);
-                        w[tb][c][4 * h + 2] = fmaf(b.z, row_sign, a.z);
-                        w[tb][c][4 * h + 3] = fmaf(b.w, row_sign, a.w);
+                    for (int o = lo; o < hi; ++o) {
+                        const int g = o / 34, q = o % 34;
+                        if (q < 8) group_fma(g, ca, cb_, q);
+                        else unit_op(cur ^ 1, nu_next, g >> 1, 2 * (g & 1) + (q - 8) / 13, (q - 8) % 13);
                     }
                 }
-            // ---- per position: column stage, split, 24 MFMAs; the next position's U is requested one position ahead
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int nu = s == 0 ? 0 : (s == 1 ? 3 : (s == 2 ? 1 : 2));      // columns 0 and 3 retire first
-                const int nu_next = s == 0 ? 3 : (s == 1 ? 1 : (s == 2 ? 2 : 0));
-                const int cur = s & 1;
-                if (s == 1 || s == 2) load_u(ub[cur ^ 1], chunk, nu_next);
-                else if (s == 3 && chunk + 1 < n_chunks) load_u(ub[cur ^ 1], chunk + 1, 0);
-                unsigned av[2][3][4];
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        v[j] = nu == 0 ? w[tb][0][j] - w[tb][2][j] : nu == 1 ? w[tb][1][j] + w[tb][2][j]
-                             : nu == 2 ? w[tb][2][j] - w[tb][1][j] : w[tb][1][j] - w[tb][3][j];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) b3_split_pair(v[2 * k], v[2 * k + 1], av[tb][0][k], av[tb][1][k], av[tb][2][k]);
-                }
-                // U of this position must have arrived; younger than it: s 0: U(chunk, 3) + the DMA, s 1: the DMA + U(chunk, 1),
-                // s 2: U(chunk, 2), s 3: U(chunk + 1, 0) if there is one
-                if (s <= 1) {
-                    if (more) B3_WAIT_U(kDma + 6, ub[cur]);
-                    else B3_WAIT_U(6, ub[cur]);
-                } else if (s == 2 || chunk + 1 < n_chunks) {
-                    B3_WAIT_U(6, ub[cur]);
-                } else {
-                    B3_WAIT_U(0, ub[cur]);
-                }
-                // six products per (tile block, channel block), small terms first
-#pragma unroll
-                for (int pr = 0; pr < 6; ++pr) {
-                    const int ta = pr == 0 ? 2 : (pr == 1 || pr == 3) ? 1 : 0;               // (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)
-                    const int tbt = pr == 0 ? 0 : pr == 1 ? 1 : pr == 2 ? 2 : pr == 3 ? 0 : pr == 4 ? 1 : 0;
-#pragma unroll
-                    for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb)
-                            acc[nu][tb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(b3_bf16x8, b3_u32x4{av[tb][ta][0], av[tb][ta][1], av[tb][ta][2], av[tb][ta][3]}),
-                                                                                      __builtin_bit_cast(b3_bf16x8, ub[cur][nb][tbt]),
-                                                                                      acc[nu][tb][nb], 0, 0, 0);
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        // a LIGHT block: 24 MFMAs beside the preparation of nu_next alone: 8 units x 13 = 104 instructions over 24 slots
+        auto light_block = [&](int cur, int nu, int nu_next) {
+#pragma unroll
+            for (int j = 0; j < 24; ++j) {
+                mfma_slot(cur, nu, j);
+                const int lo = (104 * j) / 24, hi = (104 * (j + 1)) / 24;
+#pragma unroll
+                for (int o = lo; o < hi; ++o)
+                    if (!B3_ABL(2)) unit_op(cur ^ 1, nu_next, (o / 13) >> 2, (o / 13) & 3, o % 13);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto chunk_buf = [&](int chunk) { return lds4 + (chunk % kB3Bufs) * kB3BufSlots; };
+        auto clamp_chunk = [&](int chunk) { return chunk < n_chunks ? chunk : n_chunks - 1; };
+
+        // ---- prologue of the work item (not overlapped): three chunks requested, chunk 0 staged, its columns 0, 2 and nu 0 prepared
+        // (a chunk beyond the last repeats the last one, into a buffer nobody reads; U(0, 0) sits between the requests of chunks 1
+        // and 2 so that block 0 of chunk 0 finds the order every other chunk has: U(chunk, 0), one DMA, U(chunk, 3))
+        dma_into(0, 0);
+        dma_into(1, clamp_chunk(1));
+        load_u(ub[0], 0, 0);
+        dma_into(2, clamp_chunk(2));
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kDma + 6) : "memory");
+        __syncthreads();
+        {
+            const float4* buf = chunk_buf(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                group_reads(buf, g, 0, 2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) group_fma(g, 0, 2, i);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int o = 0; o < 13; ++o) unit_op(0, 0, u >> 2, u & 3, o);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        B3_STAMP(item, 1);
+
+        for (int chunk = 0; chunk < (B3_ABL(16) ? 0 : n_chunks); ++chunk) {
+            const float4* const buf = chunk_buf(chunk);
+            // block 0: nu 0 (av[0], ub[0]); columns 1, 3 of this chunk; prepares nu 3 into av[1]
+            if (!B3_ABL(1)) load_u(ub[1], chunk, 3);
+            if (!B3_ABL(1)) B3_WAIT_U(kDma + 6, ub[0]);   // younger than U(chunk, 0): the DMA of block 3 of the previous chunk (or the prologue's) + U(chunk, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            heavy_block(0, 0, 3, buf, 1, 3, [] {});
+            // block 1: nu 3; prepares nu 1 into av[0]
+            if (!B3_ABL(1)) load_u(ub[0], chunk, 1);
+            if (!B3_ABL(1)) B3_WAIT_U(6, ub[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            light_block(1, 3, 1);
+            // block 2: nu 1; prepares nu 2 into av[1]
+            if (!B3_ABL(1)) load_u(ub[1], chunk, 2);
+            if (!B3_ABL(1)) B3_WAIT_U(6, ub[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            light_block(0, 1, 2);
+            // block 3: nu 2; chunk + 1: barrier, DMA of chunk + 3, columns 0, 2, nu 0 into av[0]
+            if (!B3_ABL(1)) load_u(ub[0], clamp_chunk(chunk + 1), 0);
+            if (!B3_ABL(1)) B3_WAIT_U(6, ub[1]);          // (everything older has landed too: this wave's pieces of chunk + 1 and chunk + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            const int c3 = clamp_chunk(chunk + 3);
+            heavy_block(1, 2, 0, chunk_buf(chunk + 1), 0, 2, [&] {
+                if (B3_ABL(8)) return;
+                __syncthreads();          // chunk + 1's staged input is complete; every wave has left the buffer chunk + 3 goes into
+                dma_into((chunk + 3) % kB3Bufs, c3);
+            });
+        }
+        B3_STAMP(item, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated requests past the last chunk have landed: the exchange overlays them
 
         // ---- output transform.  Column half in registers: s_j = sum_nu M[xi][nu] A[nu][j]: j 0: m0 + m1 + m2, j 1: m1 - m2 - m3
+        if (B3_ABL(32)) continue;
         __syncthreads();   // every wave has finished reading the chunk buffers: the exchange area overlays them
         float* const exch = b3_lds;   // [xi][j][block = 2 nb + tb][r / 4][lane][4]
+        int lane_e = lane;             // opaque: the exchange's per-lane addresses are formed here, not above the K loop (and spilled)
+        asm volatile("" : "+v"(lane_e));
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -325,14 +459,18 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
                         p1[e] = m1 - m2 - m3;
                     }
                     const int blkid = 2 * nb + tb;
-                    reinterpret_cast<float4*>(exch)[(((xi * 2 + 0) * 4 + blkid) * 4 + rq) * 64 + lane] = s0;
-                    reinterpret_cast<float4*>(exch)[(((xi * 2 + 1) * 4 + blkid) * 4 + rq) * 64 + lane] = s1;
+                    reinterpret_cast<float4*>(exch)[(((xi * 2 + 0) * 4 + blkid) * 4 + rq) * 64 + lane_e] = s0;
+                    reinterpret_cast<float4*>(exch)[(((xi * 2 + 1) * 4 + blkid) * 4 + rq) * 64 + lane_e] = s1;
                 }
+        B3_STAMP(item, 3);
         __syncthreads();
+        B3_STAMP(item, 4);
         // ---- wave w finishes block w: row half Y[0][j] = s0 + s1 + s2, Y[1][j] = s1 - s2 - s3; lane = output channel, r = tile
         {
+            int li_o = li, hl_o = hl;   // opaque: keeps the epilogue's lane-dependent offsets from being hoisted above the K loop (and spilled)
+            asm volatile("" : "+v"(li_o), "+v"(hl_o));
             const int tb = xi & 1, nb = xi >> 1, blkid = xi;
-            const int co = cb * 64 + 32 * nb + li;
+            const int co = cb * 64 + 32 * nb + li_o;
             const float bj = bias ? bias[co] : 0.f;
             const float floor_ = relu ? 0.f : -INFINITY;
             const int Ho = POOL ? TH : H, Wo = POOL ? TW : W;
@@ -343,11 +481,11 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) sv[a][j] = reinterpret_cast<const float4*>(exch)[(((a * 2 + j) * 4 + blkid) * 4 + rq) * 64 + lane];
+                    for (int j = 0; j < 2; ++j) sv[a][j] = reinterpret_cast<const float4*>(exch)[(((a * 2 + j) * 4 + blkid) * 4 + rq) * 64 + lane_e];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * rq + e;
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hl;         // tile li' of the block held by register r of this lane
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hl_o;       // tile li' of the block held by register r of this lane
                     float o[2][2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -356,11 +494,12 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
                         o[0][j] = a0 + a1 + a2;
                         o[1][j] = a1 - a2 - a3;
                     }
-                    const int strip = TC >= 64 ? 0 : (TC == 32 ? tb : 2 * tb + (row >> 4));
+                    // (row >> 4 = r >> 3 for every lane: the strip of register r is uniform, only the tile column depends on hl)
+                    const int strip = TC >= 64 ? 0 : (TC == 32 ? tb : 2 * tb + (r >> 3));
                     const int tcol = TC >= 64 ? 32 * tb + row : (TC == 32 ? row : (row & 15));
-                    const int R = R0 + strip, b_ = R / TH, th_ = R - b_ * TH;
+                    const int b_ = s_b[strip], th_ = s_th[strip];
                     const int tw_ = tc0 + tcol;
-                    if (R >= n_rows || tw_ >= TW) continue;
+                    if (!s_ok[strip] || tw_ >= TW || (B3_ABL(64) && B != -12345)) continue;
                     const int ow = 2 * tw_;
                     const bool col1 = ow + 1 < W, row1 = 2 * th_ + 1 < H;
                     float* const yb = y + (size_t)b_ * Ho * Wo * Cout + (out_nhwc ? (size_t)co : ((size_t)(co >> 3) * Ho * Wo) * 8 + (co & 7));
@@ -385,6 +524,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
                 }
             }
         }
+        B3_STAMP(item, 5);
     }
 }
 

@@ -518,27 +518,30 @@ def to_chunked(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 2, 3, 1).reshape(b, h, w, c // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
 
 
-def wino_pack_weights_device(weight: torch.Tensor, transposed: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def wino_pack_weights_device(weight: torch.Tensor, transposed: bool = False, out: Optional[torch.Tensor] = None,
+                             split_bf16: bool = False) -> torch.Tensor:
     """The same packing on the device, on the current stream, from the weight as it lies in memory (any strides: a
     channels_last parameter needs no copy) - what a training step does every step.  `transposed`: the weights of the
-    backward-data pass (dx = conv(dz, W'), W'[ci][co][i][j] = W[co][ci][2 - i][2 - j])."""
+    backward-data pass (dx = conv(dz, W'), W'[ci][co][i][j] = W[co][ci][2 - i][2 - j]).  `split_bf16`: U split into three bf16
+    terms in the operand order of iris_conv3x3_wino_b3 (the convolution on the BF16 matrix cores at fp32 accuracy)."""
     if not (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
         raise ValueError("wino_pack_weights_device: a float32 device weight [Cout, Cin, 3, 3] is expected (no CPU fallback)")
     co, ci = int(weight.shape[0]), int(weight.shape[1])
     cin, cout = (co, ci) if transposed else (ci, co)
-    n = int(N.lib().iris_wino_packed_len(cin, cout))
+    lib = N.lib()
+    n = int((lib.iris_wino_b3_packed_len if split_bf16 else lib.iris_wino_packed_len)(cin, cout))
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=weight.device)
     so, si, sh, sw = (int(v) for v in weight.stride())
+    pack = lib.iris_wino_b3_pack_weights_device if split_bf16 else lib.iris_wino_pack_weights_device
     with torch.cuda.device(weight.device):
-        rc = N.lib().iris_wino_pack_weights_device(weight.data_ptr(), so, si, sh, sw, cin, cout, 1 if transposed else 0,
-                                                   out.data_ptr(), _stream_ptr(weight.device))
-    N.check(rc, "iris_wino_pack_weights_device")
+        rc = pack(weight.data_ptr(), so, si, sh, sw, cin, cout, 1 if transposed else 0, out.data_ptr(), _stream_ptr(weight.device))
+    N.check(rc, "iris_wino_b3_pack_weights_device" if split_bf16 else "iris_wino_pack_weights_device")
     return out
 
 
 def conv3x3_wino(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, pool: bool = False,
-                 out_nhwc: bool = False, relu: bool = True) -> torch.Tensor:
+                 out_nhwc: bool = False, relu: bool = True, split_bf16: bool = False) -> torch.Tensor:
     """conv2d(x, weight, padding=1) (+ bias, + ReLU, + MaxPool 2x2 'same') as Winograd F(2x2, 3x3) on the fp32 matrix cores
     (iris_conv3x3_wino).  x: channel-chunked [B, Cin / 8, H, W, 8], or a channels_last [B, Cin, H, W] tensor (read where it
     lies: IRIS_WINO_IN_NHWC); packed: `wino_pack_weights[_device]`; returns the chunked [B, cout / 8, Ho, Wo, 8] or, with
@@ -560,10 +563,11 @@ def conv3x3_wino(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch.Ten
         y = torch.empty((b, cout // 8, ho, wo, 8), dtype=torch.float32, device=x.device)
     flags = (N.IRIS_WINO_POOL if pool else 0) | (N.IRIS_WINO_OUT_NHWC if out_nhwc else 0) | \
         (N.IRIS_WINO_IN_NHWC if in_nhwc else 0) | (N.IRIS_WINO_RELU if relu else 0)
+    fn = N.lib().iris_conv3x3_wino_b3 if split_bf16 else N.lib().iris_conv3x3_wino   # `packed` must come from the matching packer
     with torch.cuda.device(x.device):
-        rc = N.lib().iris_conv3x3_wino(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                       b, h, w, cin, int(cout), flags, _stream_ptr(x.device))
-    N.check(rc, "iris_conv3x3_wino")
+        rc = fn(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                b, h, w, cin, int(cout), flags, _stream_ptr(x.device))
+    N.check(rc, "iris_conv3x3_wino_b3" if split_bf16 else "iris_conv3x3_wino")
     return y
 
 
@@ -608,11 +612,11 @@ def conv3x3_wino_wrw(x: torch.Tensor, dy: torch.Tensor, like: Optional[torch.Ten
 
 
 def conv3x3_wino_bias_relu(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, cout: int, pool: bool = False,
-                           out_nhwc: bool = False) -> torch.Tensor:
+                           out_nhwc: bool = False, split_bf16: bool = False) -> torch.Tensor:
     """The inference form: relu(conv2d(x, weight, padding=1) + bias), with `pool` max-pooled, on the chunked layout."""
     if not (x.dim() == 5 and x.shape[-1] == 8):
         raise ValueError("conv3x3_wino_bias_relu: x must be the channel-chunked activation [B, Cin / 8, H, W, 8]")
-    return conv3x3_wino(x, packed, bias, cout, pool=pool, out_nhwc=out_nhwc, relu=True)
+    return conv3x3_wino(x, packed, bias, cout, pool=pool, out_nhwc=out_nhwc, relu=True, split_bf16=split_bf16)
 
 
 def _check_bilstm(gx, w_hh, who):

@@ -417,7 +417,9 @@ class _WinoConv3x3(torch.autograd.Function):
         if fwd == 'c32':
             z = _fe.conv3x3_c32(x, weight)
         elif fwd:
-            z = _fe.conv3x3_wino(x, _fe.wino_pack_weights_device(weight), None, int(weight.shape[0]), out_nhwc=True, relu=False)
+            b3 = SW.WINO_SPLIT_BF16 and int(weight.shape[1]) % 16 == 0   # GEMMs on the BF16 matrix cores, three-term split
+            z = _fe.conv3x3_wino(x, _fe.wino_pack_weights_device(weight, split_bf16=b3), None, int(weight.shape[0]), out_nhwc=True,
+                                 relu=False, split_bf16=b3)
         else:
             z = torch.nn.functional.conv2d(x, weight, None, 1, 1)
         ctx.save_for_backward(x, weight)
@@ -436,7 +438,9 @@ class _WinoConv3x3(torch.autograd.Function):
         if wino_dx and ctx.wino_bwd == 'c32':
             dx = _fe.conv3x3_c32(dz, weight, transposed=True)
         elif wino_dx:
-            dx = _fe.conv3x3_wino(dz, _fe.wino_pack_weights_device(weight, transposed=True), None, cin, out_nhwc=True, relu=False)
+            b3 = SW.WINO_SPLIT_BF16 and int(weight.shape[0]) % 16 == 0
+            dx = _fe.conv3x3_wino(dz, _fe.wino_pack_weights_device(weight, transposed=True, split_bf16=b3), None, cin, out_nhwc=True,
+                                  relu=False, split_bf16=b3)
         wino_dw = ctx.needs_input_grad[1] and ctx.wino_wrw
         if wino_dw:
             dw = _fe.conv3x3_wino_wrw(x, dz, like=weight)

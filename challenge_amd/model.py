@@ -428,7 +428,7 @@ class _WinoStack(nn.Module):
 
     def __init__(self, blocks):
         super().__init__()
-        self.layers = []  # (index, cout, pool)
+        self.layers = []  # (index, cout, pool, split-bf16 kernel)
         dev = None
         for blk in blocks:
             convs = list(blk.convs)
@@ -438,9 +438,11 @@ class _WinoStack(nn.Module):
                 w, b = conv.weight.detach(), conv.bias.detach()
                 dev = w.device
                 k = len(self.layers)
-                self.register_buffer(f"packed{k}", _fe.wino_pack_weights(w), persistent=False)
+                b3 = bool(SW.WINO_SPLIT_BF16) and int(w.shape[1]) % 16 == 0 and w.is_cuda   # BF16 matrix cores, three-term split
+                self.register_buffer(f"packed{k}", _fe.wino_pack_weights_device(w.contiguous(), split_bf16=True) if b3
+                                     else _fe.wino_pack_weights(w), persistent=False)
                 self.register_buffer(f"bias{k}", b.to(torch.float32).contiguous().clone(), persistent=False)
-                self.layers.append((k, int(w.shape[0]), has_pool and i == len(convs) - 1))
+                self.layers.append((k, int(w.shape[0]), has_pool and i == len(convs) - 1, b3))
 
     @staticmethod
     def eligible(blk) -> bool:
@@ -464,8 +466,9 @@ class _WinoStack(nn.Module):
         if x.dim() != 5:  # (the layer in front may already have written the chunked layout)
             x = _fe.to_chunked(x)
         last = len(self.layers) - 1
-        for k, cout, pool in self.layers:
-            x = _fe.conv3x3_wino_bias_relu(x, getattr(self, f"packed{k}"), getattr(self, f"bias{k}"), cout, pool=pool, out_nhwc=(k == last))
+        for k, cout, pool, b3 in self.layers:
+            x = _fe.conv3x3_wino_bias_relu(x, getattr(self, f"packed{k}"), getattr(self, f"bias{k}"), cout, pool=pool, out_nhwc=(k == last),
+                                           split_bf16=b3)
         return x
 
 
@@ -516,6 +519,7 @@ class InferenceEngine:
         self.fused_lstm = False
         dev = next(self.model.parameters()).device
         self.wino_convs = 0
+        self.split_bf16_convs = 0
         if fuse_epilogues and hip_convs and SW.WINO_CONVS and dev.type == 'cuda':
             # the trailing run of plain ConvMPBlocks whose convolutions the Winograd kernel takes (blocks 2-5 of v9): one module
             feats = list(self.model.features)
@@ -525,6 +529,7 @@ class InferenceEngine:
             if k < len(feats):
                 stack = _WinoStack(feats[k:])
                 self.wino_convs = len(stack.layers)
+                self.split_bf16_convs = sum(1 for layer in stack.layers if layer[3])   # of them on the BF16 matrix cores (IRIS_WINO_SPLIT_BF16)
                 self.model.features = nn.Sequential(*feats[:k], stack)
         if fuse_epilogues and dev.type == 'cuda':
             first = True

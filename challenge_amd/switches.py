@@ -47,6 +47,12 @@ WINO_TRAIN_WRW = WINO_TRAIN and _on("IRIS_WINO_TRAIN_WRW")
 # bias / ReLU instead of CK's / MIOpen's kernels (431 + ~470 us per step); IRIS_C32_TRAIN=0 keeps those
 C32_TRAIN = WINO_TRAIN and _on("IRIS_C32_TRAIN")
 
+# Round 6, opt-in: the same Winograd convolutions (forward, backward-data, inference) with their GEMMs on the BF16 matrix cores at fp32
+# accuracy - both operands split into three bf16 terms, six partial products accumulated in fp32 (k_conv_wino_b3.h: error against
+# fp64 0.65 - 1.14x the exact-fp32 kernel's, 1.13 - 1.57x faster per layer).  Layers with 16 | input channels; default OFF: the headline
+# numbers stay on the exact-fp32 kernels.
+WINO_SPLIT_BF16 = _on("IRIS_WINO_SPLIT_BF16", "0")
+
 # --- inference ------------------------------------------------------------------------------------------------------------------------
 WINO_CONVS = _on("IRIS_WINO")   # blocks 2-5 of the InferenceEngine as Winograd F(2x2, 3x3) on the fp32 MFMA (0: MIOpen + HIP epilogue)
 
@@ -65,5 +71,5 @@ DDP_BUCKET_MB = int(os.environ.get("IRIS_DDP_BUCKET_MB", "12"))
 _PLAN_CHECK_ON_CPU = False  # tests/test_ddp_gloo.py: consult the frontend plans' status for a CPU-resident loss too
 
 NAMES = ("FUSED_BN_RELU", "FUSED_FC_BN", "FUSED_BN_POOL", "FUSED_CONV0", "FUSED_LSTM", "ZERO_POOL", "WINO_TRAIN",
-         "WINO_TRAIN_MIN_C_FWD", "WINO_TRAIN_MIN_C_BWD", "WINO_TRAIN_WRW", "C32_TRAIN", "WINO_CONVS", "GRAPH_STEP", "DDP_BUCKET_MB",
+         "WINO_TRAIN_MIN_C_FWD", "WINO_TRAIN_MIN_C_BWD", "WINO_TRAIN_WRW", "C32_TRAIN", "WINO_SPLIT_BF16", "WINO_CONVS", "GRAPH_STEP", "DDP_BUCKET_MB",
          "_PLAN_CHECK_ON_CPU")

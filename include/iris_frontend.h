@@ -384,6 +384,24 @@ int iris_conv3x3_wino(const float* x, const float* packed, const float* bias, fl
                       int cout, int flags, void* stream);
 
 /*
+ * The same convolution with its 16 GEMMs on the BF16 matrix cores AT FP32 ACCURACY (round 6; opt-in: IRIS_WINO_SPLIT_BF16=1 on the
+ * Python side): v_mfma_f32_32x32x16_bf16 delivers 16x the FLOP per clock of the fp32 MFMA that bounds iris_conv3x3_wino.  Every fp32
+ * operand is the EXACT sum of three bf16 values (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)); U is split once per
+ * layer when it is packed, V in registers; six of the nine partial products (all down to 2^-24 of the product) are accumulated in
+ * fp32 by the matrix cores.  Against an fp64 convolution the error is 0.65 - 1.14x that of iris_conv3x3_wino on the CRNN's
+ * geometries (profiles/r6/wino_b3_check.log; tests/test_transforms_gpu.py holds it to 1.5x and to 1e-6 of the peak), the twelve
+ * layers of the forward run 1.13 - 1.57x faster.  Same contract as iris_conv3x3_wino (layouts, flags, bias, pooling) except:
+ *   cin % 16 == 0 (one MFMA K-step), cout % 64 == 0
+ *   packed  iris_wino_b3_pack_weights_device only: 24 cin cout floats = 96 cin cout bytes (iris_wino_b3_packed_len, in floats)
+ * Replaces: the same Conv2D layers of define_keras_model (sj_train.py:191-201, 222-242).
+ */
+size_t iris_wino_b3_packed_len(int cin, int cout);
+int iris_wino_b3_pack_weights_device(const float* weight, long stride_o, long stride_i, long stride_h, long stride_w, int cin, int cout,
+                                     int transposed, float* packed, void* stream);
+int iris_conv3x3_wino_b3(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width, int cin,
+                         int cout, int flags, void* stream);
+
+/*
  * The WEIGHT GRADIENT of the same convolution, y = conv3x3_same(x, w), as a Winograd F(2x2, 3x3) transform on the fp32 matrix
  * cores - model.fit's backward pass through blocks 2-5 (sj_train.py:191-201, 222-242, 408), which MIOpen runs as implicit
  * GEMMs at 82-127 TFLOP/s: dU[p] = sum over the tiles of the batch of (A dY A^T)[p] (B^T d B)[p] per position p, dW = G^T dU G -

@@ -123,3 +123,20 @@ def test_decision_matching_is_what_it_claims(dev):
     bad = R.reference_step(ref3, x, y, decisions=d)
     err_bad = max(P._rel(p.grad, g) for n, p, g in zip(names, model.parameters(), bad['raw']) if not P._bn_fed_bias(n))
     assert err_bad > 10 * P.BOUNDS["c4_gradient_rel"], err_bad
+
+
+def test_c3_and_c4_full_size_with_the_split_bf16_convolutions(setup, monkeypatch):
+    """IRIS_WINO_SPLIT_BF16: blocks 2-5 on the BF16 matrix cores (three-term split, fp32 accumulate) - inference engine and
+    training step at batch 64 x 512 frames under the SAME bounds as the exact-fp32 kernels (c3: 1e-4 / 2e-5; c4: loss 1e-6,
+    outputs 2e-5, BatchNorm statistics 1e-6, every gradient 5e-5 against the decision-matched fp64 reference, bit-reproducible)."""
+    from oracle import crnn_parity as P
+    S, cfg, model, fe, wav, y, feats = setup
+    monkeypatch.setattr(S, "WINO_SPLIT_BF16", True)
+    eng = S.InferenceEngine(model, fe, wav)
+    assert eng.wino_convs == 12 and eng.split_bf16_convs == 12 and eng.graph_ok, eng.graph_error
+    res3 = P.c3_parity(model, eng, feats, replay_out=eng.replay().clone())
+    print("c3 full size, split bf16:", res3)
+    assert res3["ok"] and res3["replay_equals_eager"], res3
+    res4 = P.c4_parity(model, feats, y, clipvalue=cfg.clipvalue, unmatched=False)
+    print("c4 full size, split bf16:", res4)
+    assert res4["ok"], res4

@@ -1166,6 +1166,71 @@ def test_winograd_convolution_matches_fp64(dev, b, h, w, cin, cout):
         FE.conv3x3_wino_bias_relu(x, packed, bias, cout)            # not the chunked layout
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout", [(2, 32, 256, 32, 64), (2, 32, 256, 64, 64), (3, 16, 128, 64, 128), (2, 16, 128, 128, 128),
+                                            (5, 8, 64, 256, 256), (3, 4, 32, 512, 512), (7, 2, 16, 512, 512),     # the CRNN's own shapes
+                                            (2, 40, 256, 32, 64), (3, 5, 32, 256, 512), (1, 7, 9, 16, 64), (2, 3, 70, 48, 128),
+                                            (1, 1, 1, 16, 64), (130, 2, 2, 32, 64)])                                  # odd sizes, edges
+def test_winograd_split_bf16_convolution_matches_fp64(dev, b, h, w, cin, cout):
+    """The same convolution with its GEMMs on the BF16 matrix cores (iris_conv3x3_wino_b3: both operands split into three bf16
+    terms, six partial products accumulated in fp32) under the UNCHANGED fp64-referenced gates of the exact-fp32 kernel: error
+    <= 1.5x that kernel's on the same input (floor 3e-7: both sit at a few ulp there) and <= 1e-6 of the output's peak - no
+    relaxed bound; pooled / unpooled, chunked / channels-last inputs and outputs bit-identical; all three tile geometries, odd
+    sizes, tile rows straddling images.  Measured 0.65 - 1.14x (profiles/r6/wino_b3_check.log)."""
+    from challenge_amd import frontend as FE
+    g = torch.Generator(device=dev).manual_seed(b * 1000 + h)
+    x = torch.randn(b, cin, h, w, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(cout, cin, 3, 3, generator=g, device=dev) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g, device=dev) * 0.1
+    packed, packed3 = FE.wino_pack_weights(wt), FE.wino_pack_weights_device(wt, split_bf16=True)
+    assert packed3.numel() == 24 * cin * cout                     # 96 bytes per weight pair: 16 positions x 3 bf16 terms
+    xc = FE.to_chunked(x)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1).relu()
+    for pool in (False, True):
+        want = torch.nn.functional.max_pool2d(ref, 2, 2, ceil_mode=True) if pool else ref
+        peak = want.abs().max().clamp_min(1e-30)
+        exact = FE.conv3x3_wino_bias_relu(xc, packed, bias, cout, pool=pool, out_nhwc=True)
+        y_cl = FE.conv3x3_wino_bias_relu(xc, packed3, bias, cout, pool=pool, out_nhwc=True, split_bf16=True)
+        assert tuple(y_cl.shape) == tuple(want.shape) and y_cl.is_contiguous(memory_format=torch.channels_last)
+        e_exact, e_split = float((exact.double() - want).abs().max() / peak), float((y_cl.double() - want).abs().max() / peak)
+        assert e_split <= max(1.5 * e_exact, 3e-7) and e_split <= 1e-6, (pool, e_exact, e_split)
+        y_ch = FE.conv3x3_wino_bias_relu(xc, packed3, bias, cout, pool=pool, split_bf16=True)
+        assert torch.equal(FE.to_chunked(y_cl), y_ch)
+        y_in = FE.conv3x3_wino(x, packed3, bias, cout, pool=pool, out_nhwc=True, relu=True, split_bf16=True)   # channels-last input
+        assert torch.equal(y_in, y_cl)
+    bare = FE.conv3x3_wino(x, packed3, None, cout, out_nhwc=True, relu=False, split_bf16=True)                  # the training form
+    want = torch.nn.functional.conv2d(x.double(), wt.double(), None, padding=1)
+    assert float((bare.double() - want).abs().max() / want.abs().max()) <= 1e-6
+    with pytest.raises(ValueError):
+        FE.wino_pack_weights_device(torch.zeros(64, 8, 3, 3, device=dev), split_bf16=True)   # 16 | cin
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout", [(4, 8, 64, 128, 256), (2, 4, 32, 512, 512), (3, 5, 9, 64, 128), (2, 6, 10, 32, 64)])
+def test_winograd_split_bf16_training_convolution_matches_torch(dev, b, h, w, cin, cout, monkeypatch):
+    """sj_train._WinoConv3x3 with IRIS_WINO_SPLIT_BF16 on: forward and backward-data through the BF16-matrix-core kernel (weights
+    packed and split on the device, plain and transposed / flipped), the weight gradient by the exact-fp32 Winograd kernel as
+    before - output and both gradients equal torch's fp64 convolution under the bounds of the exact-fp32 path (2e-6)."""
+    from challenge_amd import sj_train as S
+    monkeypatch.setattr(S, "WINO_SPLIT_BF16", True)
+    g = torch.Generator(device=dev).manual_seed(cin + cout + h)
+    x = torch.randn(b, cin, h, w, generator=g, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g, device=dev) * (2.0 / (9 * cin)) ** 0.5).contiguous(memory_format=torch.channels_last)
+    wt.requires_grad_(True)
+    z = S._WinoConv3x3.apply(x, wt, cout % 64 == 0, cout % 8 == 0 and cin % 64 == 0, True)
+    dz = torch.randn(z.shape, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
+    z.backward(dz)
+    x2, w2 = x.detach().clone().requires_grad_(True), wt.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(x2.double(), w2.double(), None, padding=1)
+    ref.backward(dz.double())
+
+    def rel(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max())
+    assert rel(z, ref) <= 2e-6 and rel(x.grad, x2.grad) <= 2e-6 and rel(wt.grad, w2.grad) <= 2e-6, (rel(z, ref), rel(x.grad, x2.grad))
+    # it really took the other kernel: the exact-fp32 path gives (slightly) different bits
+    monkeypatch.setattr(S, "WINO_SPLIT_BF16", False)
+    z32 = S._WinoConv3x3.apply(x.detach(), wt.detach(), cout % 64 == 0, False, False)
+    assert not torch.equal(z32, z.detach()) and rel(z32, ref) <= 2e-6
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout", [(4, 8, 64, 128, 256), (3, 8, 64, 256, 256), (5, 4, 32, 256, 512), (2, 4, 32, 512, 512),
                                             (3, 5, 9, 64, 128), (2, 6, 10, 24, 64), (2, 6, 10, 32, 64), (2, 6, 10, 32, 32), (3, 9, 70, 32, 32)])
 def test_winograd_training_convolution_matches_torch(dev, b, h, w, cin, cout):
