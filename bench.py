@@ -153,19 +153,24 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
     wav = torch.randn(batch, 1, length, generator=gen, device=dev) * 0.1
     y = (torch.rand(batch, 16, 3, generator=gen, device=dev) < 0.1).float()
 
-    def timed(fn, n):
+    host_ms = {}   # host time per step of the last `timed(..., tag=...)` calls: issue time of n steps, before the fence
+
+    def timed(fn, n, tag=None):
         for _ in range(3):
             fn()
         fence()
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
+        t_issue = time.perf_counter() - t0
         fence()
         dt = time.perf_counter() - t0
         if S.collectives_on(world):
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt, t_issue], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            dt, t_issue = float(t[0].item()), float(t[1].item())
+        if tag:
+            host_ms[tag] = round(1e3 * t_issue / n, 3)
         return dt / n
 
     def checker_leg(fn):
@@ -200,7 +205,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         feats = fe.plan.wav_to_logmel(wav, minmax=fe.do_minmax, log=True, t_bands=infer._tb, f_bands=infer._fb)
         return P.c3_parity(model, infer, feats, replay_out=rep)
     c3_parity = checker_leg(c3_leg)
-    t_train = timed(train, steps)
+    t_train = timed(train, steps, tag='eager')
 
     # where the training step goes: device time per phase from events on the stream (one extra pass, untimed)
     phases = {}
@@ -267,18 +272,23 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         bf16 = {"error": repr(exc)[:200]}
 
     # the same training step as ONE replayed hipGraph (single GPU): no zero fills, no gradient-accumulate launches, no gaps
+    # ... under DDP over RCCL too (round 6): the bucketed gradient all-reduce is issued from inside the capture, so with N ranks on
+    # one host the step costs two copies and ONE graph launch of host time instead of ~260 kernel launches (what `fit` runs by default)
     graphed = None
-    if world == 1:
+    if world == 1 or (ddp is not None and dist.get_backend() == "nccl"):
         try:
             gm = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
             gm.load_state_dict(model.state_dict())
-            gm.compile(S.make_optimizer(cfg, gm.parameters(), capturable=True), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+            gm.compile(S.make_optimizer(cfg, gm.parameters(), capturable=True), S.binary_crossentropy, clipvalue=cfg.clipvalue,
+                       ddp=S.wrap_ddp(gm, dev, world))
             gstep = S.GraphedTrainStep(gm, (fe(wav), y))
-            t_graph = timed(lambda: gstep((fe(wav), y)), steps)
-            graphed = {"ms_per_step": round(1e3 * t_graph, 3), "audio_s_per_s": round(audio_s / t_graph, 1),
-                       "what": "sj_train.GraphedTrainStep: forward, loss, backward, AGC + clipvalue, Adam captured once, replayed"}
+            t_graph = timed(lambda: gstep((fe(wav), y)), steps, tag='hipgraph')
+            graphed = {"ms_per_step": round(1e3 * t_graph, 3), "audio_s_per_s": round(world * audio_s / t_graph, 1),
+                       "host_ms_per_step": host_ms.get('hipgraph'), "gradient_allreduce_in_graph": gstep.world or None,
+                       "what": "sj_train.GraphedTrainStep: forward, loss, backward, (under DDP: the bucketed RCCL all-reduce,) AGC + "
+                               "clipvalue, Adam captured once, replayed"}
             del gstep, gm
-        except Exception as exc:  # an optimisation on top of the eager step: never takes the line down
+        except Exception as exc:  # an optimisation on top of the eager step: never takes the line down (every rank raises alike)
             graphed = {"error": repr(exc)[:200]}
 
     # checker leg for c4: one training-mode forward / backward / AGC + clipvalue on the timed batch (this step's features and
@@ -412,7 +422,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         "c4_train_step": {"audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3),
                           "batch_per_gpu": batch, "n_gpus": world, "params": sum(p.numel() for p in model.parameters()),
                           "parity": c4_parity,
-                          "hipgraph": graphed, "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if ddp is not None else "none", "device_ms_per_phase": breakdown,
+                          "host_ms_per_step": host_ms.get('eager'), "hipgraph": graphed, "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if ddp is not None else "none", "device_ms_per_phase": breakdown,
                           "allreduce": comm},
         "split_bf16_matrix_cores": split,
         "autocast_bf16_smoke_stock_ops": bf16,
@@ -838,7 +848,8 @@ def main():
                             "collective).  SCALING TARGET = the training step: see train_step_ms / train_step_audio_s_per_s / "
                             "allreduce_exposed_ms at the top level of this line (c4: frontend + CRNN forward / backward + "
                             "RCCL gradient all-reduce + AGC + Adam, batch 64 per GPU)")
-        result.update({"train_step_ms": None, "train_step_audio_s_per_s": None, "allreduce_exposed_ms": None, "grad_bytes": None})
+        result.update({"train_step_ms": None, "train_step_audio_s_per_s": None, "train_step_form": None, "host_ms_per_step": None,
+                       "allreduce_exposed_ms": None, "grad_bytes": None})
         if force_pg:
             result["forced_process_group"] = ("IRIS_FORCE_PG=1: world size 1 with the process group, DDP and every collective "
                                               "on; allreduce_exposed_ms is then the floor of the bucket launches (no peer)")
@@ -867,7 +878,13 @@ def main():
                 c4 = extras.get("c4_train_step")
                 if coll and c4:  # the scaling curve of the END-TO-END TRAINING STEP, at the top level of the line
                     comm = c4.get("allreduce") or {}
-                    result.update({"train_step_ms": c4.get("ms_per_step"), "train_step_audio_s_per_s": c4.get("audio_s_per_s"),
+                    g = c4.get("hipgraph") or {}
+                    use_graph = g.get("ms_per_step") is not None and g["ms_per_step"] < c4.get("ms_per_step", float("inf"))
+                    form = g if use_graph else c4   # what `fit` runs: the replayed graph wherever it could be captured
+                    result.update({"train_step_ms": form.get("ms_per_step"), "train_step_audio_s_per_s": form.get("audio_s_per_s"),
+                                   "train_step_form": "hipgraph replay (all-reduce inside the graph)" if use_graph else "eager DDP",
+                                   "host_ms_per_step": form.get("host_ms_per_step"),
+                                   "train_step_eager_ms": c4.get("ms_per_step"), "train_step_eager_host_ms": c4.get("host_ms_per_step"),
                                    "allreduce_exposed_ms": comm.get("exposed_allreduce_ms_per_step"),
                                    "grad_bytes": comm.get("grad_bytes")})
             algo_bytes = ALGO_BYTES_PER_AUDIO_S * audio_s_per_step  # per launch
