@@ -146,16 +146,16 @@ extern "C" int iris_wino_b3_pack_weights_device(const float* weight, long stride
 
 #ifdef IRIS_B3_STAMPS
 // timing experiments only: wave 0 of every workgroup records (s_memrealtime [100 MHz], s_memtime [shader clock]) at six points of its
-// FIRST two work items into this buffer: [workgroup][item 2][point 6][2]
-__device__ unsigned long long g_b3_stamps[256 * 2 * 6 * 2];
+// FIRST two work items into this buffer: [workgroup][item 2][point 10][2]
+__device__ unsigned long long g_b3_stamps[256 * 2 * 10 * 2];
 extern "C" int iris_b3_read_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_b3_stamps), sizeof(g_b3_stamps));
 }
 #define B3_STAMP(item, point)                                                                                  \
     do {                                                                                                       \
         if (tid == 0 && (item) < 2 && blockIdx.x < 256) {                                                      \
-            g_b3_stamps[((blockIdx.x * 2 + (item)) * 6 + (point)) * 2 + 0] = __builtin_amdgcn_s_memrealtime(); \
-            g_b3_stamps[((blockIdx.x * 2 + (item)) * 6 + (point)) * 2 + 1] = __builtin_amdgcn_s_memtime();     \
+            g_b3_stamps[((blockIdx.x * 2 + (item)) * 10 + (point)) * 2 + 0] = __builtin_amdgcn_s_memrealtime(); \
+            g_b3_stamps[((blockIdx.x * 2 + (item)) * 10 + (point)) * 2 + 1] = __builtin_amdgcn_s_memtime();     \
         }                                                                                                      \
     } while (0)
 #else
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zeros are in place before a request can land beside them
         __syncthreads();
+        B3_STAMP(item, 6);
         // ================= the K loop: a software pipeline written out as SLOTS ==================================================
         // One wave per SIMD: nothing but this wave's own instruction order hides anything.  A chunk (16 input channels) is four
         // BLOCKS, one per position of this wave's row in the order nu = 0, 3, 1, 2; a block is 24 slots, each ONE MFMA of the
@@ -387,8 +388,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
         dma_into(1, clamp_chunk(1));
         load_u(ub[0], 0, 0);
         dma_into(2, clamp_chunk(2));
+        B3_STAMP(item, 7);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kDma + 6) : "memory");
         __syncthreads();
+        B3_STAMP(item, 8);
         {
             const float4* buf = chunk_buf(0);
 #pragma unroll

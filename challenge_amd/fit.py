@@ -208,8 +208,17 @@ class GraphedTrainStep:
             torch.cuda.synchronize(dev)
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                model.train_step((self.x, self.y))
+            # (under DDP this one step runs the reducer's AccumulateGrad nodes - default stream - from a side stream: torch warns
+            # about the extra synchronisation, which is all it costs here; the capture itself goes through parameter aliases)
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None) if self.world else None
+            if quiet is not None:
+                quiet(False)
+            try:
+                with torch.cuda.stream(side):
+                    model.train_step((self.x, self.y))
+            finally:
+                if quiet is not None:
+                    quiet(True)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
         finally:

@@ -20,9 +20,9 @@ for h, w, cin, cout, pool in [(16, 128, 128, 128, False), (4, 32, 512, 512, Fals
     for _ in range(5):
         B.wino_b3(xch, pk3, bias, cout, pool)
     torch.cuda.synchronize()
-    st = np.zeros(256 * 2 * 6 * 2, np.uint64)
+    st = np.zeros(256 * 2 * 10 * 2, np.uint64)
     assert lib.iris_b3_read_stamps(st.ctypes.data) == 0
-    st = st.reshape(256, 2, 6, 2).astype(np.float64)
+    st = st.reshape(256, 2, 10, 2).astype(np.float64)
     rt, cy = st[..., 0], st[..., 1]           # 100 MHz ticks, shader cycles
     names = ["prologue", "K loop", "drain + column half + exchange writes", "exchange barrier", "row half + stores"]
     print(f"{h}x{w} {cin}->{cout} pool {int(pool)}: {cin // 16} chunks per work item")
@@ -30,8 +30,11 @@ for h, w, cin, cout, pool in [(16, 128, 128, 128, False), (4, 32, 512, 512, Fals
         ok = rt[:, item, 5] > 0
         if not ok.any():
             continue
-        d_us = np.diff(rt[ok, item], axis=1) / 100.0
-        d_cy = np.diff(cy[ok, item], axis=1)
+        d_us = np.diff(rt[ok, item][:, :6], axis=1) / 100.0
+        d_cy = np.diff(cy[ok, item][:, :6], axis=1)
+        pro = rt[ok, item]
+        print(f"    prologue: decode + zero + barrier {np.median(pro[:, 6] - pro[:, 0]) / 100:.2f} us; requests {np.median(pro[:, 7] - pro[:, 6]) / 100:.2f}; "
+              f"wait + barrier {np.median(pro[:, 8] - pro[:, 7]) / 100:.2f}; row stage + first position {np.median(pro[:, 1] - pro[:, 8]) / 100:.2f}")
         line = "; ".join(f"{n} {np.median(d_us[:, k]):.2f} us ({np.median(d_cy[:, k]) / max(np.median(d_us[:, k]), 1e-9) / 1e3:.2f} GHz)" for k, n in enumerate(names))
         print(f"  item {item}: {line}; whole item {np.median(rt[ok, item, 5] - rt[ok, item, 0]) / 100.0:.2f} us")
     if (rt[:, 1, 0] > 0).any():
