@@ -42,6 +42,11 @@ typedef unsigned b3_u32x4 __attribute__((ext_vector_type(4)));
 #define IRIS_B3_ABLATE 0
 #endif
 #define B3_ABL(bit) ((IRIS_B3_ABLATE & (bit)) != 0)
+#ifdef IRIS_B3_FREE_SCHED   // experiment: no per-slot scheduling barriers (the compiler's own interleaving)
+#define B3_SLOT_FENCE() do { } while (0)
+#else
+#define B3_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 constexpr int kB3KC = 16;                       // input channels per chunk = one K-step of v_mfma_f32_32x32x16_bf16
 constexpr int kB3Rows = 4 * 4;                  // staged pixel rows per chunk at most: 4 per strip, up to 4 strips (TC = 16)
 constexpr int kB3BufSlots = 2304;               // 16-byte pieces per chunk buffer (>= 16 rows x 4 quarters x 2 parities x 17; 36 KiB)
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
         // three-term split into av[cur ^ 1], 13 instructions per channel pair - fenced by a scheduling barrier:
         //   block 0 (nu 0): + row stage of this chunk's patch columns 1, 3 (16 LDS reads, 32 FMAs), prepares nu 3 (columns 1, 3)
         //   block 1 (nu 3): prepares nu 1 (columns 1, 2)          block 2 (nu 1): prepares nu 2 (columns 1, 2)
-        //   block 3 (nu 2): the workgroup barrier for chunk + 1's staged input, its LDS-DMA request for chunk + 3, the row stage
+        //   block 3 (nu 2): the workgroup barrier for chunk + 1's staged input, the LDS-DMA request for chunk + 2, the row stage
         //                   of chunk + 1's columns 0, 2 (w of this chunk is dead by now) and nu 0 of chunk + 1
         // U of the next position is requested at the top of every block, one block (~0.4 us) ahead.  Vector-memory requests
         // complete in order, every count below is static: past the last chunk the requests repeat the last chunk (valid memory,
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
                         else unit_op(cur ^ 1, nu_next, g >> 1, 2 * (g & 1) + (q - 8) / 13, (q - 8) % 13);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                B3_SLOT_FENCE();
             }
         };
         // a LIGHT block: 24 MFMAs beside the preparation of nu_next alone: 8 units x 13 = 104 instructions over 24 slots
@@ -375,21 +380,22 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
 #pragma unroll
                 for (int o = lo; o < hi; ++o)
                     if (!B3_ABL(2)) unit_op(cur ^ 1, nu_next, (o / 13) >> 2, (o / 13) & 3, o % 13);
-                __builtin_amdgcn_sched_barrier(0);
+                B3_SLOT_FENCE();
             }
         };
         auto chunk_buf = [&](int chunk) { return lds4 + (chunk % kB3Bufs) * kB3BufSlots; };
         auto clamp_chunk = [&](int chunk) { return chunk < n_chunks ? chunk : n_chunks - 1; };
 
-        // ---- prologue of the work item (not overlapped): three chunks requested, chunk 0 staged, its columns 0, 2 and nu 0 prepared
-        // (a chunk beyond the last repeats the last one, into a buffer nobody reads; U(0, 0) sits between the requests of chunks 1
-        // and 2 so that block 0 of chunk 0 finds the order every other chunk has: U(chunk, 0), one DMA, U(chunk, 3))
+        // ---- prologue of the work item (not overlapped): two chunks requested, chunk 0 staged, its columns 0, 2 and nu 0 prepared
+        // (a chunk beyond the last repeats the last one, into a buffer nobody reads; U(0, 0) sits between the two requests so that
+        // block 0 of chunk 0 finds the order every other chunk has: U(chunk, 0), one DMA, U(chunk, 3).  Issuing a request blocks
+        // while the memory pipeline is full - at a kernel's start all 256 workgroups ask for their first chunks at once, 2.7 us for
+        // three chunks (profiles/r6/wino_b3_stamps.log) - so only what the first chunk needs is asked for here)
         dma_into(0, 0);
-        dma_into(1, clamp_chunk(1));
         load_u(ub[0], 0, 0);
-        dma_into(2, clamp_chunk(2));
+        dma_into(1, clamp_chunk(1));
         B3_STAMP(item, 7);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kDma + 6) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma + 6) : "memory");
         __syncthreads();
         B3_STAMP(item, 8);
         {
@@ -425,15 +431,15 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
             if (!B3_ABL(1)) B3_WAIT_U(6, ub[0]);
             __builtin_amdgcn_sched_barrier(0);
             light_block(0, 1, 2);
-            // block 3: nu 2; chunk + 1: barrier, DMA of chunk + 3, columns 0, 2, nu 0 into av[0]
+            // block 3: nu 2; chunk + 1: barrier, DMA of chunk + 2, columns 0, 2, nu 0 into av[0]
             if (!B3_ABL(1)) load_u(ub[0], clamp_chunk(chunk + 1), 0);
-            if (!B3_ABL(1)) B3_WAIT_U(6, ub[1]);          // (everything older has landed too: this wave's pieces of chunk + 1 and chunk + 2)
+            if (!B3_ABL(1)) B3_WAIT_U(6, ub[1]);          // (everything older has landed too: this wave's pieces of chunk + 1)
             __builtin_amdgcn_sched_barrier(0);
-            const int c3 = clamp_chunk(chunk + 3);
+            const int c2 = clamp_chunk(chunk + 2);
             heavy_block(1, 2, 0, chunk_buf(chunk + 1), 0, 2, [&] {
                 if (B3_ABL(8)) return;
-                __syncthreads();          // chunk + 1's staged input is complete; every wave has left the buffer chunk + 3 goes into
-                dma_into((chunk + 3) % kB3Bufs, c3);
+                __syncthreads();          // chunk + 1's staged input is complete; every wave has left the buffer chunk + 2 goes into
+                dma_into((chunk + 2) % kB3Bufs, c2);   // (the buffer of chunk - 1: last read in block 0 of chunk - 1)
             });
         }
         B3_STAMP(item, 2);
