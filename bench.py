@@ -326,7 +326,7 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         split = {"what": "blocks 2-5 (12 layers forward; in training forward + backward-data) as Winograd F(2x2, 3x3) with the GEMMs on "
                          "v_mfma_f32_32x32x16_bf16: every fp32 operand = the exact sum of three bf16 terms, 6 of the 9 partial products "
                          "(all down to 2^-24) accumulated in fp32; error against fp64 0.65 - 1.14x the exact-fp32 kernel's per layer "
-                         "(profiles/r6/wino_b3_check.log); opt-in: IRIS_WINO_SPLIT_BF16=1",
+                         "(profiles/r6/wino_b3_check_and_time.log); opt-in: IRIS_WINO_SPLIT_BF16=1",
                  "c3_split_bf16": {"ms_per_step_eager": round(1e3 * t3_eager, 3),
                                    "ms_per_step_hipgraph": None if t3_graph is None else round(1e3 * t3_graph, 3),
                                    "audio_s_per_s": round(world * audio_s / best3, 1), "split_bf16_convolutions": infer3.split_bf16_convs,

@@ -389,7 +389,7 @@ int iris_conv3x3_wino(const float* x, const float* packed, const float* bias, fl
  * operand is the EXACT sum of three bf16 values (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)); U is split once per
  * layer when it is packed, V in registers; six of the nine partial products (all down to 2^-24 of the product) are accumulated in
  * fp32 by the matrix cores.  Against an fp64 convolution the error is 0.65 - 1.14x that of iris_conv3x3_wino on the CRNN's
- * geometries (profiles/r6/wino_b3_check.log; tests/test_transforms_gpu.py holds it to 1.5x and to 1e-6 of the peak), the twelve
+ * geometries (profiles/r6/wino_b3_check_and_time.log; tests/test_transforms_gpu.py holds it to 1.5x and to 1e-6 of the peak), the twelve
  * layers of the forward run 1.13 - 1.57x faster.  Same contract as iris_conv3x3_wino (layouts, flags, bias, pooling) except:
  *   cin % 16 == 0 (one MFMA K-step), cout % 64 == 0
  *   packed  iris_wino_b3_pack_weights_device only: 24 cin cout floats = 96 cin cout bytes (iris_wino_b3_packed_len, in floats)

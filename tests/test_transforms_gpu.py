@@ -1175,7 +1175,7 @@ def test_winograd_split_bf16_convolution_matches_fp64(dev, b, h, w, cin, cout):
     terms, six partial products accumulated in fp32) under the UNCHANGED fp64-referenced gates of the exact-fp32 kernel: error
     <= 1.5x that kernel's on the same input (floor 3e-7: both sit at a few ulp there) and <= 2e-6 of the output's peak, that
     kernel's own bound - nothing relaxed; pooled / unpooled, chunked / channels-last inputs and outputs bit-identical; all three tile geometries, odd
-    sizes, tile rows straddling images.  Measured 0.65 - 1.14x (profiles/r6/wino_b3_check.log)."""
+    sizes, tile rows straddling images.  Measured 0.65 - 1.14x (profiles/r6/wino_b3_check_and_time.log)."""
     from challenge_amd import frontend as FE
     g = torch.Generator(device=dev).manual_seed(b * 1000 + h)
     x = torch.randn(b, cin, h, w, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
