@@ -53,13 +53,16 @@ SIGNATURES = {
     "iris_bn_sums_len": (_sz, [_i]),
     "iris_bn_stats": (_i, [_vp, _sz, _i, _vp, _vp]),
     "iris_bn_relu_apply": (_i, [_vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "iris_bn_relu_apply_sums0": (_i, [_vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_bwd_reduce": (_i, [_vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_bwd_dx": (_i, [_vp, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_pool_apply": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "iris_bn_relu_pool_apply_sums0": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_pool_bwd_reduce": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "iris_bn_relu_pool_bwd_dx": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "iris_conv3x3_c32_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "iris_conv3x3_c32": (_i, [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _vp, _i, _i, _i, _vp]),
+    "iris_conv3x3_c32_bn": (_i, [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, _i, _i, _i, _vp, _vp]),
     "iris_wino_packed_len": (_sz, [_i, _i]),
     "iris_wino_pack_weights": (_i, [_vp, _i, _i, _vp]),
     "iris_wino_pack_weights_device": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _vp, _vp]),
@@ -67,6 +70,8 @@ SIGNATURES = {
     "iris_wino_b3_packed_len": (_sz, [_i, _i]),
     "iris_wino_b3_pack_weights_device": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _vp, _vp]),
     "iris_conv3x3_wino_b3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "iris_conv3x3_wino_bn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "iris_conv3x3_wino_b3_bn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "iris_wino_wrw_workspace_len": (_sz, [_i, _i, _i, _i, _i]),
     "iris_conv3x3_wino_wrw": (_i, [_vp, _vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "iris_conv0_dweight_len": (_sz, [_i, _i]),

@@ -514,9 +514,9 @@ extern "C" int iris_bn_stats(const float* z, size_t rows, int channels, double* 
     return IRIS_OK;
 }
 
-extern "C" int iris_bn_relu_apply(const float* z, float* y, size_t rows, int channels, const double* sums, const float* gamma,
-                                  const float* beta, const float* conv_bias, float eps, float momentum, float* running_mean,
-                                  float* running_var, float* save_mean, float* save_rstd, void* stream) {
+static int bn_relu_apply_impl(const float* z, float* y, size_t rows, int channels, const double* sums, const float* gamma,
+                              const float* beta, const float* conv_bias, float eps, float momentum, float* running_mean,
+                              float* running_var, float* save_mean, float* save_rstd, int sums_about_zero, void* stream) {
     int rc = bn_check(z, y, rows, channels, "iris_bn_relu_apply");
     if (rc) return rc;
     if (!sums || !gamma || !beta || !running_mean || !running_var || !save_mean || !save_rstd)
@@ -528,9 +528,23 @@ extern "C" int iris_bn_relu_apply(const float* z, float* y, size_t rows, int cha
     const double m = (double)rows;
     k_bn_relu_apply<<<grid_bn(n4), 256, 2 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(z, y, n4, channels / 4, 1.0 / m, rows > 1 ? m / (m - 1.0) : 1.0, sums,
                                                                    gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
-                                                                   save_mean, save_rstd);
+                                                                   save_mean, save_rstd, sums_about_zero);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
+}
+
+extern "C" int iris_bn_relu_apply(const float* z, float* y, size_t rows, int channels, const double* sums, const float* gamma,
+                                  const float* beta, const float* conv_bias, float eps, float momentum, float* running_mean,
+                                  float* running_var, float* save_mean, float* save_rstd, void* stream) {
+    return bn_relu_apply_impl(z, y, rows, channels, sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var, save_mean,
+                              save_rstd, 0, stream);
+}
+// the same with `sums` = (sum z, sum z^2) as a convolution's epilogue accumulated them (iris_conv3x3_*_bn): no iris_bn_stats pass
+extern "C" int iris_bn_relu_apply_sums0(const float* z, float* y, size_t rows, int channels, const double* sums, const float* gamma,
+                                        const float* beta, const float* conv_bias, float eps, float momentum, float* running_mean,
+                                        float* running_var, float* save_mean, float* save_rstd, void* stream) {
+    return bn_relu_apply_impl(z, y, rows, channels, sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var, save_mean,
+                              save_rstd, 1, stream);
 }
 
 extern "C" int iris_bn_relu_bwd_reduce(const float* z, const float* dy, size_t rows, int channels, const float* save_mean,
@@ -568,9 +582,10 @@ static int bn_pool_check(const void* a, const void* b, int batch, int height, in
     return bn_check(a, b, (size_t)batch * height * width, channels, who);
 }
 
-extern "C" int iris_bn_relu_pool_apply(const float* z, float* p, int batch, int height, int width, int channels, const double* sums,
-                                       const float* gamma, const float* beta, const float* conv_bias, float eps, float momentum,
-                                       float* running_mean, float* running_var, float* save_mean, float* save_rstd, void* stream) {
+static int bn_relu_pool_apply_impl(const float* z, float* p, int batch, int height, int width, int channels, const double* sums,
+                                   const float* gamma, const float* beta, const float* conv_bias, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* save_mean, float* save_rstd, int sums_about_zero,
+                                   void* stream) {
     int rc = bn_pool_check(z, p, batch, height, width, channels, "iris_bn_relu_pool_apply");
     if (rc) return rc;
     if (bn_overlap(z, (size_t)batch * height * width * channels, p, (size_t)batch * ((height + 1) / 2) * ((width + 1) / 2) * channels))
@@ -581,9 +596,22 @@ extern "C" int iris_bn_relu_pool_apply(const float* z, float* p, int batch, int 
     const double m = (double)batch * height * width;  // the statistics are those of the full-size activation
     k_bn_relu_pool_apply<<<grid_bn(n4), 256, 2 * (size_t)channels * sizeof(float), (hipStream_t)stream>>>(
         z, p, batch, height, width, channels / 4, 1.0 / m, m > 1.0 ? m / (m - 1.0) : 1.0, sums, gamma, beta, conv_bias, eps, momentum,
-        running_mean, running_var, save_mean, save_rstd);
+        running_mean, running_var, save_mean, save_rstd, sums_about_zero);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
+}
+
+extern "C" int iris_bn_relu_pool_apply(const float* z, float* p, int batch, int height, int width, int channels, const double* sums,
+                                       const float* gamma, const float* beta, const float* conv_bias, float eps, float momentum,
+                                       float* running_mean, float* running_var, float* save_mean, float* save_rstd, void* stream) {
+    return bn_relu_pool_apply_impl(z, p, batch, height, width, channels, sums, gamma, beta, conv_bias, eps, momentum, running_mean,
+                                   running_var, save_mean, save_rstd, 0, stream);
+}
+extern "C" int iris_bn_relu_pool_apply_sums0(const float* z, float* p, int batch, int height, int width, int channels, const double* sums,
+                                             const float* gamma, const float* beta, const float* conv_bias, float eps, float momentum,
+                                             float* running_mean, float* running_var, float* save_mean, float* save_rstd, void* stream) {
+    return bn_relu_pool_apply_impl(z, p, batch, height, width, channels, sums, gamma, beta, conv_bias, eps, momentum, running_mean,
+                                   running_var, save_mean, save_rstd, 1, stream);
 }
 
 extern "C" int iris_bn_relu_pool_bwd_reduce(const float* z, const float* dp, int batch, int height, int width, int channels,

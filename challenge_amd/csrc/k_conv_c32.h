@@ -2,6 +2,7 @@
 // layer of the CRNN's first block at full resolution (sj_train.py:191-201, 244), for inference.
 // Part of the single translation unit iris_frontend.hip.
 #pragma once
+#include "bn_epilogue.h"
 // ---------------------------------------------------------------------------
 // 38.7 GFLOP at batch 64 x 64 x 512 - the largest single layer of the forward pass, and the one MIOpen's kernels like least
 // (32 channels: 0.39-0.46 ms = 85-100 TFLOP/s, then a separate bias / ReLU / pooling pass over the 268 MB output).
@@ -70,7 +71,12 @@ __device__ __forceinline__ void c32_groups(float (&abuf)[2][8], const float (&br
 template <bool POOL, bool CHUNKED = false, bool RAW = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int H,
-                                                        int W, long so = 0, long si = 0, long sh = 0, long sw = 0, int transposed = 0) {
+                                                        int W, long so = 0, long si = 0, long sh = 0, long sw = 0, int transposed = 0,
+                                                        double* __restrict__ bn_sums = nullptr) {
+    // bn_sums (RAW only): sum z / sum z^2 per output channel for the BatchNorm behind the convolution (bn_epilogue.h).  A lane's
+    // channel is the same for every tile of this persistent workgroup: fp32 partial sums per patch, fp64 running totals in
+    // registers, ONE pair of atomics per lane when the workgroup has walked its tiles
+    double bn_t1 = 0.0, bn_t2 = 0.0;
     extern __shared__ float halo[];  // [6][66][33 (+ row padding)]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hl = lane >> 5, i = lane & 31;
@@ -135,13 +141,24 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
             c32_groups<0>(abuf, breg, acc, a_addr);
             // accumulator register r of this lane: MFMA row (r & 3) + 8 (r >> 2) + 4 hl, column = output channel lane & 31
             if constexpr (!POOL) {
+                BnEpilogue bn = {acc[0], 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row_i = (r & 3) + 8 * (r >> 2) + 4 * hl;
                     const int orow = h0 + 2 * t + ((row_i >> 1) & 1), ocol = w0 + 16 * wv + 2 * (row_i >> 2) + (row_i & 1);
+                    if constexpr (RAW) {
+                        if (bn_sums != nullptr) bn_epilogue_add(bn, acc[r], (orow < H && ocol < W) ? 1.f : 0.f);
+                    }
                     if (orow < H && ocol < W)
                         y[CHUNKED ? ((((size_t)b * 4 + (i >> 3)) * H + orow) * W + ocol) * 8 + (i & 7)
                                   : (((size_t)b * H + orow) * W + ocol) * kC32 + i] = RAW ? acc[r] : fmaxf(acc[r] + bj, 0.f);
+                }
+                if constexpr (RAW) {
+                    if (bn_sums != nullptr) {   // this patch's share, about zero, in fp64
+                        const double K = (double)bn.k, n = (double)bn.n, S1 = (double)bn.s1, S2 = (double)bn.s2;
+                        bn_t1 += S1 + n * K;
+                        bn_t2 += S2 + 2.0 * K * S1 + n * K * K;
+                    }
                 }
             } else {
                 const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
@@ -166,12 +183,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
             }
         }
     }
+    if constexpr (RAW) {
+        if (bn_sums != nullptr && bn_t2 > 0.0) {
+            const int slot = (int)(blockIdx.x % (unsigned)bn_slots(kC32));
+            atomicAdd(bn_sums + (size_t)slot * 2 * kC32 + i, bn_t1);
+            atomicAdd(bn_sums + (size_t)slot * 2 * kC32 + kC32 + i, bn_t2);
+        }
+    }
 }
 
 // The bare 32 -> 32 convolution for the training step (forward: transposed = 0; backward-data on dz: transposed = 1), y and x
 // channels-last [B, H, W, 32], the weight [32, 32, 3, 3] with element strides
-extern "C" int iris_conv3x3_c32(const float* x, const float* weight, long stride_o, long stride_i, long stride_h, long stride_w,
-                                int transposed, float* y, int batch, int height, int width, void* stream) {
+static int conv3x3_c32_impl(const float* x, const float* weight, long stride_o, long stride_i, long stride_h, long stride_w,
+                            int transposed, float* y, int batch, int height, int width, double* bn_sums, void* stream) {
     if (!x || !weight || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_c32: NULL argument");
     if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_c32: empty tensor");
     if ((reinterpret_cast<uintptr_t>(x) & 15)) return fail(IRIS_E_INVALID, "iris_conv3x3_c32: x must be 16-byte aligned");
@@ -188,9 +212,21 @@ extern "C" int iris_conv3x3_c32(const float* x, const float* weight, long stride
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const unsigned grid = (unsigned)std::min<long long>(n_tiles, 2LL * n_cu);
     k_conv3x3_c32<false, false, true><<<grid, 256, kC32LdsBytes, (hipStream_t)stream>>>(x, weight, nullptr, y, batch, height, width, stride_o,
-                                                                                         stride_i, stride_h, stride_w, transposed);
+                                                                                         stride_i, stride_h, stride_w, transposed, bn_sums);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
+}
+
+extern "C" int iris_conv3x3_c32(const float* x, const float* weight, long stride_o, long stride_i, long stride_h, long stride_w,
+                                int transposed, float* y, int batch, int height, int width, void* stream) {
+    return conv3x3_c32_impl(x, weight, stride_o, stride_i, stride_h, stride_w, transposed, y, batch, height, width, nullptr, stream);
+}
+// the same + the statistics of the BatchNorm behind it (bn_sums_zeroed: DEVICE double [iris_bn_sums_len(32)], zero on entry; consumed
+// by iris_bn_relu_apply_sums0 / iris_bn_relu_pool_apply_sums0)
+extern "C" int iris_conv3x3_c32_bn(const float* x, const float* weight, long stride_o, long stride_i, long stride_h, long stride_w,
+                                   float* y, int batch, int height, int width, double* bn_sums_zeroed, void* stream) {
+    if (!bn_sums_zeroed) return fail(IRIS_E_INVALID, "iris_conv3x3_c32_bn: NULL argument");
+    return conv3x3_c32_impl(x, weight, stride_o, stride_i, stride_h, stride_w, 0, y, batch, height, width, bn_sums_zeroed, stream);
 }
 
 extern "C" int iris_conv3x3_c32_bias_relu(const float* x, const float* weight, const float* bias, float* y, int batch, int height,

@@ -30,6 +30,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#include "bn_epilogue.h"
 
 // timing experiments only (results wrong when non-zero): 1 no per-chunk barrier, 2 no LDS-DMA of U, 4 no transform of the next
 // chunk (patch reads, row / column stage, V writes), 8 no operand reads after a chunk's first group, 16 no LDS-DMA of the input
@@ -105,7 +106,9 @@ struct WinoWave {
 template <bool POOL, int TC, bool IN_NHWC>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict__ x, const float* __restrict__ u,
                                                          const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
-                                                         int Cin, int Cout, int out_nhwc, int relu) {
+                                                         int Cin, int Cout, int out_nhwc, int relu, double* __restrict__ bn_sums) {
+    // bn_sums (training form only: bare convolution, channels-last out, no pooling): the per-channel sum z / sum z^2 of the
+    // BatchNorm that follows, accumulated here from the registers the output is stored from (bn_epilogue.h)
     constexpr bool in_nhwc = IN_NHWC;
     extern __shared__ __attribute__((aligned(16))) float wino_lds[];
     constexpr int TR = kWinoTM / TC, PW = 2 * TC + 2, kPieces = TR * 3 * PW, kDmaRows = (kPieces + 63) / 64;
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
             e_base[ss] = y + (size_t)b_ * Ho * Wo * Cout + (out_nhwc ? (size_t)co : ((size_t)(co >> 3) * Ho * Wo) * 8 + (co & 7))
                          + (size_t)(POOL ? th_ : 2 * th_) * Wo * ps;
         }
+        BnEpilogue bn = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hl;
@@ -335,6 +339,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
                 }
                 pooled = fmaxf(pooled + bj, floor_);
             }
+            if constexpr (!POOL) {
+                if (bn_sums != nullptr) {   // (uniform) the statistics of what is stored below: z itself (no bias, no ReLU here)
+                    if (r == 0) bn.k = o[0][0];
+                    const float in_tile = (e_ok[ss] && tw_ < TW) ? 1.f : 0.f, c1 = col1 ? in_tile : 0.f, r1 = e_row1[ss] ? 1.f : 0.f;
+                    bn_epilogue_add(bn, o[0][0], in_tile);
+                    bn_epilogue_add(bn, o[0][1], c1);
+                    bn_epilogue_add(bn, o[1][0], in_tile * r1);
+                    bn_epilogue_add(bn, o[1][1], c1 * r1);
+                }
+            }
             if (direct) {  // channels-last (the stack's last layer) or unpooled: straight from the registers
                 if (e_ok[ss] && tw_ < TW) {
                     float* const yp = e_base[ss] + (unsigned)((POOL ? tw_ : ow) * ps);
@@ -361,6 +375,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
                         for (int j = 0; j < 2; ++j) sp[((i * 32 + row) * 2 + j) * 8] = fmaxf(o[i][j] + bj, floor_);
                 }
             }
+        }
+        if constexpr (!POOL) {
+            if (bn_sums != nullptr) bn_epilogue_flush(bn, bn_sums, Cout, co, (int)(blockIdx.x % (unsigned)bn_slots(Cout)));
         }
         if (!direct) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave reads back what its own lanes wrote: LDS operations
@@ -485,10 +502,10 @@ extern "C" int iris_wino_pack_weights_device(const float* weight, long stride_o,
 
 template <bool POOL, bool IN_NHWC>
 static hipError_t wino_launch(int tc, unsigned grid, hipStream_t s, const float* x, const float* packed, const float* bias,
-                              float* y, int batch, int height, int width, int cin, int cout, int out_nhwc, int relu) {
-    if (tc >= 64) k_conv3x3_wino<POOL, 64, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
-    else if (tc >= 32) k_conv3x3_wino<POOL, 32, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
-    else k_conv3x3_wino<POOL, 16, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
+                              float* y, int batch, int height, int width, int cin, int cout, int out_nhwc, int relu, double* bn_sums) {
+    if (tc >= 64) k_conv3x3_wino<POOL, 64, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else if (tc >= 32) k_conv3x3_wino<POOL, 32, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else k_conv3x3_wino<POOL, 16, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
     return hipGetLastError();
 }
 
@@ -505,9 +522,11 @@ static hipError_t wino_set_lds_limit() {
 
 // x: channel-chunked [B][cin / 8][H][W][8] (IRIS_WINO_IN_NHWC: channels-last [B][H][W][cin]); packed: iris_wino_pack_weights[_device];
 // bias: nullable; y: chunked [B][cout / 8][Ho][Wo][8] (IRIS_WINO_OUT_NHWC: channels-last [B][Ho][Wo][cout]); flags = IRIS_WINO_*
-extern "C" int iris_conv3x3_wino(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width,
-                                 int cin, int cout, int flags, void* stream) {
+static int conv3x3_wino_impl(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width,
+                             int cin, int cout, int flags, double* bn_sums, void* stream) {
     if (!x || !packed || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_wino: NULL argument");
+    if (bn_sums && (bias || (flags & (IRIS_WINO_POOL | IRIS_WINO_RELU)) || !(flags & IRIS_WINO_OUT_NHWC)))
+        return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bn: the statistics are those of the bare convolution, channels-last out (no bias / ReLU / pooling)");
     if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_wino: empty tensor");
     if (flags & ~(IRIS_WINO_POOL | IRIS_WINO_OUT_NHWC | IRIS_WINO_IN_NHWC | IRIS_WINO_RELU)) return fail(IRIS_E_INVALID, "iris_conv3x3_wino: flags 0x%x", flags);
     if (cin <= 0 || cout <= 0 || (cin % kWinoKC) || (cout % kWinoTN))
@@ -536,10 +555,23 @@ extern "C" int iris_conv3x3_wino(const float* x, const float* packed, const floa
     const unsigned grid = (unsigned)std::min<long long>(n_work, n_cu);  // persistent: one workgroup (4 waves, 156 KiB of LDS) per CU
     const hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    if (pool) e = in_nhwc ? wino_launch<true, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu)
-                          : wino_launch<true, false>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
-    else e = in_nhwc ? wino_launch<false, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu)
-                     : wino_launch<false, false>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
+    if (pool) e = in_nhwc ? wino_launch<true, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr)
+                          : wino_launch<true, false>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr);
+    else e = in_nhwc ? wino_launch<false, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums)
+                     : wino_launch<false, false>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
     HIP_TRY(e);
     return IRIS_OK;
+}
+
+extern "C" int iris_conv3x3_wino(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width,
+                                 int cin, int cout, int flags, void* stream) {
+    return conv3x3_wino_impl(x, packed, bias, y, batch, height, width, cin, cout, flags, nullptr, stream);
+}
+// The training form (bare convolution, flags = IRIS_WINO_OUT_NHWC [| IRIS_WINO_IN_NHWC]) that ALSO accumulates the statistics of
+// the BatchNorm behind it: bn_sums_zeroed = DEVICE double [iris_bn_sums_len(cout)], zero on entry, consumed by
+// iris_bn_relu_apply_sums0 / iris_bn_relu_pool_apply_sums0 (no iris_bn_stats pass over z)
+extern "C" int iris_conv3x3_wino_bn(const float* x, const float* packed, float* y, int batch, int height, int width, int cin, int cout,
+                                    int flags, double* bn_sums_zeroed, void* stream) {
+    if (!bn_sums_zeroed) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_bn: NULL argument");
+    return conv3x3_wino_impl(x, packed, nullptr, y, batch, height, width, cin, cout, flags, bn_sums_zeroed, stream);
 }

@@ -171,7 +171,7 @@ extern "C" int iris_b3_read_stamps(unsigned long long* host) {
 template <bool POOL, int TC, bool IN_NHWC>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restrict__ x, const uint4* __restrict__ u3,
                                                             const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
-                                                            int Cin, int Cout, int out_nhwc, int relu) {
+                                                            int Cin, int Cout, int out_nhwc, int relu, double* __restrict__ bn_sums) {
     extern __shared__ __attribute__((aligned(16))) float b3_lds[];
     constexpr int TR = 64 / TC, PW = 2 * TC + 2, PH = TC + 1, ROWS = 4 * TR;
     constexpr int kSlots = ROWS * 4 * 2 * PH;          // 16-byte pieces of a chunk: [row][quarter q][pixel parity][pixel / 2]
@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
             const float floor_ = relu ? 0.f : -INFINITY;
             const int Ho = POOL ? TH : H, Wo = POOL ? TW : W;
             const int ps = out_nhwc ? Cout : 8;   // floats between pixels
+            BnEpilogue bn = {0.f, 0.f, 0.f, 0.f};   // training form: the statistics of the BatchNorm behind this convolution (bn_epilogue.h)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 float4 sv[4][2];
@@ -508,9 +509,19 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
                     const int tcol = TC >= 64 ? 32 * tb + row : (TC == 32 ? row : (row & 15));
                     const int b_ = s_b[strip], th_ = s_th[strip];
                     const int tw_ = tc0 + tcol;
-                    if (!s_ok[strip] || tw_ >= TW || (B3_ABL(64) && B != -12345)) continue;
                     const int ow = 2 * tw_;
                     const bool col1 = ow + 1 < W, row1 = 2 * th_ + 1 < H;
+                    if constexpr (!POOL) {
+                        if (bn_sums != nullptr) {   // (uniform)
+                            if (r == 0) bn.k = o[0][0];
+                            const float in_tile = (s_ok[strip] && tw_ < TW) ? 1.f : 0.f, c1 = col1 ? in_tile : 0.f, r1 = row1 ? 1.f : 0.f;
+                            bn_epilogue_add(bn, o[0][0], in_tile);
+                            bn_epilogue_add(bn, o[0][1], c1);
+                            bn_epilogue_add(bn, o[1][0], in_tile * r1);
+                            bn_epilogue_add(bn, o[1][1], c1 * r1);
+                        }
+                    }
+                    if (!s_ok[strip] || tw_ >= TW || (B3_ABL(64) && B != -12345)) continue;
                     float* const yb = y + (size_t)b_ * Ho * Wo * Cout + (out_nhwc ? (size_t)co : ((size_t)(co >> 3) * Ho * Wo) * 8 + (co & 7));
                     if constexpr (POOL) {
                         float pooled = o[0][0];
@@ -532,6 +543,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
                     }
                 }
             }
+            if constexpr (!POOL) {
+                if (bn_sums != nullptr) bn_epilogue_flush(bn, bn_sums, Cout, co, (int)(blockIdx.x % (unsigned)bn_slots(Cout)));
+            }
         }
         B3_STAMP(item, 5);
     }
@@ -539,10 +553,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
 
 template <bool POOL, bool IN_NHWC>
 static hipError_t wino_b3_launch(int tc, unsigned grid, hipStream_t s, const float* x, const uint4* packed, const float* bias, float* y,
-                                 int batch, int height, int width, int cin, int cout, int out_nhwc, int relu) {
-    if (tc >= 64) k_conv3x3_wino_b3<POOL, 64, IN_NHWC><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
-    else if (tc >= 32) k_conv3x3_wino_b3<POOL, 32, IN_NHWC><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
-    else k_conv3x3_wino_b3<POOL, 16, IN_NHWC><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
+                                 int batch, int height, int width, int cin, int cout, int out_nhwc, int relu, double* bn_sums) {
+    if (tc >= 64) k_conv3x3_wino_b3<POOL, 64, IN_NHWC><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else if (tc >= 32) k_conv3x3_wino_b3<POOL, 32, IN_NHWC><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else k_conv3x3_wino_b3<POOL, 16, IN_NHWC><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
     return hipGetLastError();
 }
 
@@ -558,9 +572,11 @@ static hipError_t wino_b3_set_lds_limit() {
 }
 
 // Same contract as iris_conv3x3_wino (k_conv_wino.h) with `packed` from iris_wino_b3_pack_weights_device and cin % 16 == 0.
-extern "C" int iris_conv3x3_wino_b3(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width,
-                                    int cin, int cout, int flags, void* stream) {
+static int conv3x3_wino_b3_impl(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width,
+                                int cin, int cout, int flags, double* bn_sums, void* stream) {
     if (!x || !packed || !y) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_b3: NULL argument");
+    if (bn_sums && (bias || (flags & (IRIS_WINO_POOL | IRIS_WINO_RELU)) || !(flags & IRIS_WINO_OUT_NHWC)))
+        return fail(IRIS_E_INVALID, "iris_conv3x3_wino_b3_bn: the statistics are those of the bare convolution, channels-last out (no bias / ReLU / pooling)");
     if (batch <= 0 || height <= 0 || width <= 0) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_b3: empty tensor");
     if (flags & ~(IRIS_WINO_POOL | IRIS_WINO_OUT_NHWC | IRIS_WINO_IN_NHWC | IRIS_WINO_RELU)) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_b3: flags 0x%x", flags);
     if (cin <= 0 || cout <= 0 || (cin % kB3KC) || (cout % 64))
@@ -590,10 +606,21 @@ extern "C" int iris_conv3x3_wino_b3(const float* x, const float* packed, const f
     const hipStream_t st = (hipStream_t)stream;
     const uint4* pk = reinterpret_cast<const uint4*>(packed);
     hipError_t e;
-    if (pool) e = in_nhwc ? wino_b3_launch<true, true>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu)
-                          : wino_b3_launch<true, false>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
-    else e = in_nhwc ? wino_b3_launch<false, true>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu)
-                     : wino_b3_launch<false, false>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu);
+    if (pool) e = in_nhwc ? wino_b3_launch<true, true>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr)
+                          : wino_b3_launch<true, false>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr);
+    else e = in_nhwc ? wino_b3_launch<false, true>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums)
+                     : wino_b3_launch<false, false>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
     HIP_TRY(e);
     return IRIS_OK;
+}
+
+extern "C" int iris_conv3x3_wino_b3(const float* x, const float* packed, const float* bias, float* y, int batch, int height, int width,
+                                    int cin, int cout, int flags, void* stream) {
+    return conv3x3_wino_b3_impl(x, packed, bias, y, batch, height, width, cin, cout, flags, nullptr, stream);
+}
+// as iris_conv3x3_wino_bn: the bare convolution + the statistics of the BatchNorm behind it
+extern "C" int iris_conv3x3_wino_b3_bn(const float* x, const float* packed, float* y, int batch, int height, int width, int cin, int cout,
+                                       int flags, double* bn_sums_zeroed, void* stream) {
+    if (!bn_sums_zeroed) return fail(IRIS_E_INVALID, "iris_conv3x3_wino_b3_bn: NULL argument");
+    return conv3x3_wino_b3_impl(x, packed, nullptr, y, batch, height, width, cin, cout, flags, bn_sums_zeroed, stream);
 }

@@ -356,18 +356,7 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool_nchw(const float* x, con
 #ifndef IRIS_BN_POOL_ROWS
 #define IRIS_BN_POOL_ROWS 8
 #endif
-#ifndef IRIS_BN_SLOTS
-#define IRIS_BN_SLOTS 8
-#endif
-// The per-channel sums are accumulated by fp64 atomics of every block.  A 32-channel layer has 64 addresses and 2048
-// blocks: the same-address atomics queue up behind one another.  Blocks therefore add into one of kBnSlots copies
-// (sums[slot][2][C], slot = block % bn_slots(C)) and the consumers add the copies up while they form their per-channel
-// coefficients (their blocks are fat - at most 2048 per launch - so that this setup is amortised).  A last-block fold behind an
-// arrival counter was measured too: the counter is one more hot address (reductions 0.88 -> 0.99 ms per step).
-constexpr int kBnSlots = IRIS_BN_SLOTS;  // at most; bn_slots(channels) of them are used (wide layers have few blocks per address)
-__host__ __device__ constexpr int bn_slots(int channels) {
-    return channels <= 64 ? kBnSlots : channels <= 128 ? kBnSlots / 2 : channels <= 256 ? kBnSlots / 4 : 1;
-}
+#include "bn_epilogue.h"   // kBnSlots, bn_slots(), and the statistics a convolution's epilogue accumulates
 __device__ __forceinline__ double bn_sum(const double* sums, int C, int i) {
     const int n = bn_slots(C);
     double v = 0.0;
@@ -448,13 +437,14 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float* z, const float* 
 __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* z, float* y, size_t n_vec4, int C4, double inv_m, double unbias,
                                                        const double* sums, const float* gamma, const float* beta,
                                                        const float* conv_bias, float eps, float momentum, float* running_mean,
-                                                       float* running_var, float* save_mean, float* save_rstd) {
+                                                       float* running_var, float* save_mean, float* save_rstd, int sums_about_zero) {
     extern __shared__ float coef[];  // [2][C]: scale = gamma rstd, shift = beta - mean scale  (y = max(z scale + shift, 0))
     const int C = 4 * C4;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        // sums are of (z - K), K = z[row 0][c] (k_bn_reduce): mean = K + E[z - K], var = E[(z - K)^2] - E[z - K]^2
+        // sums are of (z - K), K = z[row 0][c] (k_bn_reduce) - or K = 0 when a convolution's epilogue accumulated them in fp64
+        // (bn_epilogue_flush): mean = K + E[z - K], var = E[(z - K)^2] - E[z - K]^2
         const double ms = bn_sum(sums, C, c) * inv_m, var = fmax(bn_sum(sums, C, C + c) * inv_m - ms * ms, 0.0);
-        const double m = (double)z[c] + ms;
+        const double m = (sums_about_zero ? 0.0 : (double)z[c]) + ms;
         const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
         coef[c] = gamma[c] * rs;
         coef[C + c] = beta[c] - mu * (gamma[c] * rs);
@@ -547,13 +537,13 @@ __device__ __forceinline__ void pool_take(float z, float sc, float sh, int slot,
 __global__ __launch_bounds__(256) void k_bn_relu_pool_apply(const float* z, float* p, int B, int H, int W, int C4, double inv_m,
                                                             double unbias, const double* sums, const float* gamma, const float* beta,
                                                             const float* conv_bias, float eps, float momentum, float* running_mean,
-                                                            float* running_var, float* save_mean, float* save_rstd) {
+                                                            float* running_var, float* save_mean, float* save_rstd, int sums_about_zero) {
     extern __shared__ float coef[];  // [2][C], formed exactly as k_bn_relu_apply forms them
     const int C = 4 * C4;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        // sums are of (z - K), K = z[row 0][c] (k_bn_reduce): mean = K + E[z - K], var = E[(z - K)^2] - E[z - K]^2
+        // sums are of (z - K), K = z[row 0][c] (k_bn_reduce) or 0 (a convolution's epilogue): mean = K + E[z - K], var = E[(z - K)^2] - E[z - K]^2
         const double ms = bn_sum(sums, C, c) * inv_m, var = fmax(bn_sum(sums, C, C + c) * inv_m - ms * ms, 0.0);
-        const double m = (double)z[c] + ms;
+        const double m = (sums_about_zero ? 0.0 : (double)z[c]) + ms;
         const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
         coef[c] = gamma[c] * rs;
         coef[C + c] = beta[c] - mu * (gamma[c] * rs);

@@ -483,7 +483,7 @@ def conv3x3_c32_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Ten
     return y
 
 
-def conv3x3_c32(x: torch.Tensor, weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+def conv3x3_c32(x: torch.Tensor, weight: torch.Tensor, transposed: bool = False, bn_sums: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The bare conv2d(x, weight, padding=1) of a 32 -> 32 layer on the fp32 matrix cores (iris_conv3x3_c32: the inference
     kernel without bias / ReLU) for a channels_last [B, 32, H, W] input and a [32, 32, 3, 3] weight in any dense layout;
     `transposed`: the backward-data pass, conv2d(x, weight.flip(2, 3).transpose(0, 1), padding=1) with x = dz."""
@@ -494,8 +494,14 @@ def conv3x3_c32(x: torch.Tensor, weight: torch.Tensor, transposed: bool = False)
     y = torch.empty((b, 32, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     so, si, sh, sw = (int(v) for v in weight.stride())
     with torch.cuda.device(x.device):
-        rc = N.lib().iris_conv3x3_c32(x.data_ptr(), weight.data_ptr(), so, si, sh, sw, 1 if transposed else 0, y.data_ptr(), b, h, w,
-                                      _stream_ptr(x.device))
+        if bn_sums is not None:   # + the statistics of the BatchNorm behind it into the zeroed [iris_bn_sums_len(32)] doubles
+            if transposed or bn_sums.dtype != torch.float64 or bn_sums.numel() < int(N.lib().iris_bn_sums_len(32)):
+                raise ValueError("conv3x3_c32: bn_sums must be float64 [iris_bn_sums_len(32)] (forward pass only)")
+            rc = N.lib().iris_conv3x3_c32_bn(x.data_ptr(), weight.data_ptr(), so, si, sh, sw, y.data_ptr(), b, h, w, bn_sums.data_ptr(),
+                                             _stream_ptr(x.device))
+        else:
+            rc = N.lib().iris_conv3x3_c32(x.data_ptr(), weight.data_ptr(), so, si, sh, sw, 1 if transposed else 0, y.data_ptr(), b, h, w,
+                                          _stream_ptr(x.device))
     N.check(rc, "iris_conv3x3_c32")
     return y
 
@@ -541,7 +547,7 @@ def wino_pack_weights_device(weight: torch.Tensor, transposed: bool = False, out
 
 
 def conv3x3_wino(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, pool: bool = False,
-                 out_nhwc: bool = False, relu: bool = True, split_bf16: bool = False) -> torch.Tensor:
+                 out_nhwc: bool = False, relu: bool = True, split_bf16: bool = False, bn_sums: Optional[torch.Tensor] = None) -> torch.Tensor:
     """conv2d(x, weight, padding=1) (+ bias, + ReLU, + MaxPool 2x2 'same') as Winograd F(2x2, 3x3) on the fp32 matrix cores
     (iris_conv3x3_wino).  x: channel-chunked [B, Cin / 8, H, W, 8], or a channels_last [B, Cin, H, W] tensor (read where it
     lies: IRIS_WINO_IN_NHWC); packed: `wino_pack_weights[_device]`; returns the chunked [B, cout / 8, Ho, Wo, 8] or, with
@@ -563,10 +569,17 @@ def conv3x3_wino(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch.Ten
         y = torch.empty((b, cout // 8, ho, wo, 8), dtype=torch.float32, device=x.device)
     flags = (N.IRIS_WINO_POOL if pool else 0) | (N.IRIS_WINO_OUT_NHWC if out_nhwc else 0) | \
         (N.IRIS_WINO_IN_NHWC if in_nhwc else 0) | (N.IRIS_WINO_RELU if relu else 0)
-    fn = N.lib().iris_conv3x3_wino_b3 if split_bf16 else N.lib().iris_conv3x3_wino   # `packed` must come from the matching packer
+    lib = N.lib()
     with torch.cuda.device(x.device):
-        rc = fn(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                b, h, w, cin, int(cout), flags, _stream_ptr(x.device))
+        if bn_sums is not None:   # the bare convolution + the statistics of the BatchNorm behind it (zeroed float64 [iris_bn_sums_len(cout)])
+            if bias is not None or bn_sums.dtype != torch.float64 or bn_sums.numel() < int(lib.iris_bn_sums_len(int(cout))):
+                raise ValueError("conv3x3_wino: bn_sums goes with the bare convolution (no bias) and must be float64 [iris_bn_sums_len(cout)]")
+            fn = lib.iris_conv3x3_wino_b3_bn if split_bf16 else lib.iris_conv3x3_wino_bn
+            rc = fn(x.data_ptr(), packed.data_ptr(), y.data_ptr(), b, h, w, cin, int(cout), flags, bn_sums.data_ptr(), _stream_ptr(x.device))
+        else:
+            fn = lib.iris_conv3x3_wino_b3 if split_bf16 else lib.iris_conv3x3_wino   # `packed` must come from the matching packer
+            rc = fn(x.data_ptr(), packed.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                    b, h, w, cin, int(cout), flags, _stream_ptr(x.device))
     N.check(rc, "iris_conv3x3_wino_b3" if split_bf16 else "iris_conv3x3_wino")
     return y
 

@@ -263,14 +263,16 @@ class _FusedBiasBNReLU(torch.autograd.Function):
     only shifts the running mean, which iris_bn_relu_apply accounts for) and its gradient is identically zero."""
 
     @staticmethod
-    def forward(ctx, z, conv_bias, gamma, beta, running_mean, running_var, eps, momentum, pool=False):
+    def forward(ctx, z, conv_bias, gamma, beta, running_mean, running_var, eps, momentum, pool=False, sums0=None):
+        """`sums0`: (sum z, sum z^2) per channel as the convolution's epilogue accumulated them (`_WinoConv3x3(..., stats=True)`):
+        the statistics pass over z is skipped."""
         import ctypes as C
         from . import _native as N
         b, c, h, w = (int(v) for v in z.shape)
         rows = b * h * w
         dev = z.device
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        sums = _zeros(N.lib().iris_bn_sums_len(c), torch.float64, dev)
+        sums = sums0 if sums0 is not None else _zeros(N.lib().iris_bn_sums_len(c), torch.float64, dev)
         if pool:
             y = torch.empty((b, c, (h + 1) // 2, (w + 1) // 2), dtype=z.dtype, device=dev, memory_format=torch.channels_last)
         else:
@@ -282,11 +284,14 @@ class _FusedBiasBNReLU(torch.autograd.Function):
                 float(eps), float(momentum), running_mean.data_ptr(), running_var.data_ptr(), save_mean.data_ptr(),
                 save_rstd.data_ptr(), stream)
         with torch.cuda.device(dev):
-            N.check(lib.iris_bn_stats(z.data_ptr(), rows, c, sums.data_ptr(), stream), "iris_bn_stats")
+            if sums0 is None:
+                N.check(lib.iris_bn_stats(z.data_ptr(), rows, c, sums.data_ptr(), stream), "iris_bn_stats")
+            pool_apply = lib.iris_bn_relu_pool_apply if sums0 is None else lib.iris_bn_relu_pool_apply_sums0
+            apply = lib.iris_bn_relu_apply if sums0 is None else lib.iris_bn_relu_apply_sums0
             if pool:
-                N.check(lib.iris_bn_relu_pool_apply(z.data_ptr(), y.data_ptr(), b, h, w, c, *tail), "iris_bn_relu_pool_apply")
+                N.check(pool_apply(z.data_ptr(), y.data_ptr(), b, h, w, c, *tail), "iris_bn_relu_pool_apply")
             else:
-                N.check(lib.iris_bn_relu_apply(z.data_ptr(), y.data_ptr(), rows, c, *tail), "iris_bn_relu_apply")
+                N.check(apply(z.data_ptr(), y.data_ptr(), rows, c, *tail), "iris_bn_relu_apply")
         ctx.save_for_backward(z, gamma, beta, save_mean, save_rstd)  # y is not needed: the mask is recomputed from z
         ctx.has_bias = conv_bias is not None
         ctx.pool = bool(pool)
@@ -324,7 +329,7 @@ class _FusedBiasBNReLU(torch.autograd.Function):
                 N.check(lib.iris_bn_relu_bwd_dx(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, c, *stats,
                                                 dgamma.data_ptr(), dbeta.data_ptr(), stream), "iris_bn_relu_bwd_dx")
         dbias = _zeros(c, torch.float32, dev, "grad") if ctx.has_bias else None
-        return dz, dbias, dgamma, dbeta, None, None, None, None, None
+        return dz, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
 class _FusedConv0BNReLU(torch.autograd.Function):
@@ -413,22 +418,33 @@ class _WinoConv3x3(torch.autograd.Function):
     inference engine without its bias / ReLU (iris_conv3x3_c32; the backward pass reads the weight transposed and flipped)."""
 
     @staticmethod
-    def forward(ctx, x, weight, fwd=True, bwd=True, wrw=False):
+    def forward(ctx, x, weight, fwd=True, bwd=True, wrw=False, stats=False):
+        """`stats` (only where a HIP kernel runs the forward): also return the per-channel (sum z, sum z^2) of the BatchNorm behind
+        the convolution, accumulated in the kernel's epilogue - `_FusedBiasBNReLU(..., sums0=...)` then skips its pass over z."""
+        from . import _native as N
+        sums = None
+        if stats and fwd:
+            sums = _zeros(N.lib().iris_bn_sums_len(int(weight.shape[0])), torch.float64, x.device)
         if fwd == 'c32':
-            z = _fe.conv3x3_c32(x, weight)
+            z = _fe.conv3x3_c32(x, weight, bn_sums=sums)
         elif fwd:
             b3 = SW.WINO_SPLIT_BF16 and int(weight.shape[1]) % 16 == 0   # GEMMs on the BF16 matrix cores, three-term split
             z = _fe.conv3x3_wino(x, _fe.wino_pack_weights_device(weight, split_bf16=b3), None, int(weight.shape[0]), out_nhwc=True,
-                                 relu=False, split_bf16=b3)
+                                 relu=False, split_bf16=b3, bn_sums=sums)
         else:
             z = torch.nn.functional.conv2d(x, weight, None, 1, 1)
         ctx.save_for_backward(x, weight)
         ctx.wino_bwd = bwd if bwd == 'c32' else bool(bwd)
         ctx.wino_wrw = bool(wrw)
-        return z
+        if not stats:
+            return z
+        if sums is None:
+            return z, None
+        ctx.mark_non_differentiable(sums)
+        return z, sums
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, dz, _dsums=None):
         x, weight = ctx.saved_tensors
         cin = int(weight.shape[1])
         if not dz.is_contiguous(memory_format=torch.channels_last):
@@ -449,7 +465,7 @@ class _WinoConv3x3(torch.autograd.Function):
             gi, gw, _ = torch.ops.aten.convolution_backward(dz, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
             dx = gi if need[0] else dx
             dw = gw if need[1] else dw
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def _wino_train_conv(conv: nn.Conv2d, x: torch.Tensor):

@@ -50,7 +50,11 @@ class _ConvBNReLU(nn.Sequential):
                     return _FusedConv0BNReLU.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                                    bn.running_var, bn.eps, bn.momentum)
                 wino = _wino_train_conv(conv, x)
-                if wino is not None:
+                sums0 = None
+                if wino is not None and wino[0] and SW.FUSED_BN_STATS:
+                    # a HIP kernel runs the forward: the BatchNorm's statistics come out of its epilogue (no pass over z for them)
+                    z, sums0 = _WinoConv3x3.apply(x, conv.weight, wino[0], wino[1], wino[2], True)
+                elif wino is not None:
                     z = _WinoConv3x3.apply(x, conv.weight, wino[0], wino[1], wino[2])
                 else:
                     z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
@@ -58,7 +62,7 @@ class _ConvBNReLU(nn.Sequential):
                     _count_batch(bn)
                     fold = SW.FUSED_BN_POOL and _is_pool_2x2_same(pool)
                     y = _FusedBiasBNReLU.apply(z, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                               bn.eps, bn.momentum, fold)
+                                               bn.eps, bn.momentum, fold, sums0)
                     return y if (fold or pool is None) else pool(y)
                 y = self[2](bn(z + conv.bias.view(1, -1, 1, 1) if conv.bias is not None else z))
                 return y if pool is None else pool(y)

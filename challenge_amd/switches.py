@@ -25,6 +25,9 @@ def _on(name: str, default: str = "1") -> bool:
 FUSED_BN_RELU = _on("IRIS_FUSED_BN")
 FUSED_FC_BN = _on("IRIS_FUSED_FC_BN")        # Dense + BatchNorm1d + ReLU through the same passes
 FUSED_BN_POOL = _on("IRIS_FUSED_BN_POOL")    # a block's MaxPool inside its last layer's passes
+# round 6: the forward statistics (sum z, sum z^2) come out of the convolution kernel's epilogue wherever a HIP convolution produces z
+# (Winograd, split-bf16 Winograd, the 32 -> 32 kernel): the iris_bn_stats pass over z disappears; 0: the separate pass
+FUSED_BN_STATS = _on("IRIS_FUSED_BN_STATS")
 FUSED_CONV0 = _on("IRIS_FUSED_CONV0")        # the first layer (1-2 input channels): convolution recomputed inside every pass
 FUSED_LSTM = _on("IRIS_FUSED_LSTM")          # Bidirectional(LSTM(128)): each pass through time in one launch (k_lstm.h)
 # zero-initialised scratch (BatchNorm sums, first-layer dW copies, zero bias gradients) from one pool with one fill per step
@@ -70,6 +73,6 @@ DDP_BUCKET_MB = int(os.environ.get("IRIS_DDP_BUCKET_MB", "12"))
 # --- test hook ------------------------------------------------------------------------------------------------------------------------
 _PLAN_CHECK_ON_CPU = False  # tests/test_ddp_gloo.py: consult the frontend plans' status for a CPU-resident loss too
 
-NAMES = ("FUSED_BN_RELU", "FUSED_FC_BN", "FUSED_BN_POOL", "FUSED_CONV0", "FUSED_LSTM", "ZERO_POOL", "WINO_TRAIN",
+NAMES = ("FUSED_BN_RELU", "FUSED_FC_BN", "FUSED_BN_POOL", "FUSED_BN_STATS", "FUSED_CONV0", "FUSED_LSTM", "ZERO_POOL", "WINO_TRAIN",
          "WINO_TRAIN_MIN_C_FWD", "WINO_TRAIN_MIN_C_BWD", "WINO_TRAIN_WRW", "C32_TRAIN", "WINO_SPLIT_BF16", "WINO_CONVS", "GRAPH_STEP", "DDP_BUCKET_MB",
          "_PLAN_CHECK_ON_CPU")

@@ -308,7 +308,23 @@ int iris_bias_relu_maxpool(const float* x, const float* bias, float* y, int batc
  * NOT in-place: y (and p below) must not overlap z - every block of the apply passes reads K back from row 0 of z while
  * others write their outputs (IRIS_E_INVALID otherwise).
  */
+/* Round 6: the forward statistics can come out of the CONVOLUTION's epilogue instead (iris_conv3x3_wino_bn, iris_conv3x3_wino_b3_bn,
+ * iris_conv3x3_c32_bn: the bare convolution + sum z / sum z^2 per output channel into a zeroed [iris_bn_sums_len] buffer, accumulated
+ * from the registers z is stored from) - the iris_bn_stats pass over z disappears; the *_sums0 forms of the apply entry points
+ * consume sums taken about zero (iris_bn_stats' are taken about row 0 of z).  Replaces the same layers of sj_train.py:191-201. */
 size_t iris_bn_sums_len(int channels);
+int iris_bn_relu_apply_sums0(const float* z, float* y, size_t rows, int channels, const double* sums, const float* gamma,
+                             const float* beta, const float* conv_bias, float eps, float momentum, float* running_mean,
+                             float* running_var, float* save_mean, float* save_rstd, void* stream);
+int iris_bn_relu_pool_apply_sums0(const float* z, float* p, int batch, int height, int width, int channels, const double* sums,
+                                  const float* gamma, const float* beta, const float* conv_bias, float eps, float momentum,
+                                  float* running_mean, float* running_var, float* save_mean, float* save_rstd, void* stream);
+int iris_conv3x3_wino_bn(const float* x, const float* packed, float* y, int batch, int height, int width, int cin, int cout, int flags,
+                         double* bn_sums_zeroed, void* stream);
+int iris_conv3x3_wino_b3_bn(const float* x, const float* packed, float* y, int batch, int height, int width, int cin, int cout, int flags,
+                            double* bn_sums_zeroed, void* stream);
+int iris_conv3x3_c32_bn(const float* x, const float* weight, long stride_o, long stride_i, long stride_h, long stride_w, float* y,
+                        int batch, int height, int width, double* bn_sums_zeroed, void* stream);
 int iris_bn_stats(const float* z, size_t rows, int channels, double* sums_zeroed, void* stream);
 int iris_bn_relu_apply(const float* z, float* y, size_t rows, int channels, const double* sums, const float* gamma,
                        const float* beta, const float* conv_bias, float eps, float momentum, float* running_mean,

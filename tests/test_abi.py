@@ -305,7 +305,9 @@ def test_winograd_kernel_hand_set_waits_match_its_requests(device_asm):
             checked += 1
         scratch = int(re.search(r"\.amdhsa_kernel " + re.escape(head) + r"\s.*?\.amdhsa_private_segment_fixed_size (\d+)", text, re.S).group(1))
         pooled = head.startswith("_Z14k_conv3x3_winoILb1")
-        assert scratch == 0 if pooled else scratch <= 128, (head, scratch)
+        # (unpooled forms: a few dozen bytes of spilled epilogue / prologue state outside the K loop - 120-132 bytes since round 6,
+        # when the epilogue also accumulates the BatchNorm statistics; the loop itself is checked scratch-free above)
+        assert scratch == 0 if pooled else scratch <= 160, (head, scratch)
     assert checked == 24
 
 

@@ -1166,6 +1166,50 @@ def test_winograd_convolution_matches_fp64(dev, b, h, w, cin, cout):
         FE.conv3x3_wino_bias_relu(x, packed, bias, cout)            # not the chunked layout
 
 
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("b,h,w,cin,cout,offset", [(3, 16, 128, 64, 128, 0.0), (2, 7, 9, 32, 64, 0.0), (5, 4, 32, 256, 512, 0.0),
+                                                   (2, 33, 70, 32, 32, 0.0), (4, 8, 64, 128, 256, 30.0), (3, 9, 21, 32, 32, 30.0)])
+def test_batchnorm_statistics_from_the_convolution_epilogue(dev, b, h, w, cin, cout, offset, split, monkeypatch):
+    """Round 6: the convolution kernels of the training step (Winograd, split-bf16 Winograd, the 32 -> 32 kernel) accumulate the
+    statistics of the BatchNorm behind them in their epilogue (fp32 about a local shift per lane, fp64 about zero when flushed,
+    bn_epilogue.h) and `_FusedBiasBNReLU(..., sums0)` skips its pass over z.  Against the separate pass on the same z: outputs,
+    saved statistics and running statistics equal to fp32 rounding, gradients too; with an input offset (z's mean ~ 30x its
+    spread) the variance stays right; odd sizes (tiles outside the image must not be counted); pooled and unpooled."""
+    from challenge_amd import sj_train as S
+    from challenge_amd.hip_autograd import _FusedBiasBNReLU, _WinoConv3x3
+    if split and (cin % 16 or (cin, cout) == (32, 32)):
+        pytest.skip("the split-bf16 kernel takes 16 | cin and 64 | cout")
+    monkeypatch.setattr(S, "WINO_SPLIT_BF16", split)
+    g = torch.Generator(device=dev).manual_seed(b + h + cout)
+    x = (torch.randn(b, cin, h, w, generator=g, device=dev) + offset).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g, device=dev) * (2.0 / (9 * cin)) ** 0.5 + (0.02 if offset else 0.0))
+    wt = wt.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gamma, beta = torch.rand(cout, generator=g, device=dev) + 0.5, torch.randn(cout, generator=g, device=dev) * 0.1
+    fwd = 'c32' if (cin, cout) == (32, 32) else True
+    for pool in (False, True):
+        outs = []
+        for fused in (True, False):
+            rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+            w_ = wt.detach().clone().requires_grad_(True)
+            if fused:
+                z, sums0 = _WinoConv3x3.apply(x, w_, fwd, False, False, True)
+                assert sums0 is not None and sums0.dtype == torch.float64
+            else:
+                z, sums0 = _WinoConv3x3.apply(x, w_, fwd, False, False), None
+            y = _FusedBiasBNReLU.apply(z, None, gamma, beta, rm, rv, 1e-3, 0.01, pool, sums0)
+            y.backward(torch.ones_like(y))
+            outs.append((y.detach(), rm, rv, w_.grad, z.detach()))
+        (y1, m1, v1, g1, z1), (y0, m0, v0, g0, z0) = outs
+        assert torch.equal(z1, z0)                                     # the convolution itself does not change
+        zd = z0.double()
+        mean64, var64 = zd.mean((0, 2, 3)), zd.var((0, 2, 3), unbiased=True)
+        for got_m, got_v in ((m1, v1), (m0, v0)):                     # both forms against fp64 on the same z
+            assert float((got_m.double() - 0.01 * mean64).abs().max()) <= 1e-6 * float(mean64.abs().max()) * 0.01 + 1e-9
+            assert float(((got_v.double() - 0.99) - 0.01 * var64).abs().max()) <= 2e-6 * float(var64.max()) * 0.01 + 1e-9
+        assert float((y1 - y0).abs().max()) <= 2e-6 * float(y0.abs().max()) + 1e-6, (pool, float((y1 - y0).abs().max()))
+        assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-9
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout", [(2, 32, 256, 32, 64), (2, 32, 256, 64, 64), (3, 16, 128, 64, 128), (2, 16, 128, 128, 128),
                                             (5, 8, 64, 256, 256), (3, 4, 32, 512, 512), (7, 2, 16, 512, 512),     # the CRNN's own shapes
                                             (2, 40, 256, 32, 64), (3, 5, 32, 256, 512), (1, 7, 9, 16, 64), (2, 3, 70, 48, 128),
