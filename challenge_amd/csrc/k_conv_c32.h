@@ -68,7 +68,8 @@ __device__ __forceinline__ void c32_groups(float (&abuf)[2][8], const float (&br
 // RAW: the bare convolution of a TRAINING pass (BatchNorm follows: no bias, no ReLU), channels-last out, the weight read with its
 // own element strides (so / si / sh / sw over [cout][cin][3][3]: a channels_last parameter as it is) and, with `transposed`, as
 // the backward-data pass needs it: W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]
-template <bool POOL, bool CHUNKED = false, bool RAW = false>
+// BN (RAW only): also accumulate the statistics of the BatchNorm behind the convolution - a template parameter (see k_conv_wino_b3.h)
+template <bool POOL, bool CHUNKED = false, bool RAW = false, bool BN = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int H,
                                                         int W, long so = 0, long si = 0, long sh = 0, long sw = 0, int transposed = 0,
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
     // bn_sums (RAW only): sum z / sum z^2 per output channel for the BatchNorm behind the convolution (bn_epilogue.h).  A lane's
     // channel is the same for every tile of this persistent workgroup: fp32 partial sums per patch, fp64 running totals in
     // registers, ONE pair of atomics per lane when the workgroup has walked its tiles
-    double bn_t1 = 0.0, bn_t2 = 0.0;
+    [[maybe_unused]] double bn_t1 = 0.0, bn_t2 = 0.0;
     extern __shared__ float halo[];  // [6][66][33 (+ row padding)]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hl = lane >> 5, i = lane & 31;
@@ -141,24 +142,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
             c32_groups<0>(abuf, breg, acc, a_addr);
             // accumulator register r of this lane: MFMA row (r & 3) + 8 (r >> 2) + 4 hl, column = output channel lane & 31
             if constexpr (!POOL) {
-                BnEpilogue bn = {acc[0], 0.f, 0.f, 0.f};
+                [[maybe_unused]] BnEpilogue bn = {acc[0], 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row_i = (r & 3) + 8 * (r >> 2) + 4 * hl;
                     const int orow = h0 + 2 * t + ((row_i >> 1) & 1), ocol = w0 + 16 * wv + 2 * (row_i >> 2) + (row_i & 1);
-                    if constexpr (RAW) {
-                        if (bn_sums != nullptr) bn_epilogue_add(bn, acc[r], (orow < H && ocol < W) ? 1.f : 0.f);
-                    }
+                    if constexpr (RAW && BN) bn_epilogue_add(bn, acc[r], (orow < H && ocol < W) ? 1.f : 0.f);
                     if (orow < H && ocol < W)
                         y[CHUNKED ? ((((size_t)b * 4 + (i >> 3)) * H + orow) * W + ocol) * 8 + (i & 7)
                                   : (((size_t)b * H + orow) * W + ocol) * kC32 + i] = RAW ? acc[r] : fmaxf(acc[r] + bj, 0.f);
                 }
-                if constexpr (RAW) {
-                    if (bn_sums != nullptr) {   // this patch's share, about zero, in fp64
-                        const double K = (double)bn.k, n = (double)bn.n, S1 = (double)bn.s1, S2 = (double)bn.s2;
-                        bn_t1 += S1 + n * K;
-                        bn_t2 += S2 + 2.0 * K * S1 + n * K * K;
-                    }
+                if constexpr (RAW && BN) {   // this patch's share, about zero, in fp64
+                    const double K = (double)bn.k, n = (double)bn.n, S1 = (double)bn.s1, S2 = (double)bn.s2;
+                    bn_t1 += S1 + n * K;
+                    bn_t2 += S2 + 2.0 * K * S1 + n * K * K;
                 }
             } else {
                 const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
@@ -183,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const float* __restrict_
             }
         }
     }
-    if constexpr (RAW) {
-        if (bn_sums != nullptr && bn_t2 > 0.0) {
+    if constexpr (RAW && BN) {
+        if (bn_t2 > 0.0) {
             const int slot = (int)(blockIdx.x % (unsigned)bn_slots(kC32));
             atomicAdd(bn_sums + (size_t)slot * 2 * kC32 + i, bn_t1);
             atomicAdd(bn_sums + (size_t)slot * 2 * kC32 + kC32 + i, bn_t2);
@@ -205,14 +202,20 @@ static int conv3x3_c32_impl(const float* x, const float* weight, long stride_o, 
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c32<false, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC32LdsBytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c32<false, false, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC32LdsBytes));
         if (dev >= 0 && dev < 64) attr_set[dev].store(1u, std::memory_order_release);
     }
     const long long n_tiles = (long long)((width + kC32TileW - 1) / kC32TileW) * ((height + kC32TileH - 1) / kC32TileH) * batch;
     if (n_tiles >= 2147483647LL) return fail(IRIS_E_UNSUPPORTED, "iris_conv3x3_c32: too many tiles");
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const unsigned grid = (unsigned)std::min<long long>(n_tiles, 2LL * n_cu);
-    k_conv3x3_c32<false, false, true><<<grid, 256, kC32LdsBytes, (hipStream_t)stream>>>(x, weight, nullptr, y, batch, height, width, stride_o,
-                                                                                         stride_i, stride_h, stride_w, transposed, bn_sums);
+    if (bn_sums)
+        k_conv3x3_c32<false, false, true, true><<<grid, 256, kC32LdsBytes, (hipStream_t)stream>>>(x, weight, nullptr, y, batch, height, width,
+                                                                                                   stride_o, stride_i, stride_h, stride_w, transposed, bn_sums);
+    else
+        k_conv3x3_c32<false, false, true><<<grid, 256, kC32LdsBytes, (hipStream_t)stream>>>(x, weight, nullptr, y, batch, height, width, stride_o,
+                                                                                             stride_i, stride_h, stride_w, transposed, nullptr);
     HIP_TRY(hipGetLastError());
     return IRIS_OK;
 }

@@ -103,12 +103,13 @@ struct WinoWave {
 // in_nhwc: x is channels-last [B][H][W][Cin] (a chunk of a pixel = 32 bytes at a stride of Cin x 4: every gather touches 64
 // cache lines instead of 16 - 14 % slower over the CRNN's layers, what a training pass pays for keeping its activations where
 // the weight-gradient kernel (k_conv_wino_wrw.h: lane = channel) reads them); relu == 0 and bias == nullptr: the bare convolution (training: BatchNorm follows)
-template <bool POOL, int TC, bool IN_NHWC>
+template <bool POOL, int TC, bool IN_NHWC, bool BN = false>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict__ x, const float* __restrict__ u,
                                                          const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
                                                          int Cin, int Cout, int out_nhwc, int relu, double* __restrict__ bn_sums) {
-    // bn_sums (training form only: bare convolution, channels-last out, no pooling): the per-channel sum z / sum z^2 of the
-    // BatchNorm that follows, accumulated here from the registers the output is stored from (bn_epilogue.h)
+    // BN / bn_sums (training form only: bare convolution, channels-last out, no pooling): the per-channel sum z / sum z^2 of the
+    // BatchNorm that follows, accumulated here from the registers the output is stored from (bn_epilogue.h); a template parameter so
+    // that the instantiations without it are exactly the code measured before (see k_conv_wino_b3.h)
     constexpr bool in_nhwc = IN_NHWC;
     extern __shared__ __attribute__((aligned(16))) float wino_lds[];
     constexpr int TR = kWinoTM / TC, PW = 2 * TC + 2, kPieces = TR * 3 * PW, kDmaRows = (kPieces + 63) / 64;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
             e_base[ss] = y + (size_t)b_ * Ho * Wo * Cout + (out_nhwc ? (size_t)co : ((size_t)(co >> 3) * Ho * Wo) * 8 + (co & 7))
                          + (size_t)(POOL ? th_ : 2 * th_) * Wo * ps;
         }
-        BnEpilogue bn = {0.f, 0.f, 0.f, 0.f};
+        [[maybe_unused]] BnEpilogue bn = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hl;
@@ -339,8 +340,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
                 }
                 pooled = fmaxf(pooled + bj, floor_);
             }
-            if constexpr (!POOL) {
-                if (bn_sums != nullptr) {   // (uniform) the statistics of what is stored below: z itself (no bias, no ReLU here)
+            if constexpr (BN && !POOL) {
+                {   // the statistics of what is stored below: z itself (no bias, no ReLU here)
                     if (r == 0) bn.k = o[0][0];
                     const float in_tile = (e_ok[ss] && tw_ < TW) ? 1.f : 0.f, c1 = col1 ? in_tile : 0.f, r1 = e_row1[ss] ? 1.f : 0.f;
                     bn_epilogue_add(bn, o[0][0], in_tile);
@@ -376,9 +377,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino(const float* __restrict
                 }
             }
         }
-        if constexpr (!POOL) {
-            if (bn_sums != nullptr) bn_epilogue_flush(bn, bn_sums, Cout, co, (int)(blockIdx.x % (unsigned)bn_slots(Cout)));
-        }
+        if constexpr (BN && !POOL) bn_epilogue_flush(bn, bn_sums, Cout, co, (int)(blockIdx.x % (unsigned)bn_slots(Cout)));
         if (!direct) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave reads back what its own lanes wrote: LDS operations
             __builtin_amdgcn_wave_barrier();                         // of a wave execute in order, this only pins the compiler
@@ -500,19 +499,19 @@ extern "C" int iris_wino_pack_weights_device(const float* weight, long stride_o,
     return IRIS_OK;
 }
 
-template <bool POOL, bool IN_NHWC>
+template <bool POOL, bool IN_NHWC, bool BN = false>
 static hipError_t wino_launch(int tc, unsigned grid, hipStream_t s, const float* x, const float* packed, const float* bias,
                               float* y, int batch, int height, int width, int cin, int cout, int out_nhwc, int relu, double* bn_sums) {
-    if (tc >= 64) k_conv3x3_wino<POOL, 64, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
-    else if (tc >= 32) k_conv3x3_wino<POOL, 32, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
-    else k_conv3x3_wino<POOL, 16, IN_NHWC><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    if (tc >= 64) k_conv3x3_wino<POOL, 64, IN_NHWC, BN><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else if (tc >= 32) k_conv3x3_wino<POOL, 32, IN_NHWC, BN><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else k_conv3x3_wino<POOL, 16, IN_NHWC, BN><<<grid, 256, kWinoLdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
     return hipGetLastError();
 }
 
-template <bool POOL, bool IN_NHWC>
+template <bool POOL, bool IN_NHWC, bool BN = false>
 static hipError_t wino_set_lds_limit() {
-    const void* ks[3] = {(const void*)k_conv3x3_wino<POOL, 64, IN_NHWC>, (const void*)k_conv3x3_wino<POOL, 32, IN_NHWC>,
-                         (const void*)k_conv3x3_wino<POOL, 16, IN_NHWC>};
+    const void* ks[3] = {(const void*)k_conv3x3_wino<POOL, 64, IN_NHWC, BN>, (const void*)k_conv3x3_wino<POOL, 32, IN_NHWC, BN>,
+                         (const void*)k_conv3x3_wino<POOL, 16, IN_NHWC, BN>};
     for (const void* k : ks) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLdsBytes);
         if (e != hipSuccess) return e;
@@ -543,6 +542,8 @@ static int conv3x3_wino_impl(const float* x, const float* packed, const float* b
         HIP_TRY((wino_set_lds_limit<false, true>()));
         HIP_TRY((wino_set_lds_limit<true, false>()));
         HIP_TRY((wino_set_lds_limit<true, true>()));
+        HIP_TRY((wino_set_lds_limit<false, false, true>()));
+        HIP_TRY((wino_set_lds_limit<false, true, true>()));
         if (dev >= 0 && dev < 64) attr_set[dev].store(1u, std::memory_order_release);
     }
     const int pool = (flags & IRIS_WINO_POOL) != 0, out_nhwc = (flags & IRIS_WINO_OUT_NHWC) != 0;
@@ -557,8 +558,10 @@ static int conv3x3_wino_impl(const float* x, const float* packed, const float* b
     hipError_t e;
     if (pool) e = in_nhwc ? wino_launch<true, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr)
                           : wino_launch<true, false>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr);
-    else e = in_nhwc ? wino_launch<false, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums)
-                     : wino_launch<false, false>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else if (bn_sums) e = in_nhwc ? wino_launch<false, true, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums)
+                                  : wino_launch<false, false, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else e = in_nhwc ? wino_launch<false, true>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr)
+                     : wino_launch<false, false>(tc, grid, st, x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr);
     HIP_TRY(e);
     return IRIS_OK;
 }

@@ -168,7 +168,10 @@ extern "C" int iris_b3_read_stamps(unsigned long long* host) {
 #endif
 
 // ---- the convolution --------------------------------------------------------------------------------------------------------
-template <bool POOL, int TC, bool IN_NHWC>
+// BN: also accumulate the statistics of the BatchNorm behind the convolution (training form only).  A TEMPLATE parameter, not a test of
+// the pointer: with the test in the kernel the build for bn_sums == nullptr faulted on the 32-tile-column geometry (the code with the
+// branch compiled out did not: profiles/r6/b3_bn_runtime_branch_fault.log) - the instantiation without BN is the code that was measured
+template <bool POOL, int TC, bool IN_NHWC, bool BN = false>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restrict__ x, const uint4* __restrict__ u3,
                                                             const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
                                                             int Cin, int Cout, int out_nhwc, int relu, double* __restrict__ bn_sums) {
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
             const float floor_ = relu ? 0.f : -INFINITY;
             const int Ho = POOL ? TH : H, Wo = POOL ? TW : W;
             const int ps = out_nhwc ? Cout : 8;   // floats between pixels
-            BnEpilogue bn = {0.f, 0.f, 0.f, 0.f};   // training form: the statistics of the BatchNorm behind this convolution (bn_epilogue.h)
+            [[maybe_unused]] BnEpilogue bn = {0.f, 0.f, 0.f, 0.f};   // BN: the statistics of the BatchNorm behind this convolution (bn_epilogue.h)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 float4 sv[4][2];
@@ -511,8 +514,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
                     const int tw_ = tc0 + tcol;
                     const int ow = 2 * tw_;
                     const bool col1 = ow + 1 < W, row1 = 2 * th_ + 1 < H;
-                    if constexpr (!POOL) {
-                        if (bn_sums != nullptr) {   // (uniform)
+                    if constexpr (BN && !POOL) {
+                        {
                             if (r == 0) bn.k = o[0][0];
                             const float in_tile = (s_ok[strip] && tw_ < TW) ? 1.f : 0.f, c1 = col1 ? in_tile : 0.f, r1 = row1 ? 1.f : 0.f;
                             bn_epilogue_add(bn, o[0][0], in_tile);
@@ -543,27 +546,25 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino_b3(const float* __restr
                     }
                 }
             }
-            if constexpr (!POOL) {
-                if (bn_sums != nullptr) bn_epilogue_flush(bn, bn_sums, Cout, co, (int)(blockIdx.x % (unsigned)bn_slots(Cout)));
-            }
+            if constexpr (BN && !POOL) bn_epilogue_flush(bn, bn_sums, Cout, co, (int)(blockIdx.x % (unsigned)bn_slots(Cout)));
         }
         B3_STAMP(item, 5);
     }
 }
 
-template <bool POOL, bool IN_NHWC>
+template <bool POOL, bool IN_NHWC, bool BN = false>
 static hipError_t wino_b3_launch(int tc, unsigned grid, hipStream_t s, const float* x, const uint4* packed, const float* bias, float* y,
                                  int batch, int height, int width, int cin, int cout, int out_nhwc, int relu, double* bn_sums) {
-    if (tc >= 64) k_conv3x3_wino_b3<POOL, 64, IN_NHWC><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
-    else if (tc >= 32) k_conv3x3_wino_b3<POOL, 32, IN_NHWC><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
-    else k_conv3x3_wino_b3<POOL, 16, IN_NHWC><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    if (tc >= 64) k_conv3x3_wino_b3<POOL, 64, IN_NHWC, BN><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else if (tc >= 32) k_conv3x3_wino_b3<POOL, 32, IN_NHWC, BN><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else k_conv3x3_wino_b3<POOL, 16, IN_NHWC, BN><<<grid, 256, kB3LdsBytes, s>>>(x, packed, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
     return hipGetLastError();
 }
 
-template <bool POOL, bool IN_NHWC>
+template <bool POOL, bool IN_NHWC, bool BN = false>
 static hipError_t wino_b3_set_lds_limit() {
-    const void* ks[3] = {(const void*)k_conv3x3_wino_b3<POOL, 64, IN_NHWC>, (const void*)k_conv3x3_wino_b3<POOL, 32, IN_NHWC>,
-                         (const void*)k_conv3x3_wino_b3<POOL, 16, IN_NHWC>};
+    const void* ks[3] = {(const void*)k_conv3x3_wino_b3<POOL, 64, IN_NHWC, BN>, (const void*)k_conv3x3_wino_b3<POOL, 32, IN_NHWC, BN>,
+                         (const void*)k_conv3x3_wino_b3<POOL, 16, IN_NHWC, BN>};
     for (const void* k : ks) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kB3LdsBytes);
         if (e != hipSuccess) return e;
@@ -593,6 +594,8 @@ static int conv3x3_wino_b3_impl(const float* x, const float* packed, const float
         HIP_TRY((wino_b3_set_lds_limit<false, true>()));
         HIP_TRY((wino_b3_set_lds_limit<true, false>()));
         HIP_TRY((wino_b3_set_lds_limit<true, true>()));
+        HIP_TRY((wino_b3_set_lds_limit<false, false, true>()));
+        HIP_TRY((wino_b3_set_lds_limit<false, true, true>()));
         if (dev >= 0 && dev < 64) attr_set[dev].store(1u, std::memory_order_release);
     }
     const int pool = (flags & IRIS_WINO_POOL) != 0, out_nhwc = (flags & IRIS_WINO_OUT_NHWC) != 0;
@@ -608,8 +611,10 @@ static int conv3x3_wino_b3_impl(const float* x, const float* packed, const float
     hipError_t e;
     if (pool) e = in_nhwc ? wino_b3_launch<true, true>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr)
                           : wino_b3_launch<true, false>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr);
-    else e = in_nhwc ? wino_b3_launch<false, true>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums)
-                     : wino_b3_launch<false, false>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else if (bn_sums) e = in_nhwc ? wino_b3_launch<false, true, true>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums)
+                                  : wino_b3_launch<false, false, true>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, bn_sums);
+    else e = in_nhwc ? wino_b3_launch<false, true>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr)
+                     : wino_b3_launch<false, false>(tc, grid, st, x, pk, bias, y, batch, height, width, cin, cout, out_nhwc, relu, nullptr);
     HIP_TRY(e);
     return IRIS_OK;
 }

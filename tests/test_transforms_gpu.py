@@ -1204,8 +1204,9 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(dev, b, h, w, cin, c
         zd = z0.double()
         mean64, var64 = zd.mean((0, 2, 3)), zd.var((0, 2, 3), unbiased=True)
         for got_m, got_v in ((m1, v1), (m0, v0)):                     # both forms against fp64 on the same z
-            assert float((got_m.double() - 0.01 * mean64).abs().max()) <= 1e-6 * float(mean64.abs().max()) * 0.01 + 1e-9
-            assert float(((got_v.double() - 0.99) - 0.01 * var64).abs().max()) <= 2e-6 * float(var64.max()) * 0.01 + 1e-9
+            # (+ 2e-7: the running values are stored in fp32 - running_var sits near 1, one ulp = 1.2e-7)
+            assert float((got_m.double() - 0.01 * mean64).abs().max()) <= 1e-6 * float(mean64.abs().max()) * 0.01 + 2e-7
+            assert float(((got_v.double() - 0.99) - 0.01 * var64).abs().max()) <= 2e-6 * float(var64.max()) * 0.01 + 2e-7
         assert float((y1 - y0).abs().max()) <= 2e-6 * float(y0.abs().max()) + 1e-6, (pool, float((y1 - y0).abs().max()))
         assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-9
 
