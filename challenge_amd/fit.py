@@ -236,6 +236,13 @@ class GraphedTrainStep:
             self._buckets = _gradient_buckets(model.parameters(), SW.DDP_BUCKET_MB << 20)
             self._flats = [torch.zeros(sum(p.numel() for p in b), dtype=b[0].dtype, device=dev) for b in self._buckets]
         torch.cuda.synchronize(dev)
+        if self.world:
+            # The process group's watchdog thread polls the end events of the EAGER collectives it still holds (the warm-up steps'
+            # bucket all-reduces) every 100 ms.  Once the capture below has pulled RCCL's stream in, such a poll fails with
+            # "operation not permitted on an event last recorded in a capturing stream" and takes the process down (seen once in
+            # four runs: profiles/r6/rccl_watchdog_event_query_during_capture.log).  The device is idle now: give the watchdog three of
+            # its periods to retire every finished collective, so that it holds nothing while the capture runs.
+            time.sleep(0.35)
         self.graph = torch.cuda.CUDAGraph()
         self._pool_marks = {}
         ok, error = True, None

@@ -1208,7 +1208,8 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(dev, b, h, w, cin, c
             assert float((got_m.double() - 0.01 * mean64).abs().max()) <= 1e-6 * float(mean64.abs().max()) * 0.01 + 2e-7
             assert float(((got_v.double() - 0.99) - 0.01 * var64).abs().max()) <= 2e-6 * float(var64.max()) * 0.01 + 2e-7
         assert float((y1 - y0).abs().max()) <= 2e-6 * float(y0.abs().max()) + 1e-6, (pool, float((y1 - y0).abs().max()))
-        assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-9
+        # (with the 30-sigma input offset the weight gradient sums inputs ~30 times their spread: a 1e-6 difference in rstd shows at 2-3e-5)
+        assert float((g1 - g0).abs().max()) <= (1e-4 if offset else 2e-5) * float(g0.abs().max()) + 1e-9
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout", [(2, 32, 256, 32, 64), (2, 32, 256, 64, 64), (3, 16, 128, 64, 128), (2, 16, 128, 128, 128),
