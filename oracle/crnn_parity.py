@@ -9,7 +9,7 @@ the product's step.  Used by tests/test_fullsize_gpu.py and by bench.py's `extra
 on the timed batch.  Bounds (measured values: profiles/r6/fullsize_parity.log):
 
     c3  sigmoid outputs <= 1e-4 abs, pre-sigmoid activations <= 2e-5 of their peak          (measured 6e-8, 2.5e-7)
-    c4  loss <= 1e-6; outputs <= 2e-5 abs; BatchNorm running statistics <= 1e-6 of their peak (measured 1e-8, 6.6e-6, 8.5e-8)
+    c4  loss <= 1e-6; outputs <= 2e-5 abs; BatchNorm running statistics <= 1e-6 of their peak + 0.05 (measured 1e-8, 6.6e-6, 8.5e-8)
         every gradient <= 5e-5 of its peak   (measured 2.0e-5 at the c4 size, on the LSTM biases, 1.2 - 1.8e-5 elsewhere; 3.5e-5 at
                                               batch 4 x 128 frames; the STOCK fp32 layers read 1.0 - 2.0e-5 against the same fp64
                                               reference wherever no decision flips: it is the fp32 step's own rounding - BatchNorm's
@@ -150,7 +150,11 @@ def c4_parity(model, feats, y, clipvalue=0.01, unmatched: bool = True, stock_fp3
     want_clipped = [g.clamp(-clipvalue, clipvalue) if clipvalue else g
                     for g in R.adaptive_clip_grad(params64, [g.double() for g in g_a])]
     agc_err, agc_where = worst(got_clipped, want_clipped)                      # the AGC + clipvalue launch on the same gradients
-    bufs = [(_rel(a, b), n) for (n, a), b in zip(m_a.named_buffers(), r64.buffers()) if a.dtype.is_floating_point]
+    # BatchNorm running statistics: |d| against the buffer's peak + 0.05 - a running mean moves by 0.01 x the batch mean per step,
+    # which for a centred channel is ~1e-3 while its fp32 error is 0.01 x eps x |z| whatever the mean: the floor keeps that (5e-8
+    # absolute) from reading as a "relative" error of 2e-6 on a vector of near-zero means (seen at 32 rows in smoke())
+    bufs = [(float((a.double() - b.double()).abs().max()) / (float(b.double().abs().max()) + 0.05), n)
+            for (n, a), b in zip(m_a.named_buffers(), r64.buffers()) if a.dtype.is_floating_point]
     counters_ok = all(torch.equal(a.cpu(), b.cpu().to(a.dtype)) for (n, a), b in zip(m_a.named_buffers(), r64.buffers())
                       if not a.dtype.is_floating_point)
     out = {"checked": f"one training-mode forward / backward / AGC + clipvalue of the module on the timed batch {tuple(feats.shape)}, "
