@@ -492,7 +492,7 @@ def kernel_source_sha() -> str:
 
 
 def committed_traffic():
-    """HBM bytes per launch of the step's kernels from the committed PMC passes (profiles/r4/pmc_traffic.json,
+    """HBM bytes per launch of the step's kernels from the committed PMC passes (profiles/r6/pmc_traffic.json,
     written by scripts/pmc_summarise.py).  Refused (None + reason) when the kernel sources changed since.
     Returns (dominant-kernel bytes, whole-step bytes, note)."""
     path = os.path.join(ROOT, PMC_JSON)
