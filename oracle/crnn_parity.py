@@ -14,6 +14,12 @@ on the timed batch.  Bounds (measured values: profiles/r6/fullsize_parity.log):
                                               batch 4 x 128 frames; the STOCK fp32 layers read 1.0 - 2.0e-5 against the same fp64
                                               reference wherever no decision flips: it is the fp32 step's own rounding - BatchNorm's
                                               backward cancels sums - not a property of these kernels)
+          ... or, where a tensor reads more, <= 2x what the STOCK fp32 layers (RefCRNN in fp32, torch / MIOpen ops) read on that
+          tensor with the same decisions on the same batch.  Why: profiles/r6/c4_parity_hunt_*.log, 60 batches at the c4 size - on a
+          freshly initialised model the first block's BatchNorm gradients sit at 3e-5 .. 7e-5 in 11 of 20 batches FOR BOTH (product
+          7.10e-5 where stock reads 7.58e-5, 3.67e-5 / 3.68e-5, 4.51e-5 / 3.59e-5 ...; stock's own worst 9.9e-5), a few Adam steps in
+          both read 4e-6 .. 1e-5.  That tail is the conditioning of the batch in fp32, and a fixed bound cannot tell it from an
+          error; the stock layers' figure on the same tensor can.  The record says which gate a run passed (`gradient_gate`).
         AGC + clipvalue (one HIP launch over the whole model) applied to those gradients <= 2e-6 of each tensor's peak against
         the fp64 restatement of sj_train.py:145-155 applied to the SAME gradients; the end-to-end figure (product's clipped
         gradients vs the fp64 step's) is reported beside it: clipping shrinks a tensor's peak, not its small elements' error
@@ -28,7 +34,7 @@ import torch
 from . import crnn_ref as R
 
 BOUNDS = {"c3_sigmoid_abs": 1e-4, "c3_pre_sigmoid_rel": 2e-5, "c4_loss_abs": 1e-6, "c4_outputs_abs": 2e-5, "c4_bn_buffers_rel": 1e-6,
-          "c4_gradient_rel": 5e-5, "c4_agc_clip_rel": 2e-6, "c4_zero_gradient_rel": 1e-6}
+          "c4_gradient_rel": 5e-5, "c4_gradient_vs_stock_fp32": 2.0, "c4_agc_clip_rel": 2e-6, "c4_zero_gradient_rel": 1e-6}
 
 
 def _rel(a, b):
@@ -94,10 +100,12 @@ def _bn_fed_bias(name: str) -> bool:
     return (name.endswith(".0.bias") and name.startswith("features.")) or (name.endswith("fc.bias") and not name.startswith("head."))
 
 
-def c4_parity(model, feats, y, clipvalue=0.01, unmatched: bool = True, stock_fp32: bool = False) -> dict:
+def c4_parity(model, feats, y, clipvalue=0.01, unmatched: bool = True, stock_fp32: bool = False, stock_matched: bool = True) -> dict:
     """One training-mode forward / backward of (a copy of) `model` on (feats, y) with every HIP pass as the switches have it,
-    against the decision-matched fp64 reference.  `model` itself is not touched.  `unmatched`: also report the distance to the fp64
-    reference taking its OWN decisions (the flips); `stock_fp32`: and the stock fp32 layers' distance to it (slow: MIOpen find)."""
+    against the decision-matched fp64 reference.  `model` itself is not touched.  `stock_matched`: also run the STOCK fp32 layers with
+    the same decisions (one more reference pass; always run when a gradient reads above the fixed bound - it is the second gate).
+    `unmatched`: also report the distance to the fp64 reference taking its OWN decisions (the flips); `stock_fp32`: and the stock
+    fp32 layers' distance to it (slow: MIOpen find)."""
     from challenge_amd.hip_autograd import record_activations   # the checker reads the product's activations, never the reverse
     from challenge_amd.model import binary_crossentropy
     dev = feats.device
@@ -139,6 +147,20 @@ def c4_parity(model, feats, y, clipvalue=0.01, unmatched: bool = True, stock_fp3
         if _bn_fed_bias(n):
             zero_rows.append((float(g_a[k].abs().max()) / (float(g_a[k - 1].abs().max()) + 1e-300), n))
     grad_err, grad_where = worst(g_a, q['raw'])
+    # second gate (see the header): the stock fp32 layers on the same batch with the same decisions, tensor by tensor
+    grad_gate, stock_err, stock_where, ratio_worst, ratio_where = "fixed bound", None, None, None, None
+    grad_ok = grad_err <= BOUNDS["c4_gradient_rel"]
+    if stock_matched or not grad_ok:
+        r32m = _ref_like(model, feats, torch.float32)
+        q32m = R.reference_step(r32m, feats, y, clipvalue=clipvalue, decisions=decisions)
+        stock_err, stock_where = worst(q32m['raw'], q['raw'])
+        over = [(_rel(a, b), _rel(c, b), n) for n, a, c, b in zip(names, g_a, q32m['raw'], q['raw'])
+                if not _bn_fed_bias(n) and _rel(a, b) > BOUNDS["c4_gradient_rel"]]
+        if over:
+            grad_gate = "stock fp32 layers, same decisions, same tensor"
+            ratio_worst, ratio_where = max((mine / (stock + 1e-300), n) for mine, stock, n in over)
+            grad_ok = ratio_worst <= BOUNDS["c4_gradient_vs_stock_fp32"]
+        del r32m, q32m
     # the whole train_step at learning rate 0: what AGC + clipvalue leave in p.grad
     m_c = clone_module(model)
     m_c.compile(torch.optim.Adam(m_c.parameters(), lr=0.0, eps=1e-7), binary_crossentropy, clipvalue=clipvalue)
@@ -161,7 +183,9 @@ def c4_parity(model, feats, y, clipvalue=0.01, unmatched: bool = True, stock_fp3
                       "every HIP pass on, vs oracle.crnn_ref.RefCRNN in fp64 taking the same ReLU / max-pool decisions",
            "loss": float(loss_a), "loss_abs": abs(float(loss_a) - float(q['loss'])), "train_step_loss_abs": abs(float(step_loss) - float(q['loss'])),
            "outputs_abs": float((out_a.double() - q['out']).abs().max()),
-           "gradient_rel_worst": grad_err, "gradient_rel_worst_where": grad_where,
+           "gradient_rel_worst": grad_err, "gradient_rel_worst_where": grad_where, "gradient_gate": grad_gate,
+           "stock_fp32_same_decisions_gradient_rel_worst": stock_err, "stock_fp32_same_decisions_where": stock_where,
+           "gradient_over_stock_fp32_worst_above_the_fixed_bound": ratio_worst, "gradient_over_stock_fp32_where": ratio_where,
            "agc_clip_rel_worst": agc_err, "agc_clip_where": agc_where,
            "gradient_after_agc_clip_vs_fp64_step_rel_worst": clip_err, "gradient_after_agc_clip_where": clip_where,
            "zero_gradient_rel_worst": max(zero_rows)[0] if zero_rows else 0.0,
@@ -170,10 +194,11 @@ def c4_parity(model, feats, y, clipvalue=0.01, unmatched: bool = True, stock_fp3
            "decisions": {"relu_masks": len(decisions.conv_masks) + len(decisions.fc_masks) + 1, "pool_maps": len(decisions.pool_slots),
                          "rederived_and_verified_bitwise": decisions.rederived},
            "bounds": {"loss_abs": BOUNDS["c4_loss_abs"], "outputs_abs": BOUNDS["c4_outputs_abs"], "gradient_rel": BOUNDS["c4_gradient_rel"],
+                      "gradient_over_stock_fp32_where_above": BOUNDS["c4_gradient_vs_stock_fp32"],
                       "agc_clip_rel": BOUNDS["c4_agc_clip_rel"], "zero_gradient_rel": BOUNDS["c4_zero_gradient_rel"],
                       "bn_buffers_rel": BOUNDS["c4_bn_buffers_rel"]}}
     ok = (out["loss_abs"] <= BOUNDS["c4_loss_abs"] and out["train_step_loss_abs"] <= BOUNDS["c4_loss_abs"]
-          and out["outputs_abs"] <= BOUNDS["c4_outputs_abs"] and grad_err <= BOUNDS["c4_gradient_rel"]
+          and out["outputs_abs"] <= BOUNDS["c4_outputs_abs"] and grad_ok
           and agc_err <= BOUNDS["c4_agc_clip_rel"] and out["zero_gradient_rel_worst"] <= BOUNDS["c4_zero_gradient_rel"]
           and out["bn_buffers_rel_worst"] <= BOUNDS["c4_bn_buffers_rel"] and counters_ok
           and run_to_run <= 1e-5)   # (bit-reproducible up to the BatchNorm sums' fp64 atomics: a last-bit event once in ~1e5 runs)

@@ -140,3 +140,31 @@ def test_c3_and_c4_full_size_with_the_split_bf16_convolutions(setup, monkeypatch
     res4 = P.c4_parity(model, feats, y, clipvalue=cfg.clipvalue, unmatched=False)
     print("c4 full size, split bf16:", res4)
     assert res4["ok"], res4
+
+
+def test_c4_gradient_tail_on_a_fresh_model_is_the_fp32_steps_own(setup):
+    """profiles/r6/c4_parity_hunt_*.log: on a freshly initialised model at batch 64 x 512 frames the first block's BatchNorm gradients
+    read 3e-5 .. 7e-5 of their peak against the decision-matched fp64 reference in about half of all batches - for the STOCK fp32
+    layers with the same decisions just as for this repository's kernels.  The parity leg therefore has a second gate behind its fixed
+    5e-5 (<= 2x the stock layers' figure on the same tensor); here: four fresh batches pass, the stock figure is always reported,
+    and whenever the fixed bound is exceeded the record says which gate decided."""
+    from oracle import crnn_parity as P
+    S, cfg, _, fe, _, _, _ = setup
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(100)
+    model = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    gen = torch.Generator(device=dev).manual_seed(2024)
+    seen = []
+    for _ in range(4):
+        wav = torch.randn(BATCH, 1, LENGTH, generator=gen, device=dev) * 0.1
+        y = (torch.rand(BATCH, N_FRAME // 32, 3, generator=gen, device=dev) < 0.1).float()
+        res = P.c4_parity(model, fe(wav), y, clipvalue=cfg.clipvalue, unmatched=False)
+        seen.append((res["gradient_rel_worst"], res["stock_fp32_same_decisions_gradient_rel_worst"], res["gradient_gate"]))
+        assert res["ok"], res
+        assert res["stock_fp32_same_decisions_gradient_rel_worst"] is not None
+        if res["gradient_rel_worst"] > P.BOUNDS["c4_gradient_rel"]:
+            assert res["gradient_gate"].startswith("stock fp32")
+            assert res["gradient_over_stock_fp32_worst_above_the_fixed_bound"] <= P.BOUNDS["c4_gradient_vs_stock_fp32"]
+        else:
+            assert res["gradient_gate"] == "fixed bound"
+    print("fresh model, product / stock fp32 (same decisions) / gate:", seen)
