@@ -274,14 +274,16 @@ def test_winograd_kernel_hand_set_waits_match_its_requests(device_asm):
     every steady-state chunk body the wave requests 7 rows of input, then 8 rows of U, and `s_waitcnt vmcnt(8)` in front of the
     patch reads relies on exactly that order - a wave's vector-memory operations return in order, so at most the 8 YOUNGER U
     requests may be outstanding once the input has landed.  Checked on the assembly of all twelve variants (pooled or not x
-    tile columns x input layout): in each loop body with the 64 MFMAs of a chunk and the hand-set wait, the vector-memory
+    tile columns x input layout, + the six BatchNorm-statistics forms): in each loop body with the 64 MFMAs of a chunk and the hand-set wait, the vector-memory
     instructions in front of the wait are 15 LDS-DMA requests and nothing else, and the loop has no scratch access.  (The
     unpooled variants sit at the 256 + 256 register limit of a one-wave-per-SIMD kernel and keep up to 31 dwords of per-work-item
     geometry in scratch OUTSIDE the chunk loop - stored once, reloaded once per 64 x 64 block; the pooled ones use none.)"""
     import re
     text = open(device_asm).read()
-    fns = re.split(r"\n(?=_Z14k_conv3x3_winoILb[01]ELi\d+ELb[01]EE[^\n]*:\s)", text)
-    assert len(fns) == 13, len(fns)   # preamble + 2 (pooled or not) x 3 (tile columns) x 2 (chunked / channels-last input)
+    fns = re.split(r"\n(?=_Z14k_conv3x3_winoILb[01]ELi\d+ELb[01]ELb[01]EE[^\n]*:\s)", text)
+    # preamble + 2 (pooled or not) x 3 (tile columns) x 2 (chunked / channels-last input) + the 6 unpooled forms that also accumulate
+    # the BatchNorm statistics in their epilogue (template parameter BN)
+    assert len(fns) == 19, len(fns)
     checked = 0
     for fn in fns[1:]:
         head = fn.split(":", 1)[0]
@@ -308,7 +310,7 @@ def test_winograd_kernel_hand_set_waits_match_its_requests(device_asm):
         # (unpooled forms: a few dozen bytes of spilled epilogue / prologue state outside the K loop - 120-132 bytes since round 6,
         # when the epilogue also accumulates the BatchNorm statistics; the loop itself is checked scratch-free above)
         assert scratch == 0 if pooled else scratch <= 160, (head, scratch)
-    assert checked == 24
+    assert checked == 36
 
 
 def test_winograd_weight_gradient_kernel_fits_two_waves_per_simd(device_asm):
