@@ -36,6 +36,8 @@ SIGNATURES = {
     "iris_plan_num_frames": (_i, [_vp, _i]),
     "iris_normalize_workspace": (_sz, [_i, _sz]),
     "iris_normalize": (_i, [_vp, _vp, _i, _sz, _vp, _sz, _vp]),
+    "iris_resample_len": (C.c_longlong, [C.c_longlong, _i, _i]),
+    "iris_resample": (_i, [_vp, _i, C.c_longlong, _i, _i, _vp, _vp]),
     "iris_stft": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "iris_complex_to_magphase": (_i, [_vp, _vp, _sz, _i, _vp]),
     "iris_magphase_to_complex": (_i, [_vp, _vp, _sz, _i, _vp]),

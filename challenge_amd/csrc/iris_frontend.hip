@@ -42,3 +42,4 @@
 #include "k_conv_wino.h"
 #include "k_conv_wino_b3.h"
 #include "k_conv_wino_wrw.h"
+#include "k_resample.h"

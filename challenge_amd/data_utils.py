@@ -54,13 +54,11 @@ def stft_array(wav: torch.Tensor, n_fft: int = 512, normalize: bool = False) -> 
 
 def load_wav_array(wav, sample_rate: int = _SR, device=None) -> torch.Tensor:
     """The numeric part of load_wav on an in-memory [chan, samples] array."""
-    if sample_rate != _SR:
-        raise NotImplementedError(
-            f"sample rate {sample_rate}: resampling to 16 kHz (torchaudio.compliance.kaldi."
-            "resample_waveform, data_utils.py:20-21) is outside the accelerated path; resample first")
     device = _default_device() if device is None else torch.device(device)
     wav = torch.as_tensor(np.asarray(wav, dtype=np.float32) if not isinstance(wav, torch.Tensor) else wav)
     wav = wav.to(device=device, dtype=torch.float32)
+    if sample_rate != _SR:   # data_utils.py:20-21: kaldi.resample_waveform(wav, r, 16000), on the device (iris_resample)
+        wav = _fe.resample(wav, int(sample_rate), _SR)
     # normalize + STFT as ONE transform launch behind a partial-sums launch (iris_stft with IRIS_F_NORMALIZE): the
     # two-kernel iris_normalize pass over the waveform cost as much as the transform itself.  Equal to
     # stft_array(normalize(wav)) up to the fp32 rounding of the scaled samples (<= 2e-6 of the spectrum's peak)
@@ -71,6 +69,11 @@ def load_wav(wav_fname: str, device=None) -> torch.Tensor:
     """complex spectrogram [freq, time, chan*2] of a wav file (data_utils.py:9-29)."""
     data, sr = read_wav_file(wav_fname)
     return load_wav_array(data, sr, device)
+
+
+def resample_waveform(wav: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
+    """torchaudio.compliance.kaldi.resample_waveform as load_wav calls it (data_utils.py:20-21), on a ROCm device tensor."""
+    return _fe.resample(wav, orig_freq, new_freq)
 
 
 def normalize(wav: torch.Tensor) -> torch.Tensor:

@@ -721,6 +721,27 @@ class PipelinedFrontend:
             s.synchronize()
 
 
+def resample(wav: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
+    """torchaudio.compliance.kaldi.resample_waveform(wav, orig_freq, new_freq) (data_utils.py:20-21) for a device waveform
+    [chan, samples] (or [samples]): the Hann-windowed-sinc polyphase filter of torchaudio.functional.resample
+    (lowpass_filter_width 6, rolloff 0.99) as one HIP launch (iris_resample); returns [chan, ceil(new_freq samples / orig_freq)]."""
+    wav = _require_device_f32(wav, "wav")
+    if int(orig_freq) != orig_freq or int(new_freq) != new_freq or orig_freq <= 0 or new_freq <= 0:
+        raise ValueError("resample: the sample rates must be positive integers")   # (torchaudio raises for non-integer rates too)
+    flat = wav.dim() == 1
+    if wav.dim() not in (1, 2) or wav.numel() == 0:
+        raise ValueError("resample: wav must be a non-empty [chan, samples] or [samples] tensor")
+    w2 = (wav.unsqueeze(0) if flat else wav).contiguous()
+    chan, n = int(w2.shape[0]), int(w2.shape[1])
+    lib = N.lib()
+    n_out = int(lib.iris_resample_len(n, int(orig_freq), int(new_freq)))
+    out = torch.empty((chan, n_out), dtype=torch.float32, device=wav.device)
+    with torch.cuda.device(wav.device):
+        rc = lib.iris_resample(w2.data_ptr(), chan, n, int(orig_freq), int(new_freq), out.data_ptr(), _stream_ptr(wav.device))
+    N.check(rc, "iris_resample")
+    return out[0] if flat else out
+
+
 def normalize(wav: torch.Tensor) -> torch.Tensor:
     """wav / (10 rms) with the rms over the whole tensor for [C,L] input
     (data_utils.py:32-34) or per leading item for [B,C,L]."""

@@ -167,6 +167,17 @@ int iris_plan_get_mel(const iris_plan* plan, float* out_host);
 int iris_plan_num_frames(const iris_plan* plan, int len);
 
 /*
+ * resample (data_utils.py:20-21: torchaudio.compliance.kaldi.resample_waveform(wav, r, 16000), the step of load_wav in front of
+ * normalize + STFT).  torchaudio (unpinned in requirements.txt:5, not vendored) implements it as functional.resample with
+ * lowpass_filter_width 6, rolloff 0.99 and a Hann-windowed sinc: a polyphase FIR of 2 ceil(6 o / (0.99 min(o, n))) + o taps per
+ * output phase on the reduced ratio o : n; csrc/k_resample.h restates it (taps in fp64, rounded once).
+ * wav: DEVICE [channels][len] fp32 at orig_freq; out: DEVICE [channels][iris_resample_len(len, orig_freq, new_freq)] fp32.
+ * orig_freq == new_freq is a copy.  Runs on the current HIP device; the tap table of a rate pair is cached per device.
+ */
+long long iris_resample_len(long long len, int orig_freq, int new_freq);
+int iris_resample(const float* wav, int channels, long long len, int orig_freq, int new_freq, float* out, void* stream);
+
+/*
  * normalize (data_utils.py:32-34):  out[r] = wav[r] / (10 * sqrt(mean(wav[r]^2)))
  * per row r of wav[n_rows, row_len]; one row = all C*L samples of one clip (the
  * reference takes the rms over every channel jointly).  out may alias wav.

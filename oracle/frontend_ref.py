@@ -126,9 +126,54 @@ def to_ref_layout(spec: np.ndarray) -> np.ndarray:
         np.float32 if spec.dtype == np.complex64 else np.float64)
 
 
-def load_wav_array(wav: np.ndarray, n_fft: int = 512) -> np.ndarray:
-    """The numeric tail of load_wav (data_utils.py:22-29) on an in-memory
-    [C, L] array already at 16 kHz: normalize -> STFT -> [F, T, 2C]."""
+def resample_taps(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """The polyphase filter of torchaudio.functional.resample, resampling_method "sinc_interp_hann" - what
+    torchaudio.compliance.kaldi.resample_waveform (data_utils.py:20-21) computes with.  torchaudio is a third-party dependency of
+    the reference (requirements.txt:5, UNPINNED, source not under /root/reference) and is not installed here, so this restates
+    its published algorithm and is pinned only by the independent evaluation of the same formula in tests/test_oracle.py:
+    PARITY UNPINNED against torchaudio's own outputs.  Returns (taps [new, K] float64, width, orig, new) on the reduced ratio:
+        f = rolloff min(o, n);  w = ceil(lowpass_filter_width o / f);  K = 2 w + o
+        t[j, k] = clamp(f ((k - w) / o - j / n), -lpw, lpw)
+        taps[j, k] = (f / o) sinc(pi t) cos^2(pi t / (2 lpw))"""
+    if int(orig_freq) != orig_freq or int(new_freq) != new_freq or orig_freq <= 0 or new_freq <= 0:
+        raise ValueError("sample rates must be positive integers")
+    g = math.gcd(int(orig_freq), int(new_freq))
+    o, n = int(orig_freq) // g, int(new_freq) // g
+    base = min(o, n) * rolloff
+    width = math.ceil(lowpass_filter_width * o / base)
+    idx = np.arange(-width, width + o, dtype=np.float64)[None, :] / o
+    t = np.arange(0, -n, -1, dtype=np.float64)[:, None] / n + idx
+    t = np.clip(t * base, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * np.pi / lowpass_filter_width / 2) ** 2
+    t = t * np.pi
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sinc = np.where(t == 0, 1.0, np.sin(t) / np.where(t == 0, 1.0, t))
+    return sinc * window * (base / o), width, o, n
+
+
+def resample_waveform(wav: np.ndarray, orig_freq: int, new_freq: int) -> np.ndarray:
+    """kaldi.resample_waveform(wav, orig_freq, new_freq) of data_utils.py:20-21 for wav [C, L] (see `resample_taps`): the
+    waveform padded with `width` zeros in front and `width + o` behind, a strided correlation with the n phase filters (conv1d,
+    stride o), phases interleaved, cut to ceil(n L / o) samples.  fp64 sums; the result in wav's dtype."""
+    wav = np.asarray(wav)
+    if orig_freq == new_freq:
+        return wav
+    taps, width, o, n = resample_taps(orig_freq, new_freq)
+    c, length = wav.shape
+    k = taps.shape[1]
+    xp = np.pad(wav.astype(np.float64), ((0, 0), (width, width + o)))
+    frames = (xp.shape[1] - k) // o + 1
+    win = np.lib.stride_tricks.sliding_window_view(xp, k, axis=1)[:, ::o][:, :frames]     # [C, frames, K]
+    out = np.einsum("cfk,jk->cfj", win, taps).reshape(c, frames * n)
+    target = -(-n * length // o)
+    return out[:, :target].astype(wav.dtype if wav.dtype in (np.float32, np.float64) else np.float32)
+
+
+def load_wav_array(wav: np.ndarray, n_fft: int = 512, sample_rate: int = 16000) -> np.ndarray:
+    """The numeric part of load_wav (data_utils.py:20-29) on an in-memory
+    [C, L] array: resample to 16 kHz -> normalize -> STFT -> [F, T, 2C]."""
+    if sample_rate != 16000:
+        wav = resample_waveform(wav, sample_rate, 16000)
     return to_ref_layout(stft(normalize(wav), n_fft))
 
 

@@ -487,3 +487,41 @@ def test_mel_tolerance_silent_and_masked_frames_must_be_exact(golden_dir):
     # the committed golden mel (fp32 oracle) is inside the rule
     ref_g, tol_g = R.mel_tolerance(g["wav"][None], 1024, 256, 64, 16000)
     assert R.mel_err_ratio(g["mel"][None], ref_g, tol_g) <= 0.5
+
+
+@pytest.mark.parametrize("orig,new,length", [(44100, 16000, 5000), (48000, 16000, 4801), (8000, 16000, 1234), (22050, 16000, 3000),
+                                             (32000, 16000, 37), (16000, 44100, 900)])
+def test_resample_oracle_is_the_published_formula_evaluated_directly(orig, new, length):
+    """R.resample_waveform restates torchaudio.functional.resample (what kaldi.resample_waveform of data_utils.py:20-21 runs;
+    torchaudio is unpinned, not vendored and not installed: PARITY UNPINNED against its outputs).  Pinned here against the SAME
+    published formula evaluated without any of its indexing - y[m] = sum_l x[l] g(l / o - m / n), g the Hann-windowed sinc - so
+    the padding, the stride, the phase interleave and the final cut are checked independently of how they are written; + the
+    output length ceil(n L / o), unit DC gain within the window's ripple, and a sine that keeps its frequency and amplitude."""
+    import math
+    rng = np.random.default_rng(orig + new + length)
+    x = rng.standard_normal((2, length))
+    y = R.resample_waveform(x, orig, new)
+    g = math.gcd(orig, new)
+    o, n = orig // g, new // g
+    assert y.shape == (2, -(-n * length // o)) and y.dtype == np.float64
+    base = 0.99 * min(o, n)
+    m = np.arange(y.shape[1])[:, None]
+    l_ = np.arange(length)[None, :]
+    u = np.clip((l_ / o - m / n) * base, -6, 6)
+    a = u * np.pi
+    w = np.where(a == 0, 1.0, np.sin(a) / np.where(a == 0, 1.0, a)) * np.cos(u * np.pi / 12) ** 2 * base / o
+    assert np.abs(x @ w.T - y).max() <= 1e-12 * np.abs(y).max()
+    taps, width, o2, n2 = R.resample_taps(orig, new)
+    assert (o2, n2) == (o, n) and taps.shape == (n, 2 * width + o) and width == math.ceil(6 * o / base)
+    assert np.abs(taps.sum(axis=1) - 1.0).max() <= 2e-3          # DC gain of every phase
+    if length >= 1000:
+        f0 = 0.2 * min(orig, new) / 2                            # well inside the pass band of both rates
+        t_in, t_out = np.arange(length) / orig, np.arange(y.shape[1]) / new
+        s = R.resample_waveform(np.sin(2 * np.pi * f0 * t_in)[None], orig, new)[0]
+        k = int(0.05 * len(s))
+        assert np.abs(s - np.sin(2 * np.pi * f0 * t_out))[k:-k].max() <= 2e-3
+    assert R.resample_waveform(x, 16000, 16000) is x             # equal rates: untouched, as torchaudio returns the input
+    x32 = x.astype(np.float32)
+    assert R.resample_waveform(x32, orig, new).dtype == np.float32
+    with pytest.raises(ValueError):
+        R.resample_taps(0, 16000)

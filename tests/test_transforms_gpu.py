@@ -151,8 +151,12 @@ def test_data_utils_chain_matches_oracle(dev):
     r = R.log_on_mel(R.minmax(R.magphase_to_mel(80)(R.complex_to_magphase(r))))
     assert tuple(x.shape) == r.shape == (80, 24, 2)
     assert np.abs(np.exp(x.cpu().numpy()) - np.exp(r)).max() <= 1e-5   # per-mel-row min-max (unbatched quirk)
-    with pytest.raises(NotImplementedError):
-        D.load_wav_array(wav, 44100, dev)
+    # any other sample rate goes through the device resampler first (data_utils.py:20-21), as the oracle's chain does
+    spec44 = D.load_wav_array(wav, 44100, dev)
+    ref44 = R.load_wav_array(wav, 512, sample_rate=44100)
+    n16 = -(-160 * 6000 // 441)
+    assert tuple(spec44.shape) == ref44.shape == (257, 1 + n16 // 256, 4)
+    assert np.abs(spec44.cpu().numpy() - ref44).max() <= 3e-6 * np.abs(ref44).max()
     n = D.normalize(torch.from_numpy(wav).to(dev)).cpu().numpy()
     assert np.abs(n - R.normalize(wav)).max() <= 1e-6
     m = torch.rand(3, 8, 9, 2, device=dev)
@@ -1689,3 +1693,47 @@ def test_bench_strong_scaling_two_ranks(dev):
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["scaling"] == "strong" and res["n_gpus"] == 2 and res["config"]["global_batch"] == 256
     assert "batch 128" in res["config"]["workload"] and res["value"] > 0 and res["rccl_world"] == 2
+
+
+@pytest.mark.parametrize("orig,new,chan,length", [(44100, 16000, 2, 441000), (48000, 16000, 1, 48001), (8000, 16000, 2, 12345),
+                                                  (22050, 16000, 1, 30000), (32000, 16000, 3, 37), (16000, 44100, 1, 900),
+                                                  (44100, 16000, 1, 5), (11025, 16000, 2, 1)])
+def test_resample_matches_oracle(dev, orig, new, chan, length):
+    """iris_resample (the kaldi.resample_waveform of data_utils.py:20-21 = torchaudio.functional.resample's Hann-windowed sinc) against
+    the fp64 oracle: <= 2e-6 of the peak (fp32 taps rounded once from fp64, fp32 sums over <= 2 w + o taps), the length
+    ceil(n L / o), inputs shorter than one filter, up- and down-sampling, 1-3 channels, a [samples] vector, equal rates = a copy;
+    invalid arguments are refused before the device is touched."""
+    from challenge_amd import frontend as F
+    _, D, _ = mods()
+    rng = np.random.default_rng(orig + length)
+    x = (rng.standard_normal((chan, length)) * 0.3).astype(np.float32)
+    want = R.resample_waveform(x.astype(np.float64), orig, new)
+    got = D.resample_waveform(torch.from_numpy(x).to(dev), orig, new)
+    assert tuple(got.shape) == want.shape and got.dtype == torch.float32
+    assert np.abs(got.cpu().numpy() - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-3)
+    flat = F.resample(torch.from_numpy(x[0]).to(dev), orig, new)
+    assert flat.dim() == 1 and torch.equal(flat, got[0])
+    same = F.resample(torch.from_numpy(x).to(dev), 16000, 16000)
+    assert torch.equal(same.cpu(), torch.from_numpy(x))
+    with pytest.raises(ValueError):
+        F.resample(torch.from_numpy(x).to(dev), 0, 16000)
+    with pytest.raises(ValueError):
+        F.resample(torch.empty((1, 0), device=dev), 44100, 16000)
+    with pytest.raises(RuntimeError):
+        F.resample(torch.from_numpy(x), 44100, 16000)    # a CPU tensor: no fallback
+
+
+def test_load_wav_resamples_a_44k_file(dev, tmp_path):
+    """load_wav on a 44.1 kHz stereo PCM file: read -> resample to 16 kHz -> normalize -> STFT(512), against the oracle's chain on the
+    same samples (data_utils.py:9-29; the reference reads with torchaudio.load, here scipy's reader: int16 / 32768)."""
+    from scipy.io import wavfile
+    _, D, _ = mods()
+    rng = np.random.default_rng(5)
+    pcm = (rng.standard_normal((22050, 2)) * 4000).astype(np.int16)
+    path = str(tmp_path / "clip44.wav")
+    wavfile.write(path, 44100, pcm)
+    spec = D.load_wav(path, dev)
+    x = (pcm.astype(np.float32) / 32768.0).T
+    ref = R.load_wav_array(x, 512, sample_rate=44100)
+    assert tuple(spec.shape) == ref.shape == (257, 1 + 8000 // 256, 4)
+    assert np.abs(spec.cpu().numpy() - ref).max() <= 3e-6 * np.abs(ref).max()
