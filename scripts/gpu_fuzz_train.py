@@ -1,20 +1,24 @@
 """Randomised sweep of the CRNN-side HIP passes against the stock torch / MIOpen ops: ConvMPBlock (BatchNorm + ReLU + MaxPool
 passes, the first-layer form with 1-2 input channels), FullyConnectedLayer, the bidirectional LSTM - outputs and every gradient.
-usage: gpu_fuzz_train.py [n_cases] [seed]"""
+usage: gpu_fuzz_train.py [n_cases] [seed] [--split]      (--split: the HIP side runs its Winograd passes on the BF16 matrix cores)"""
 import os, sys, copy
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from challenge_amd import sj_train as S
 S.configure_miopen()
 dev = torch.device("cuda", 0)
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-FLAGS = ("FUSED_BN_RELU", "FUSED_BN_POOL", "FUSED_CONV0", "FUSED_LSTM", "FUSED_FC_BN", "WINO_TRAIN", "WINO_TRAIN_WRW", "ZERO_POOL")
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_cases = int(_args[0]) if len(_args) > 0 else 40
+rng = np.random.default_rng(int(_args[1]) if len(_args) > 1 else 0)
+SPLIT = "--split" in sys.argv
+FLAGS = ("FUSED_BN_RELU", "FUSED_BN_POOL", "FUSED_BN_STATS", "FUSED_CONV0", "FUSED_LSTM", "FUSED_FC_BN", "WINO_TRAIN", "WINO_TRAIN_WRW",
+         "C32_TRAIN", "ZERO_POOL")
 
 
 def set_flags(v):
     for f in FLAGS:
         setattr(S, f, v)
+    S.WINO_SPLIT_BF16 = bool(v) and SPLIT
 
 
 def rel(a, b):
@@ -26,8 +30,8 @@ for case in range(n_cases):
     kind = rng.choice(["block", "block", "fc", "lstm"])
     torch.manual_seed(int(rng.integers(1 << 30)))
     if kind == "block":
-        cin = int(rng.choice([1, 2, 8, 32, 64]))
-        cout = int(rng.choice([8, 16, 32, 64, 128, 256]))
+        cin = int(rng.choice([1, 2, 8, 32, 64, 64, 128, 256]))
+        cout = int(rng.choice([8, 16, 32, 64, 64, 128, 256]))
         # (B >= 2: the STOCK side of the comparison - torch's BatchNorm2d on MIOpen, channels-last, training mode - dumps core on
         # batch-1 inputs in this image)
         nconv, b, h, w = int(rng.integers(1, 4)), int(rng.integers(2, 6)), int(rng.integers(2, 20)), int(rng.integers(2, 70))
