@@ -21,6 +21,12 @@ IRIS_E_EPILOGUE_TIMEOUT = -5
 
 # every symbol include/iris_frontend.h declares, with (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class PackJob(C.Structure):
+    """iris_pack_job of include/iris_frontend.h (iris_wino_pack_weights_device_multi)."""
+    _fields_ = [("weight", C.c_void_p), ("packed", C.c_void_p), ("stride_o", C.c_long), ("stride_i", C.c_long), ("stride_h", C.c_long),
+                ("stride_w", C.c_long), ("cin", C.c_int), ("cout", C.c_int), ("transposed", C.c_int), ("first_block", C.c_int)]
 _fp = C.POINTER(C.c_float)
 SIGNATURES = {
     "iris_abi_version": (_i, []),
@@ -36,6 +42,7 @@ SIGNATURES = {
     "iris_plan_num_frames": (_i, [_vp, _i]),
     "iris_normalize_workspace": (_sz, [_i, _sz]),
     "iris_normalize": (_i, [_vp, _vp, _i, _sz, _vp, _sz, _vp]),
+    "iris_wino_pack_weights_device_multi": (_i, [_vp, _i, _i, _vp]),
     "iris_resample_len": (C.c_longlong, [C.c_longlong, _i, _i]),
     "iris_resample": (_i, [_vp, _i, C.c_longlong, _i, _i, _vp, _vp]),
     "iris_stft": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

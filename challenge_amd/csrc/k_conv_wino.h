@@ -39,6 +39,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 #define WINO_ABL(bit) ((IRIS_WINO_ABLATE & (bit)) != 0)
 constexpr int kWinoTM = 64, kWinoTN = 64, kWinoKC = 8;
+constexpr int kWinoPackMaxJobs = 48;
 constexpr int kWinoVFloats = 16 * 4 * kWinoTM * 2;   // [pos 16][pair 2][hl 2][tile 64][2]
 constexpr int kWinoUFloats = 16 * 4 * kWinoTN * 2;   // [pos 16][pair 2][hl 2][cout 64][2]
 constexpr int kWinoBuf = kWinoVFloats + kWinoUFloats;
@@ -450,11 +451,10 @@ extern "C" int iris_wino_pack_weights(const float* weight_host, int cin, int cou
 // whole lines (a thread per weight writing its 16 values straight to memory touched a different line with every 4-byte store:
 // 12 us per layer on average, 35 for 512 x 512 - nine times the traffic's worth).  Threads run along whichever of the two
 // channel axes is the denser one in memory.
-__global__ __launch_bounds__(512) void k_wino_pack(const float* __restrict__ w, long so, long si, long sh, long sw, int cin, int cout,
-                                                   int transposed, float* __restrict__ packed) {
-    __shared__ __attribute__((aligned(16))) float u[kWinoUFloats];
+__device__ __forceinline__ void wino_pack_block(float* __restrict__ u /* LDS, kWinoUFloats */, int block, const float* __restrict__ w, long so,
+                                                long si, long sh, long sw, int cin, int cout, int transposed, float* __restrict__ packed) {
     const int n_chunks = cin / kWinoKC;
-    const int cb = blockIdx.x / n_chunks, chunk = blockIdx.x - cb * n_chunks;
+    const int cb = block / n_chunks, chunk = block - cb * n_chunks;
     const long str_o = transposed ? si : so, str_c = transposed ? so : si;   // element strides along the packed cout / cin
     const int t = threadIdx.x;
     const int oc = str_c <= str_o ? t >> 3 : t & 63, k = str_c <= str_o ? t & 7 : t >> 6;
@@ -485,6 +485,28 @@ __global__ __launch_bounds__(512) void k_wino_pack(const float* __restrict__ w, 
     float4* const out = reinterpret_cast<float4*>(packed + ((size_t)cb * n_chunks + chunk) * kWinoUFloats);
 #pragma unroll
     for (int q = 0; q < kWinoUFloats / 4 / 512; ++q) out[q * 512 + t] = reinterpret_cast<const float4*>(u)[q * 512 + t];
+}
+
+__global__ __launch_bounds__(512) void k_wino_pack(const float* __restrict__ w, long so, long si, long sh, long sw, int cin, int cout,
+                                                   int transposed, float* __restrict__ packed) {
+    __shared__ __attribute__((aligned(16))) float u[kWinoUFloats];
+    wino_pack_block(u, (int)blockIdx.x, w, so, si, sh, sw, cin, cout, transposed, packed);
+}
+
+// All the packings of a training step in ONE launch (round 6): 23 launches of ~6.7 us (12 forward + 11 backward-data layers, each a
+// few dozen workgroups) were 0.16 ms of a 10 ms step, most of it launch latency and tails.  The jobs travel BY VALUE in the kernel
+// arguments (<= 4 KiB: 48 jobs), so the launch needs no device-side table and is captured into a hipGraph like any other.
+struct WinoPackJobs {
+    int n, pad;
+    iris_pack_job j[kWinoPackMaxJobs];
+};
+__global__ __launch_bounds__(512) void k_wino_pack_multi(const WinoPackJobs jobs) {
+    __shared__ __attribute__((aligned(16))) float u[kWinoUFloats];
+    int k = 0;
+    while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].first_block) ++k;   // uniform
+    const iris_pack_job& jb = jobs.j[k];
+    wino_pack_block(u, (int)blockIdx.x - jb.first_block, jb.weight, jb.stride_o, jb.stride_i, jb.stride_h, jb.stride_w, jb.cin, jb.cout,
+                    jb.transposed, jb.packed);
 }
 
 extern "C" int iris_wino_pack_weights_device(const float* weight, long stride_o, long stride_i, long stride_h, long stride_w, int cin,

@@ -92,10 +92,10 @@ __device__ __forceinline__ b3_u32x4 b3_gload16(const uint4* base /*uniform*/, un
 
 // ---- packing: weight [Cout][Cin][3][3] (any strides) -> U = G g G^T, split, in the kernel's operand order ---------------------
 // thread = (channel block nb, lane): output channel 64 cb + 32 nb + (lane & 31), input channels 16 chunk + 8 (lane >> 5) + j
-__global__ __launch_bounds__(128) void k_wino_pack_b3(const float* __restrict__ w, long so, long si, long sh, long sw, int cin, int cout,
-                                                      int transposed, uint4* __restrict__ packed) {
+__device__ __forceinline__ void wino_pack_b3_block(int block, const float* __restrict__ w, long so, long si, long sh, long sw, int cin, int cout,
+                                                   int transposed, uint4* __restrict__ packed) {
     const int n_chunks = cin / kB3KC;
-    const int cb = blockIdx.x / n_chunks, chunk = blockIdx.x - cb * n_chunks;
+    const int cb = block / n_chunks, chunk = block - cb * n_chunks;
     const int nb = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long str_o = transposed ? si : so, str_c = transposed ? so : si;
     const int oc = cb * 64 + nb * 32 + (lane & 31);
@@ -133,6 +133,48 @@ __global__ __launch_bounds__(128) void k_wino_pack_b3(const float* __restrict__ 
 #pragma unroll
         for (int term = 0; term < 3; ++term) out[(size_t)(pos * 3 + term) * 2 * 64] = make_uint4(t[term][0], t[term][1], t[term][2], t[term][3]);
     }
+}
+
+__global__ __launch_bounds__(128) void k_wino_pack_b3(const float* __restrict__ w, long so, long si, long sh, long sw, int cin, int cout,
+                                                      int transposed, uint4* __restrict__ packed) {
+    wino_pack_b3_block((int)blockIdx.x, w, so, si, sh, sw, cin, cout, transposed, packed);
+}
+// every packing of a training step in one launch (k_conv_wino.h: k_wino_pack_multi)
+__global__ __launch_bounds__(128) void k_wino_pack_b3_multi(const WinoPackJobs jobs) {
+    int k = 0;
+    while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].first_block) ++k;   // uniform
+    const iris_pack_job& jb = jobs.j[k];
+    wino_pack_b3_block((int)blockIdx.x - jb.first_block, jb.weight, jb.stride_o, jb.stride_i, jb.stride_h, jb.stride_w, jb.cin, jb.cout,
+                       jb.transposed, reinterpret_cast<uint4*>(jb.packed));
+}
+
+extern "C" int iris_wino_pack_weights_device_multi(iris_pack_job* jobs_host, int n_jobs, int split_bf16, void* stream) {
+    if (!jobs_host || n_jobs <= 0) return fail(IRIS_E_INVALID, "iris_wino_pack_weights_device_multi: no jobs");
+    const int kc = split_bf16 ? kB3KC : kWinoKC;
+    for (int i = 0; i < n_jobs; ++i) {
+        const iris_pack_job& jb = jobs_host[i];
+        if (!jb.weight || !jb.packed) return fail(IRIS_E_INVALID, "iris_wino_pack_weights_device_multi: job %d: NULL pointer", i);
+        if (jb.cin <= 0 || jb.cout <= 0 || (jb.cin % kc) || (jb.cout % 64))
+            return fail(IRIS_E_UNSUPPORTED, "iris_wino_pack_weights_device_multi: job %d: cin %d must be a multiple of %d, cout %d of 64", i, jb.cin, kc, jb.cout);
+        if (reinterpret_cast<uintptr_t>(jb.packed) & 15) return fail(IRIS_E_INVALID, "iris_wino_pack_weights_device_multi: job %d: packed must be 16-byte aligned", i);
+    }
+    for (int base = 0; base < n_jobs; base += kWinoPackMaxJobs) {
+        WinoPackJobs jobs;
+        jobs.n = std::min(kWinoPackMaxJobs, n_jobs - base);
+        jobs.pad = 0;
+        long long blocks = 0;
+        for (int i = 0; i < jobs.n; ++i) {
+            iris_pack_job& jb = jobs_host[base + i];
+            jb.first_block = (int)blocks;
+            jobs.j[i] = jb;
+            blocks += (long long)(jb.cout / 64) * (jb.cin / kc);
+        }
+        if (blocks >= 2147483647LL) return fail(IRIS_E_UNSUPPORTED, "iris_wino_pack_weights_device_multi: too many blocks");
+        if (split_bf16) k_wino_pack_b3_multi<<<(unsigned)blocks, 128, 0, (hipStream_t)stream>>>(jobs);
+        else k_wino_pack_multi<<<(unsigned)blocks, 512, 0, (hipStream_t)stream>>>(jobs);
+        HIP_TRY(hipGetLastError());
+    }
+    return IRIS_OK;
 }
 
 extern "C" size_t iris_wino_b3_packed_len(int cin, int cout) { return (cin > 0 && cout > 0) ? wino_b3_packed_bytes(cin, cout) / 4 : 0; }  // in floats

@@ -546,6 +546,35 @@ def wino_pack_weights_device(weight: torch.Tensor, transposed: bool = False, out
     return out
 
 
+def wino_packed_len(cin: int, cout: int, split_bf16: bool = False) -> int:
+    """floats of the packed weights of a cin -> cout layer (iris_wino_packed_len / iris_wino_b3_packed_len)."""
+    lib = N.lib()
+    return int((lib.iris_wino_b3_packed_len if split_bf16 else lib.iris_wino_packed_len)(int(cin), int(cout)))
+
+
+def wino_pack_weights_device_multi(jobs, split_bf16: bool = False) -> None:
+    """`jobs`: [(weight [Cout, Cin, 3, 3] float32 device tensor, transposed, out float32 device tensor of wino_packed_len floats)]:
+    every packing in ONE launch on the current stream (iris_wino_pack_weights_device_multi), same results as
+    `wino_pack_weights_device` per job."""
+    if not jobs:
+        return
+    arr = (N.PackJob * len(jobs))()
+    dev = jobs[0][0].device
+    for k, (weight, transposed, out) in enumerate(jobs):
+        if not (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+                and out.is_cuda and out.dtype == torch.float32 and weight.device == dev and out.device == dev):
+            raise ValueError("wino_pack_weights_device_multi: float32 device tensors on one device are expected (no CPU fallback)")
+        co, ci = int(weight.shape[0]), int(weight.shape[1])
+        cin, cout = (co, ci) if transposed else (ci, co)
+        if out.numel() < wino_packed_len(cin, cout, split_bf16):
+            raise ValueError("wino_pack_weights_device_multi: output buffer too small")
+        so, si, sh, sw = (int(v) for v in weight.stride())
+        arr[k] = N.PackJob(weight.data_ptr(), out.data_ptr(), so, si, sh, sw, cin, cout, 1 if transposed else 0, 0)
+    with torch.cuda.device(dev):
+        rc = N.lib().iris_wino_pack_weights_device_multi(C.cast(arr, C.c_void_p), len(jobs), 1 if split_bf16 else 0, _stream_ptr(dev))
+    N.check(rc, "iris_wino_pack_weights_device_multi")
+
+
 def conv3x3_wino(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, pool: bool = False,
                  out_nhwc: bool = False, relu: bool = True, split_bf16: bool = False, bn_sums: Optional[torch.Tensor] = None) -> torch.Tensor:
     """conv2d(x, weight, padding=1) (+ bias, + ReLU, + MaxPool 2x2 'same') as Winograd F(2x2, 3x3) on the fp32 matrix cores

@@ -410,6 +410,77 @@ def _is_first_layer_conv(conv, x) -> bool:
             and x.shape[3] <= 2048)
 
 
+class _PackBook:
+    """The Winograd weight packings of a training step, made in ONE launch at the top of the forward pass (switch FUSED_PACK).
+
+    `_WinoConv3x3` asks `take(weight, transposed, b3)` for every packing it needs.  The first time a (weight storage, pass, kind) is
+    asked for it is packed on the spot, as before, into a buffer this book keeps - and remembered; from the next forward pass on,
+    `prepack()` (called by CustomModel.forward in training mode) packs everything remembered in one launch per kind, and `take`
+    hands those buffers out.  A packing is used only while the weight's autograd version is the one it was packed at (any in-place
+    update - the optimiser step, load_state_dict, SWA - makes it stale and `take` packs again), so a layer called on its own, two
+    forwards before one backward, or an evaluation in between all stay correct.  Entries are keyed by the weight's storage address,
+    shape and strides, not by the tensor object: GraphedTrainStep runs the model on ALIASES of the parameters over the same storage
+    (they share the version counter).  The buffers persist, so a captured graph replays the one-launch packing and the
+    convolutions on fixed addresses."""
+
+    def __init__(self):
+        self.entries = {}   # key -> [packed tensor, version it was packed at, weakref to a tensor over the weight]
+
+    @staticmethod
+    def _key(weight, transposed, b3):
+        return (weight.device.index, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), bool(transposed), bool(b3))
+
+    def take(self, weight, transposed: bool, b3: bool):
+        if not SW.FUSED_PACK:
+            return _fe.wino_pack_weights_device(weight, transposed=transposed, split_bf16=b3)
+        import weakref
+        key = self._key(weight, transposed, b3)
+        ent = self.entries.get(key)
+        if ent is not None and ent[1] == weight._version:
+            return ent[0]
+        co, ci = int(weight.shape[0]), int(weight.shape[1])
+        cin, cout = (co, ci) if transposed else (ci, co)
+        out = ent[0] if ent is not None else torch.empty(_fe.wino_packed_len(cin, cout, b3), dtype=torch.float32, device=weight.device)
+        _fe.wino_pack_weights_device(weight, transposed=transposed, out=out, split_bf16=b3)
+        self.entries[key] = [out, weight._version, weakref.ref(weight)]
+        return out
+
+    def prepack(self, device):
+        """Pack every remembered weight of `device` whose packing is stale, one launch per kind; forget weights that are gone."""
+        if not SW.FUSED_PACK or not self.entries:
+            return
+        jobs = {False: [], True: []}
+        dead = []
+        for key, ent in self.entries.items():
+            if key[0] != device.index:
+                continue
+            w = ent[2]()
+            if w is None or w.data_ptr() != key[1] or tuple(w.stride()) != key[3]:
+                dead.append(key)
+                continue
+            if ent[1] != w._version:
+                jobs[key[5]].append((w, key[4], ent[0], ent))
+        for key in dead:
+            del self.entries[key]
+        for b3, lst in jobs.items():
+            if lst:
+                _fe.wino_pack_weights_device_multi([(w, t, out) for w, t, out, _ in lst], split_bf16=b3)
+                for w, _, _, ent in lst:
+                    ent[1] = w._version
+
+    def invalidate(self):
+        """Every packing is stale (CustomModel.bump_generation: a hipGraph replay, an all-reduce into the parameters or any other
+        update that does not move the weights' autograd version); the buffers are kept."""
+        for ent in self.entries.values():
+            ent[1] = -1
+
+    def clear(self):
+        self.entries.clear()
+
+
+_PACKS = _PackBook()
+
+
 class _WinoConv3x3(torch.autograd.Function):
     """z = conv2d(x, weight, padding=1) for channels_last fp32 tensors.  forward (`fwd`): iris_conv3x3_wino on the weights packed
     on the device this step, else MIOpen; backward: dx (`bwd`) by the same kernel on the transposed / flipped weights, else
@@ -429,7 +500,7 @@ class _WinoConv3x3(torch.autograd.Function):
             z = _fe.conv3x3_c32(x, weight, bn_sums=sums)
         elif fwd:
             b3 = SW.WINO_SPLIT_BF16 and int(weight.shape[1]) % 16 == 0   # GEMMs on the BF16 matrix cores, three-term split
-            z = _fe.conv3x3_wino(x, _fe.wino_pack_weights_device(weight, split_bf16=b3), None, int(weight.shape[0]), out_nhwc=True,
+            z = _fe.conv3x3_wino(x, _PACKS.take(weight, False, b3), None, int(weight.shape[0]), out_nhwc=True,
                                  relu=False, split_bf16=b3, bn_sums=sums)
         else:
             z = torch.nn.functional.conv2d(x, weight, None, 1, 1)
@@ -455,7 +526,7 @@ class _WinoConv3x3(torch.autograd.Function):
             dx = _fe.conv3x3_c32(dz, weight, transposed=True)
         elif wino_dx:
             b3 = SW.WINO_SPLIT_BF16 and int(weight.shape[0]) % 16 == 0
-            dx = _fe.conv3x3_wino(dz, _fe.wino_pack_weights_device(weight, transposed=True, split_bf16=b3), None, cin, out_nhwc=True,
+            dx = _fe.conv3x3_wino(dz, _PACKS.take(weight, True, b3), None, cin, out_nhwc=True,
                                   relu=False, split_bf16=b3)
         wino_dw = ctx.needs_input_grad[1] and ctx.wino_wrw
         if wino_dw:

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import frontend as _fe
 from . import switches as SW
-from .hip_autograd import (FusedAGC, _FusedBiasBNReLU, _FusedConv0BNReLU, _IN_STEP, _WinoConv3x3, _ZERO_POOL, _is_first_layer_conv,
+from .hip_autograd import (FusedAGC, _FusedBiasBNReLU, _FusedConv0BNReLU, _IN_STEP, _PACKS, _WinoConv3x3, _ZERO_POOL, _is_first_layer_conv,
                            _is_pool_2x2_same, _lstm_is_bilstm128, _wino_train_conv, adaptive_clip_grad, bilstm128)
 
 
@@ -206,6 +206,8 @@ class CustomModel(nn.Module):
             # a training-mode pass outside train_step (a custom loop, a test's grads()): it is its own "step" for the zero pool,
             # whose demand would otherwise add up over such passes until the next train_step allocated twice their SUM
             _ZERO_POOL.begin_step(x.device)
+        if SW.FUSED_PACK and SW.WINO_TRAIN and self.training and x.is_cuda and torch.is_grad_enabled():
+            _PACKS.prepack(x.device)   # every Winograd weight packing this step will ask for, in one launch (hip_autograd._PackBook)
         outer, _NBT_PENDING = _NBT_PENDING, []
         try:
             return self._forward(x)
@@ -287,6 +289,7 @@ class CustomModel(nn.Module):
     def bump_generation(self) -> None:
         """Tell `predict` that parameters / buffers have changed (see `_generation`)."""
         object.__setattr__(self, '_generation', self._generation + 1)
+        _PACKS.invalidate()   # (a graph replay updates the weights without touching their autograd version: packed copies are stale)
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)

@@ -33,6 +33,10 @@ FUSED_LSTM = _on("IRIS_FUSED_LSTM")          # Bidirectional(LSTM(128)): each pa
 # zero-initialised scratch (BatchNorm sums, first-layer dW copies, zero bias gradients) from one pool with one fill per step
 ZERO_POOL = _on("IRIS_ZERO_POOL")
 
+# round 6: every Winograd weight packing of a training step (12 forward + 11 backward-data layers) in ONE launch at the top of the
+# forward pass (iris_wino_pack_weights_device_multi) instead of one launch per layer and pass; 0: per layer
+FUSED_PACK = _on("IRIS_FUSED_PACK")
+
 # --- the convolutions themselves in the training step -------------------------------------------------------------------------------
 # The bare 3x3 convolutions of blocks 2-5 - forward and backward-data - as Winograd F(2x2, 3x3) on the fp32 matrix cores
 # (iris_conv3x3_wino) instead of MIOpen's implicit GEMMs, reading and writing channels_last where the weight-gradient kernel and the
@@ -73,6 +77,6 @@ DDP_BUCKET_MB = int(os.environ.get("IRIS_DDP_BUCKET_MB", "12"))
 # --- test hook ------------------------------------------------------------------------------------------------------------------------
 _PLAN_CHECK_ON_CPU = False  # tests/test_ddp_gloo.py: consult the frontend plans' status for a CPU-resident loss too
 
-NAMES = ("FUSED_BN_RELU", "FUSED_FC_BN", "FUSED_BN_POOL", "FUSED_BN_STATS", "FUSED_CONV0", "FUSED_LSTM", "ZERO_POOL", "WINO_TRAIN",
+NAMES = ("FUSED_BN_RELU", "FUSED_FC_BN", "FUSED_BN_POOL", "FUSED_BN_STATS", "FUSED_PACK", "FUSED_CONV0", "FUSED_LSTM", "ZERO_POOL", "WINO_TRAIN",
          "WINO_TRAIN_MIN_C_FWD", "WINO_TRAIN_MIN_C_BWD", "WINO_TRAIN_WRW", "C32_TRAIN", "WINO_SPLIT_BF16", "WINO_CONVS", "GRAPH_STEP", "DDP_BUCKET_MB",
          "_PLAN_CHECK_ON_CPU")

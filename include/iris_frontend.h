@@ -336,6 +336,21 @@ int iris_conv3x3_wino_b3_bn(const float* x, const float* packed, float* y, int b
                             double* bn_sums_zeroed, void* stream);
 int iris_conv3x3_c32_bn(const float* x, const float* weight, long stride_o, long stride_i, long stride_h, long stride_w, float* y,
                         int batch, int height, int width, double* bn_sums_zeroed, void* stream);
+
+/*
+ * All the weight packings of a training step in ONE launch (round 6; replaces N calls of iris_wino_pack_weights_device /
+ * iris_wino_b3_pack_weights_device - 23 per step of the CRNN, 0.16 ms of launches and tails).  jobs: HOST array (read during the
+ * call, passed to the kernel by value: nothing device-side to keep alive, capturable into a hipGraph); per job the arguments of the
+ * single-layer entry points; first_block is filled in by the call.  split_bf16 != 0: the iris_wino_b3 packing (cin % 16 == 0).
+ * Any number of jobs (48 per launch).
+ */
+typedef struct iris_pack_job {
+    const float* weight;
+    float* packed;
+    long stride_o, stride_i, stride_h, stride_w;
+    int cin, cout, transposed, first_block;
+} iris_pack_job;
+int iris_wino_pack_weights_device_multi(iris_pack_job* jobs_host, int n_jobs, int split_bf16, void* stream);
 int iris_bn_stats(const float* z, size_t rows, int channels, double* sums_zeroed, void* stream);
 int iris_bn_relu_apply(const float* z, float* y, size_t rows, int channels, const double* sums, const float* gamma,
                        const float* beta, const float* conv_bias, float eps, float momentum, float* running_mean,

@@ -10,8 +10,8 @@ run() {   # name, limit, command...
   if [ $rc -ge 124 ]; then echo "$name killed at its limit: stopping"; exit $rc; fi
   if [ $rc -ne 0 ]; then rc_all=$rc; fi
 }
-run fuzz_frontend 400 python3 scripts/gpu_fuzz.py 150 11
-run fuzz_train 400 python3 scripts/gpu_fuzz_train.py 80 12
-run fuzz_train_split 400 python3 scripts/gpu_fuzz_train.py 60 13 --split
+run fuzz_frontend 800 python3 scripts/gpu_fuzz.py ${FUZZ_N:-150} 11
+run fuzz_train 800 python3 scripts/gpu_fuzz_train.py ${FUZZ_T:-80} 12
+run fuzz_train_split 800 python3 scripts/gpu_fuzz_train.py ${FUZZ_S:-60} 13 --split
 run stress 300 python3 scripts/gpu_stress.py
 exit $rc_all

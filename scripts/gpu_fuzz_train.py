@@ -104,7 +104,36 @@ for case in range(n_cases):
         yc.backward(g)
         self_err = max(rel(pc.grad, pb.grad) for (n, pc), (_, pb) in zip(ref2.named_parameters(), ref.named_parameters())
                        if pb.grad is not None and not (n.endswith("0.bias") or n == "fc.bias"))
-        if errs["out"] <= 1e-5 and self_err >= 0.5 * errs[worst]:
+        # ... or directly: do the two sides take a different ReLU / pooling decision anywhere?  (the HIP side's activations from
+        # hip_autograd.record_activations, a pooled layer's full-resolution activation re-derived and verified as in
+        # oracle.crnn_ref.Decisions; the stock side's from hooks on its BatchNorm layers)
+        differing = None
+        if kind == "block":
+            from challenge_amd.hip_autograd import record_activations
+            from oracle import crnn_ref as RR
+            set_flags(True)
+            with torch.no_grad(), record_activations() as acts:
+                copy.deepcopy(ref).train()(x)
+            stock_full = []
+            probe = copy.deepcopy(ref).train()
+            hooks = [m.register_forward_hook(lambda mod, i, o: stock_full.append(torch.relu(o.detach())))
+                     for m in probe.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+            set_flags(False)
+            with torch.no_grad():
+                probe(x)
+            for h in hooks:
+                h.remove()
+            differing = 0
+            for e, full_b in zip(acts, stock_full):
+                full_a = RR.Decisions._rederive(e) if e['pool'] else e['y']
+                differing += int(((full_a > 0) != (full_b > 0)).sum())
+                if e['pool']:
+                    differing += int((RR._windows(full_a).argmax(-1) != RR._windows(full_b).argmax(-1)).sum())
+            if errs["out"] <= 1e-5 and differing > 0:
+                bad -= 1
+                flips += 1
+                print(f"     (reclassified as a flip: {differing} ReLU / pooling decisions differ between the two sides while the outputs agree)")
+        if errs["out"] <= 1e-5 and self_err >= 0.5 * errs[worst] and not differing:
             # the stock ops, perturbed in the last bit of their input, move their own gradients as far: a decision made within
             # rounding with a large gradient behind it - a flip after all, just above the 2e-2 bound
             bad -= 1

@@ -28,6 +28,12 @@ extern "C" const char* wino_last_error(void) { return g_err; }
         if (e_ != hipSuccess) return fail((int)e_, "%s failed: %s", #expr, hipGetErrorString(e_));        \
     } while (0)
 #define IRIS_WINO_STANDALONE 1
+typedef struct iris_pack_job {
+    const float* weight;
+    float* packed;
+    long stride_o, stride_i, stride_h, stride_w;
+    int cin, cout, transposed, first_block;
+} iris_pack_job;
 #include "../../challenge_amd/csrc/k_conv_wino.h"
 #include "../../challenge_amd/csrc/k_conv_wino_wrw.h"
 #include "../../challenge_amd/csrc/k_conv_wino_b3.h"

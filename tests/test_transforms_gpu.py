@@ -1737,3 +1737,74 @@ def test_load_wav_resamples_a_44k_file(dev, tmp_path):
     ref = R.load_wav_array(x, 512, sample_rate=44100)
     assert tuple(spec.shape) == ref.shape == (257, 1 + 8000 // 256, 4)
     assert np.abs(spec.cpu().numpy() - ref).max() <= 3e-6 * np.abs(ref).max()
+
+
+def test_weight_packings_in_one_launch(dev):
+    """iris_wino_pack_weights_device_multi == iris_wino_pack_weights_device per job, bit for bit (exact-fp32 and split-bf16 packing,
+    forward and transposed, contiguous and channels_last weights, more jobs than one launch carries); and the training step's
+    `_PackBook`: the first forward packs per layer and remembers, the next one packs everything in one launch, a packing is
+    reused only at the weight version it was made at, gradients equal those of the per-layer path bit for bit."""
+    from challenge_amd import frontend as F
+    from challenge_amd import sj_train as S
+    from challenge_amd import hip_autograd as HA
+    torch.manual_seed(11)
+    shapes = [(64, 32), (64, 64), (128, 64), (128, 128), (256, 128), (64, 16)]
+    for split in (False, True):
+        jobs, want = [], []
+        for rep in range(10):   # 60-100 jobs: several launches of 48
+            for co, ci in shapes:
+                w = torch.randn(co, ci, 3, 3, device=dev)
+                if (rep + co) % 2:
+                    w = w.contiguous(memory_format=torch.channels_last)
+                for transposed in (False, True):
+                    cin, cout = (co, ci) if transposed else (ci, co)
+                    if cout % 64 or cin % (16 if split else 8):
+                        continue
+                    out = torch.empty(F.wino_packed_len(cin, cout, split), device=dev)
+                    jobs.append((w, transposed, out))
+                    want.append(F.wino_pack_weights_device(w, transposed=transposed, split_bf16=split))
+        assert len(jobs) > 48
+        F.wino_pack_weights_device_multi(jobs, split_bf16=split)
+        for (w, t, out), ref in zip(jobs, want):
+            assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    with pytest.raises(ValueError):
+        F.wino_pack_weights_device_multi([(torch.randn(64, 64, 3, 3, device=dev), False, torch.empty(8, device=dev))])
+    # the book, on a two-layer block
+    S.configure_miopen()
+    blk = S.ConvMPBlock(64, num_convs=2, fsize=64, BN=True, MP=True).to(dev).to(memory_format=torch.channels_last).train()
+    x = torch.randn(2, 64, 8, 40, device=dev).contiguous(memory_format=torch.channels_last)
+
+    start = [p.detach().clone() for p in blk.parameters()]
+    bufs = [b.detach().clone() for b in blk.buffers()]
+
+    def grads(fused):
+        S.FUSED_PACK = fused
+        HA._PACKS.clear()
+        with torch.no_grad():
+            for p, q in zip(blk.parameters(), start):
+                p.copy_(q)
+            for b, q in zip(blk.buffers(), bufs):
+                b.copy_(q)
+        out = []
+        for it in range(3):
+            for p in blk.parameters():
+                p.grad = None
+            HA._PACKS.prepack(dev)
+            xx = x.clone().requires_grad_(True)
+            blk(xx).square().sum().backward()
+            out.append([p.grad.clone() for p in blk.parameters()] + [xx.grad.clone()])
+            with torch.no_grad():   # an in-place update: every packing is stale now
+                for p in blk.parameters():
+                    p.mul_(1.01)
+        return out
+    try:
+        a = grads(True)
+        n_entries = len(HA._PACKS.entries)
+        b = grads(False)
+    finally:
+        S.FUSED_PACK = True
+        HA._PACKS.clear()
+    assert n_entries == 4   # two layers x (forward, backward-data)
+    for ga, gb in zip(a, b):
+        for u, v in zip(ga, gb):
+            assert torch.equal(u, v)
