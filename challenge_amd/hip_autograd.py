@@ -436,7 +436,9 @@ class _PackBook:
         import weakref
         key = self._key(weight, transposed, b3)
         ent = self.entries.get(key)
-        if ent is not None and ent[1] == weight._version:
+        # (the tensor the packing was made from must still be alive: a freed weight's address - and version 0 - comes back with
+        # the next tensor of its size)
+        if ent is not None and ent[1] == weight._version and ent[2]() is not None:
             return ent[0]
         co, ci = int(weight.shape[0]), int(weight.shape[1])
         cin, cout = (co, ci) if transposed else (ci, co)
