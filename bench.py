@@ -131,6 +131,11 @@ def parity(wav_cpu: np.ndarray, gpu_logmel: np.ndarray, gpu_mel: np.ndarray, ref
             "rule": "|mel - ref_fp64| <= 1e-5 |ref| + 4 eps_fp32 xrms[b,t,c] sum_k W[k,m] (oracle.frontend_ref.mel_tolerance)"}
 
 
+# what `side_measurements` has finished so far: if a LATER leg hangs (a rank stuck inside a collective: the one thing a one-GPU box
+# cannot rehearse is RCCL inside a captured graph at world > 1) the watchdog prints the line with these instead of nothing
+PARTIAL_EXTRAS = {}
+
+
 def side_measurements(dev, rank, world, steps, fence, strong=False):
     """BASELINE configs[2] and [3], reported beside the headline (never as `value`):
     c3 = fused frontend with SpecAugment + CRNN v9 forward, batch 64 x 8.176 s (T = 512);
@@ -239,6 +244,15 @@ def side_measurements(dev, rank, world, steps, fence, strong=False):
         comm = {"step_ms_with_allreduce": round(1e3 * t_train, 3), "step_ms_no_sync": round(1e3 * t_nosync, 3),
                 "exposed_allreduce_ms_per_step": round(1e3 * (t_train - t_nosync), 3),
                 "grad_bytes": 4 * sum(p.numel() for p in model.parameters()), "bucket_cap_mb": S.DDP_BUCKET_MB}
+
+    PARTIAL_EXTRAS["c4_train_step"] = {
+        "audio_s_per_s": round(world * audio_s / t_train, 1), "ms_per_step": round(1e3 * t_train, 3), "batch_per_gpu": batch, "n_gpus": world,
+        "host_ms_per_step": host_ms.get('eager'), "allreduce": comm,
+        "grad_allreduce": ("DDP/" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if ddp is not None else "none",
+        "partial": "the eager step only: a later side measurement did not finish (see `error`)"}
+    PARTIAL_EXTRAS["c3_frontend_specaug_crnn_fwd"] = {"ms_per_step": round(1e3 * t_fwd, 3), "parity": c3_parity,
+                                                      "inference_engine_ms_per_step": round(1e3 * t_fwd_folded, 3), "partial": True}
+    PARTIAL_EXTRAS["c3_best_fp32_audio_s_per_s"] = round(world * audio_s / min(t for t in (t_fwd, t_fwd_folded, t_fwd_graph) if t is not None), 1)
 
     # opt-in bf16 autocast variant of the forward and the training step, with its deviation from fp32 stated
     bf16 = None
@@ -676,7 +690,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (batch sweep, cache-resident replay, c3 forward, c4 training step)")
     ap.add_argument("--extra-steps", type=int, default=20)
-    ap.add_argument("--extras-limit", type=float, default=600.0,
+    ap.add_argument("--extras-limit", type=float, default=300.0,
                     help="seconds the side measurements may take before the line is printed without them")
     ap.add_argument("--only-sweep", action="store_true", help="of the side measurements, run only the K1 batch sweep (A/B runs)")
     ap.add_argument("--resident", action="store_true",
@@ -939,7 +953,7 @@ def main():
     # headline down with it: after --extras-limit seconds rank 0 prints the line without the extras and every rank leaves.
     def abandon():
         print(f"bench.py: rank {rank}: side measurements exceeded {args.extras_limit} s, abandoned", file=sys.stderr, flush=True)
-        finish({"error": f"side measurements exceeded {args.extras_limit} s and were abandoned"})
+        finish(dict(PARTIAL_EXTRAS, error=f"side measurements exceeded {args.extras_limit} s and were abandoned; what had finished by then is kept"))
         os._exit(0 if all(parity_ok) else 3)
     timer = threading.Timer(args.extras_limit, abandon)
     timer.daemon = True
