@@ -12,7 +12,8 @@ for grp in "$@"; do
   i=$((i+1))
   echo "pass $i: $grp"
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o pmc -- python3 ${PMC_CMD:-bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events --no-extras $BENCH_ARGS} > $OUT/p$i.log 2>&1
-  echo "  rc $?"; tail -1 $OUT/p$i.log | cut -c1-200
+  rc=$?; echo "  rc $rc"; tail -1 $OUT/p$i.log | cut -c1-200
+  if [ $rc -ge 124 ]; then echo "pass $i was killed at its limit: no further pass"; exit $rc; fi   # no GPU step after a hang
   find $OUT/p$i -name "*kernel_trace.csv" -delete
 done
 find $OUT -name "*counter_collection.csv" | head -30; du -sh $OUT
