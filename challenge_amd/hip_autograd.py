@@ -509,6 +509,9 @@ class _WinoConv3x3(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.wino_bwd = bwd if bwd == 'c32' else bool(bwd)
         ctx.wino_wrw = bool(wrw)
+        # (the statistics output is not differentiable: without this autograd materialises a zero "gradient" for it in every
+        # backward - 13 fp64 fills per training step, found in the step's kernel trace)
+        ctx.set_materialize_grads(False)
         if not stats:
             return z
         if sums is None:
@@ -518,6 +521,8 @@ class _WinoConv3x3(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz, _dsums=None):
+        if dz is None:   # (nothing flows back through z: grads are no longer materialised, see forward)
+            return None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         cin = int(weight.shape[1])
         if not dz.is_contiguous(memory_format=torch.channels_last):

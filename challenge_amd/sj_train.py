@@ -366,23 +366,21 @@ class WaveFrontend:
         self.training, self.filter_bins, self.do_minmax = training, filter_bins, do_minmax
         self.device_draw = device_draw
         self.rng = np.random.default_rng(seed)
-        self._gen = torch.Generator(device=self.plan.device).manual_seed(seed)
+        self._seed, self._ddraw = int(seed), None
 
     def draw_bands(self, batch: int, n_time: int):
         """Host draw (NumPy Generator): exact integer distributions of transforms.py:25-26."""
         return _du.augment_draw_batch(batch, n_time, self.plan.n_bins, self.rng)
 
     def draw_bands_device(self, batch: int, n_time: int):
-        """Device draw, no host round trip: size ~ U{0..max-1}, offset = floor(U[0,1) * (total - size))
-        (same support as the reference's integer draw; probabilities equal up to fp32 rounding)."""
-        dev = self.plan.device
-
-        def draw(total, max_size, n):
-            size = torch.randint(0, max_size, (batch, n), device=dev, generator=self._gen)
-            off = (torch.rand((batch, n), device=dev, generator=self._gen) * (total - size)).floor().to(torch.int64)
-            off = torch.minimum(off, total - size - 1)
-            return torch.stack([off, size], dim=-1).to(torch.int32)
-        return draw(n_time, 24, 6), draw(self.plan.n_bins, 16, 1)
+        """Device draw, no host round trip, ONE launch (`iris_augment_draw`: Philox keyed by the seed, call counter in device
+        memory; the exact integer distributions of transforms.py:25-26; capturable into a hipGraph).  Returns long-lived int32
+        device tensors (t_bands [B, 6, 2], f_bands [B, 1, 2]) that the next draw of the same shape overwrites.  (Until round 6
+        this was ~20 small torch launches per call - randint, rand, floor, minimum, stack ... - a tenth of a millisecond in front
+        of every training step: scripts/gpu_op_census.py.)"""
+        if self._ddraw is None:
+            self._ddraw = _du.DeviceAugmentDraw(self.plan.device, seed=self._seed)
+        return self._ddraw(batch, n_time, self.plan.n_bins)
 
     def __call__(self, wav: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         b, n_time = wav.shape[0], self.plan.num_frames(wav.shape[2])

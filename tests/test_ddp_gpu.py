@@ -277,12 +277,21 @@ def _rccl_world1_worker(rank, port, out_dir):
             assert d_grad <= 1e-4, d_grad
             graph_ddp[lr] = (d_loss, d_state, d_grad)
         else:
-            # both train; Adam's normalised update turns last-bit differences of near-zero gradients (the GEMMs' algorithm choice
-            # under capture) into steps of up to the learning rate on those elements: the parameters stay within a fraction of
-            # what ONE corrupted or missing bucket would cost (lr per element and step)
-            d_abs = max(float((a - b_).abs().max()) for a, b_ in zip(gm.parameters(), e.parameters()))
-            assert d_abs <= 0.1 * lr * 3, d_abs
-            graph_ddp[lr] = (d_loss, d_abs)
+            # both train.  Their forwards differ in last bits (the GEMMs' algorithm choice under capture); a ReLU / max-pool
+            # decision taken the other way moves single gradient elements by ~1e-2 of the peak (oracle.crnn_ref.Decisions), and
+            # Adam's normalised update turns the flipped SIGN of a small element into a step of up to the learning rate - on
+            # that element.  A corrupted or missing bucket costs the same lr per step, but on EVERY element of the bucket (the
+            # smallest holds 0.7 MB = 175,000 of them).  So: no element further apart than the two runs can legally get
+            # (2 lr per step), and almost none of them (< 1e-4 of the model, < 2 % of any tensor of >= 10^4 elements) more
+            # than a tenth of a learning rate apart (measured: 0.75 lr at worst, a few dozen elements)
+            diffs = [(a - b_).abs() for a, b_ in zip(gm.parameters(), e.parameters())]
+            d_abs = max(float(d.max()) for d in diffs)
+            assert d_abs <= 2 * lr * 3, d_abs
+            far = [int((d > 0.1 * lr).sum()) for d in diffs]
+            total = sum(d.numel() for d in diffs)
+            assert sum(far) <= 1e-4 * total, (sum(far), total)
+            assert all(f <= 0.02 * d.numel() for f, d in zip(far, diffs) if d.numel() >= 10000), [(f, d.numel()) for f, d in zip(far, diffs) if f]
+            graph_ddp[lr] = (d_loss, d_abs, sum(far))
     # `fit` picks the graph by default under DDP over RCCL, and one epoch leaves the same collectives as before + the capture's
     calls2 = {"replays": 0}
     real_call = S.GraphedTrainStep.__call__
