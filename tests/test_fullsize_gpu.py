@@ -168,3 +168,39 @@ def test_c4_gradient_tail_on_a_fresh_model_is_the_fp32_steps_own(setup):
         else:
             assert res["gradient_gate"] == "fixed bound"
     print("fresh model, product / stock fp32 (same decisions) / gate:", seen)
+
+
+@pytest.mark.parametrize("v,n_mels,n_chan,batch,n_frame", [(9, 80, 2, 12, 512), (8, 64, 1, 4, 128), (1, 80, 2, 3, 128)])
+def test_c3_and_c4_parity_at_other_configurations(dev, v, n_mels, n_chan, batch, n_frame):
+    """The same two legs away from BASELINE's c3 / c4 shape: the REFERENCE'S OWN default configuration (sj_train.py:20-71: 80 mel
+    bands, 2 channels, 512 frames, batch 12 - a first layer with two input channels, odd tile counts: 80 -> 40 -> 20 -> 10 -> 5 ->
+    3 mel rows), model v8 (48 / 96 / 192 / 384 / 768 channels: the Winograd kernels take the layers whose channel counts they
+    cover, MIOpen the rest, in one step) and the plain variant v1 (no LSTM, two Dense layers)."""
+    from challenge_amd import sj_train as S
+    from oracle import crnn_parity as P
+    S.configure_miopen()
+    cfg = S.ARGS().get(['--v', str(v), '--n_mels', str(n_mels), '--n_frame', str(n_frame), '--n_chan', str(n_chan), '--batch_size', str(batch)])
+    torch.manual_seed(v)
+    model = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                mod.running_mean.uniform_(-0.2, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.2, 0.2)
+    length = (n_frame - 1) * 256
+    fe = S.WaveFrontend(1024, 256, n_mels, 16000, n_chan, batch, length, dev, training=False)
+    gen = torch.Generator(device=dev).manual_seed(100 + v)
+    wav = torch.randn(batch, n_chan, length, generator=gen, device=dev) * 0.1
+    y = (torch.rand(batch, n_frame // 32, 3, generator=gen, device=dev) < 0.15).float()
+    feats = fe(wav)
+    assert tuple(feats.shape) == (batch, n_mels, n_frame, n_chan)
+    eng = S.InferenceEngine(model)
+    res3 = P.c3_parity(model, eng, feats)
+    assert res3["ok"], res3
+    # (v8: MIOpen runs the 48- and 96-channel layers, its weight gradients accumulate with atomics: not reproducible run to run)
+    res4 = P.c4_parity(model, feats, y, clipvalue=cfg.clipvalue, unmatched=False, deterministic=(v != 8))
+    print(f"v{v} {n_mels} mel x {n_chan} ch x {n_frame} frames, batch {batch}: c3 {res3['sigmoid_abs_vs_fp64']:.1e} / {res3['pre_sigmoid_rel_vs_fp64']:.1e}; "
+          f"c4 gradient {res4['gradient_rel_worst']:.1e} ({res4['gradient_gate']}), stock {res4['stock_fp32_same_decisions_gradient_rel_worst']:.1e}")
+    assert res4["ok"], res4
