@@ -43,6 +43,7 @@ SIGNATURES = {
     "iris_normalize_workspace": (_sz, [_i, _sz]),
     "iris_normalize": (_i, [_vp, _vp, _i, _sz, _vp, _sz, _vp]),
     "iris_wino_pack_weights_device_multi": (_i, [_vp, _i, _i, _vp]),
+    "iris_agc_clip_adam": (_i, [_vp, _sz, _f, _f, _f, _i, _vp, _f, C.c_double, C.c_double, _f, _vp, _vp]),
     "iris_resample_len": (C.c_longlong, [C.c_longlong, _i, _i]),
     "iris_resample": (_i, [_vp, _i, C.c_longlong, _i, _i, _vp, _vp]),
     "iris_stft": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -43,3 +43,4 @@
 #include "k_conv_wino_b3.h"
 #include "k_conv_wino_wrw.h"
 #include "k_resample.h"
+#include "k_agc_adam.h"

@@ -230,6 +230,7 @@ class GraphedTrainStep:
         # freeing - the buffers the graph replays from.
         self._agc = FusedAGC(list(model.parameters())) if model.use_agc else None
         if self._agc is not None:
+            self._agc.attach_adam(opt)   # (before `reserve`: an attached optimiser makes the table five columns wide)
             self._agc.reserve()
         self._flats, self._buckets = [], []
         if self.world:
@@ -321,12 +322,17 @@ class GraphedTrainStep:
                 raise RuntimeError("GraphedTrainStep: a parameter received no gradient - its bucket was never exchanged")
             for w in works:
                 w.wait()                      # the capture stream joins RCCL's stream again
+        stepped = False
         if model.use_agc:
-            self._agc(0.01, 1e-3, model.clipvalue)
+            if self._agc.attach_adam(opt):   # AGC + clipvalue + Adam in one launch (hip_autograd.FusedAGC.adam_step)
+                stepped = self._agc.adam_step(0.01, 1e-3, model.clipvalue)
+            if not stepped:
+                self._agc(0.01, 1e-3, model.clipvalue)
             self._agc.freeze()
         elif model.clipvalue:
             torch.nn.utils.clip_grad_value_([p for p in model.parameters() if p.grad is not None], model.clipvalue)
-        opt.step()
+        if not stepped:
+            opt.step()
         opt.zero_grad(set_to_none=True)
         self.loss = loss.detach()
         self._pool_marks = _ZERO_POOL.marks(dev) if SW.ZERO_POOL else {}

@@ -42,6 +42,7 @@ class FusedAGC:
 
     def __init__(self, params):
         self.params = [p for p in params]
+        self._adam = None   # a torch.optim.Adam whose update rides in the same launch (`adam_step`), or None
         self._sig = None
         self._table = None
         self._slow = []
@@ -85,19 +86,24 @@ class FusedAGC:
             length = np.array([l for _, l in rows_len], np.int64)[rep]
             plan = self._plan = (key, rep, within * length * 4, length)
         _, rep, offs, length = plan
-        table = np.empty((rep.shape[0], 3), np.int64)
+        cols = self._cols()
+        table = np.empty((rep.shape[0], cols), np.int64)
         if fast:
             table[:, 0] = np.array([p.data_ptr() for p in fast], np.int64)[rep] + offs
             table[:, 1] = np.array([p.grad.data_ptr() for p in fast], np.int64)[rep] + offs
             table[:, 2] = length
+            if cols == 5:   # iris_agc_adam_row: the two moments lie in the parameter's own layout
+                st = self._adam.state
+                table[:, 3] = np.array([st[p]['exp_avg'].data_ptr() for p in fast], np.int64)[rep] + offs
+                table[:, 4] = np.array([st[p]['exp_avg_sq'].data_ptr() for p in fast], np.int64)[rep] + offs
         recs = [table]
-        table = np.concatenate(recs) if recs else np.zeros((0, 3), np.int64)
+        table = np.concatenate(recs) if recs else np.zeros((0, cols), np.int64)
         # pinned staging + asynchronous copy: legal while a hipGraph is being captured (it becomes a copy node of the graph).
         # Under capture the buffers must already exist (`reserve`, called by GraphedTrainStep before the capture starts:
         # allocating pinned memory inside a capture invalidates it); the staging buffer stays alive for as long as a captured
         # copy may replay from it.
         reserved = getattr(self, '_reserved', None)
-        if reserved is not None and reserved[0].shape[0] >= table.shape[0]:
+        if reserved is not None and reserved[0].shape[0] >= table.shape[0] and reserved[0].shape[1] == cols:
             # `reserve` sized the buffers for EVERY parameter having a gradient in a layout the kernel takes; a parameter
             # without a gradient or on the torch path (`_slow`) only makes the table shorter: fill a prefix and hand the
             # kernel the actual row count (no allocation inside a capture whatever the row count turns out to be)
@@ -107,28 +113,122 @@ class FusedAGC:
             host.numpy()[...] = table
             dev_table.copy_(host, non_blocking=True)
             self._host_table, self._table = host, dev_table
+        elif self.params[0].is_cuda:
+            # One arena of eight tables (device + pinned staging), allocated once: a table per recurring address set WITHOUT a fresh
+            # allocation per build.  (Allocating each new table from torch's caching allocator moved the small-block pool the
+            # gradients themselves come from: with the five-column tables their addresses never recurred, every step built and
+            # pinned a new table - 1 ms, sometimes 170 ms - and the eager step read 37 ms instead of 10.)
+            n, slot = int(table.shape[0]), len(self._cache) % 8
+            arena = getattr(self, '_arena', None)
+            rows = sum(self._rows_of(p)[0] for p in self.params)
+            if arena is None or arena[0].shape[1] < rows or arena[0].shape[2] != cols:
+                arena = self._arena = (torch.empty((8, rows, cols), dtype=torch.int64).pin_memory(),
+                                       torch.empty((8, rows, cols), dtype=torch.int64, device=self.params[0].device))
+            host, dev_table = arena[0][slot][:n], arena[1][slot][:n]
+            host.numpy()[...] = table
+            dev_table.copy_(host, non_blocking=True)
+            self._host_table, self._table = host, dev_table
         else:
-            host = torch.from_numpy(table)
-            if self.params[0].is_cuda:
-                host = host.pin_memory()
-                self._host_table = host
-            self._table = host.to(self.params[0].device, non_blocking=True)
+            self._table = torch.from_numpy(table)
         self._sig = self._signature()
 
     def _signature(self):
         """(parameter address, gradient address, gradient strides) per parameter: a gradient buffer handed back at the same
-        address in another layout must not reuse a table built for the old one (fast / slow classification, row stride)."""
+        address in another layout must not reuse a table built for the old one (fast / slow classification, row stride).
+        With an optimiser attached: + the address of its first moment (a replaced state means a new table)."""
+        adam = self._adam
         return tuple((p.data_ptr(),) + ((-1, ()) if p.grad is None else (p.grad.data_ptr(), tuple(p.grad.stride())))
+                     + ((adam.state[p]['exp_avg'].data_ptr(),) if adam is not None and 'exp_avg' in adam.state.get(p, {}) else ())
                      for p in self.params)
+
+    def _cols(self) -> int:
+        return 5 if self._adam is not None else 3
+
+    def _reset_tables(self, adam) -> None:
+        """Another table format from here on: forget the cached tables (their arena slots are reused from the first, so nothing
+        in flight may still read them)."""
+        if self._cache and self.params and self.params[0].is_cuda:
+            torch.cuda.synchronize(self.params[0].device)
+        self._adam, self._sig, self._cache = adam, None, {}
+
+    # ---- the optimiser's update in the same launch (round 6) -----------------------------------------------------------------
+    @staticmethod
+    def adam_fusable(opt) -> bool:
+        """A plain torch.optim.Adam as `make_optimizer` builds it: one group, no weight decay / amsgrad / maximize, fp32 device
+        parameters, step counters on the device (fused or capturable)."""
+        if not SW.FUSED_ADAM or type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return False
+        g = opt.param_groups[0]
+        if g.get('amsgrad') or g.get('weight_decay') or g.get('maximize') or g.get('differentiable'):
+            return False
+        if not (g.get('fused') or g.get('capturable')) or not isinstance(g['betas'][0], float) or not isinstance(g['betas'][1], float):
+            return False
+        return all(p.is_cuda and p.dtype == torch.float32 for p in g['params'])
+
+    def attach_adam(self, opt) -> bool:
+        """Let `adam_step` run `opt`'s update: creates the optimiser state torch would create at its first step (same keys,
+        dtypes and layouts: state_dict() / load_state_dict() stay interchangeable).  False: not an optimiser this kernel covers."""
+        if not self.adam_fusable(opt) or [id(p) for p in opt.param_groups[0]['params']] != [id(p) for p in self.params]:
+            return False
+        for p in self.params:
+            st = opt.state[p]
+            if 'exp_avg' not in st:
+                st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if not (torch.is_tensor(st['step']) and st['step'].is_cuda and st['step'].dtype == torch.float32
+                    and st['exp_avg'].stride() == p.stride() and st['exp_avg_sq'].stride() == p.stride()
+                    and st['exp_avg'].dtype == torch.float32 and st['exp_avg_sq'].dtype == torch.float32):
+                return False
+        if self._adam is not opt:
+            self._reset_tables(opt)
+        return True
+
+    def adam_step(self, clip_factor=0.01, eps=1e-3, clipvalue=None, use_agc=True) -> bool:
+        """AGC + clipvalue + the attached optimiser's Adam update in ONE launch (iris_agc_clip_adam).  False (nothing done): a
+        parameter without a gradient or with a layout the kernel does not take - the caller then runs the two steps apart."""
+        import ctypes as C
+        if getattr(self, '_frozen', False):
+            raise RuntimeError("FusedAGC: this instance belongs to a captured hipGraph (GraphedTrainStep) and cannot be called eagerly")
+        opt = self._adam
+        if opt is None or any(p.grad is None for p in self.params):
+            return False
+        sig = self._signature()
+        if sig != self._sig:
+            hit = self._cache.get(sig)
+            if hit is not None:
+                self._sig, self._table, self._slow, self._host_table = sig, hit[0], hit[1], hit[2]
+            else:
+                if len(self._cache) >= 8:   # the arena's slots are reused from the first: nothing in flight may still read them
+                    torch.cuda.synchronize(self.params[0].device)
+                    self._cache.clear()
+                self._build()
+                self._cache[self._sig] = (self._table, self._slow, getattr(self, '_host_table', None))
+        if self._slow or self._table.shape[1] != 5:
+            return False
+        g = opt.param_groups[0]
+        steps = [opt.state[p]['step'] for p in self.params]
+        torch._foreach_add_(steps, 1)
+        lr = g['lr']
+        dev = self.params[0].device
+        from . import _native as N
+        with torch.cuda.device(dev):
+            rc = N.lib().iris_agc_clip_adam(self._table.data_ptr(), int(self._table.shape[0]), float(clip_factor), float(eps),
+                                            float(clipvalue or 0.0), 1 if use_agc else 0,
+                                            lr.data_ptr() if torch.is_tensor(lr) else None, 0.0 if torch.is_tensor(lr) else float(lr),
+                                            float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), steps[0].data_ptr(),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        N.check(rc, "iris_agc_clip_adam")
+        return True
 
     def reserve(self) -> None:
         """Allocate the table and its pinned staging buffer NOW (outside any capture), sized for every parameter having a
         gradient in a layout the kernel takes; the next `_build` fills them in place."""
-        rows = sum(self._rows_of(p)[0] for p in self.params)
-        host = torch.empty((rows, 3), dtype=torch.int64)
+        rows, cols = sum(self._rows_of(p)[0] for p in self.params), self._cols()
+        host = torch.empty((rows, cols), dtype=torch.int64)
         if self.params[0].is_cuda:
             host = host.pin_memory()
-        self._reserved = (host, torch.empty((rows, 3), dtype=torch.int64, device=self.params[0].device))
+        self._reserved = (host, torch.empty((rows, cols), dtype=torch.int64, device=self.params[0].device))
 
     def freeze(self) -> None:
         """After a hipGraph capture: the table and its pinned staging buffer are referenced by the graph and must never be
@@ -140,15 +240,19 @@ class FusedAGC:
         if getattr(self, '_frozen', False):
             raise RuntimeError("FusedAGC: this instance belongs to a captured hipGraph (GraphedTrainStep) and cannot be "
                                "called eagerly; eager steps use the model's own instance")
+        if self._adam is not None:   # AGC alone: the three-column table of iris_agc_clip (an attached optimiser's table has five)
+            self._reset_tables(None)
         sig = self._signature()
         if sig != self._sig:
             hit = self._cache.get(sig)
             if hit is not None:
                 self._sig, self._table, self._slow, self._host_table = sig, hit[0], hit[1], hit[2]
             else:
-                self._build()
-                if len(self._cache) >= 8:
+                if len(self._cache) >= 8:   # the arena's slots are reused from the first: nothing in flight may still read them
+                    if self.params[0].is_cuda:
+                        torch.cuda.synchronize(self.params[0].device)
                     self._cache.clear()
+                self._build()
                 self._cache[self._sig] = (self._table, self._slow, getattr(self, '_host_table', None))
         dev = self.params[0].device
         if self._table.shape[0]:

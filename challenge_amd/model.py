@@ -263,10 +263,15 @@ class CustomModel(nn.Module):
         loss.backward()  # under DDP the bucketed RCCL all-reduce overlaps with this
         mark('backward')
         fused = self.use_agc and x.is_cuda  # one HIP launch for AGC + clipvalue over the whole model
+        stepped = False
         if fused:
             if self._fused_agc is None:
                 object.__setattr__(self, '_fused_agc', FusedAGC(list(self.parameters())))
-            self._fused_agc(0.01, 1e-3, self.clipvalue)
+            # AGC + clipvalue, and - for the plain Adam make_optimizer builds - the optimiser's update in the same launch
+            if self._fused_agc.attach_adam(self.optimizer):
+                stepped = self._fused_agc.adam_step(0.01, 1e-3, self.clipvalue)
+            if not stepped:
+                self._fused_agc(0.01, 1e-3, self.clipvalue)
         else:
             params = [p for p in self.parameters() if p.grad is not None]
             if self.use_agc:
@@ -276,7 +281,8 @@ class CustomModel(nn.Module):
             if self.clipvalue:
                 torch.nn.utils.clip_grad_value_(params, self.clipvalue)
         mark('agc_clip')
-        self.optimizer.step()
+        if not stepped:
+            self.optimizer.step()
         mark('optimizer')
         return {'loss': loss.detach()}
 

@@ -37,6 +37,10 @@ ZERO_POOL = _on("IRIS_ZERO_POOL")
 # forward pass (iris_wino_pack_weights_device_multi) instead of one launch per layer and pass; 0: per layer
 FUSED_PACK = _on("IRIS_FUSED_PACK")
 
+# round 6: AGC + clipvalue + the Adam update in ONE launch (iris_agc_clip_adam) for the optimiser make_optimizer builds (plain Adam,
+# fused or capturable); 0: iris_agc_clip, then torch's fused Adam (three more launches, 143 us for the CRNN)
+FUSED_ADAM = _on("IRIS_FUSED_ADAM_AGC")
+
 # --- the convolutions themselves in the training step -------------------------------------------------------------------------------
 # The bare 3x3 convolutions of blocks 2-5 - forward and backward-data - as Winograd F(2x2, 3x3) on the fp32 matrix cores
 # (iris_conv3x3_wino) instead of MIOpen's implicit GEMMs, reading and writing channels_last where the weight-gradient kernel and the
@@ -77,6 +81,6 @@ DDP_BUCKET_MB = int(os.environ.get("IRIS_DDP_BUCKET_MB", "12"))
 # --- test hook ------------------------------------------------------------------------------------------------------------------------
 _PLAN_CHECK_ON_CPU = False  # tests/test_ddp_gloo.py: consult the frontend plans' status for a CPU-resident loss too
 
-NAMES = ("FUSED_BN_RELU", "FUSED_FC_BN", "FUSED_BN_POOL", "FUSED_BN_STATS", "FUSED_PACK", "FUSED_CONV0", "FUSED_LSTM", "ZERO_POOL", "WINO_TRAIN",
+NAMES = ("FUSED_BN_RELU", "FUSED_FC_BN", "FUSED_BN_POOL", "FUSED_BN_STATS", "FUSED_PACK", "FUSED_ADAM", "FUSED_CONV0", "FUSED_LSTM", "ZERO_POOL", "WINO_TRAIN",
          "WINO_TRAIN_MIN_C_FWD", "WINO_TRAIN_MIN_C_BWD", "WINO_TRAIN_WRW", "C32_TRAIN", "WINO_SPLIT_BF16", "WINO_CONVS", "GRAPH_STEP", "DDP_BUCKET_MB",
          "_PLAN_CHECK_ON_CPU")

@@ -281,6 +281,24 @@ int iris_agc_clip(const iris_agc_row* rows_dev, size_t n_rows, float clip_factor
                   float clipvalue, void* stream);
 
 /*
+ * The same launch carrying on into the optimiser (round 6): AGC + clipvalue + the Adam update of sj_train.py:434-435 / :176-182 in
+ * one pass over parameters, gradients and both moments (torch.optim.Adam's arithmetic, no weight decay / amsgrad; the clipped
+ * gradient is written back to `grad`).  use_agc == 0: clipvalue + Adam only.  lr_dev: nullable DEVICE float (a capturable
+ * optimiser's learning-rate tensor), else lr_host; step_dev: DEVICE float holding the step count t >= 1 of THIS update (the
+ * optimiser's already incremented counter).  Rows as for iris_agc_clip, plus the two moment rows in the parameter's own layout.
+ */
+typedef struct {
+    float* param;
+    float* grad;
+    int64_t len;
+    float* exp_avg;
+    float* exp_avg_sq;
+} iris_agc_adam_row;
+int iris_agc_clip_adam(const iris_agc_adam_row* rows_dev, size_t n_rows, float clip_factor, float eps_agc, float clipvalue,
+                       int use_agc, const float* lr_dev, float lr_host, double beta1, double beta2, float eps,
+                       const float* step_dev, void* stream);
+
+/*
  * Inference epilogue of ConvMPBlock's Conv2D + BatchNormalization + ReLU (+ MaxPool2D 2x2 'same'), sj_train.py:191-201,
  * once the eval-mode BatchNorm is folded into the convolution (sj_train.fold_batchnorm): the convolution itself stays
  * MIOpen (PyTorch-ROCm, per north_star); these replace the separate bias-add, ReLU and pooling passes over its output.

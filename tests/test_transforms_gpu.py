@@ -1808,3 +1808,109 @@ def test_weight_packings_in_one_launch(dev):
     for ga, gb in zip(a, b):
         for u, v in zip(ga, gb):
             assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("capturable", [False, True])
+def test_agc_clip_adam_in_one_launch_matches_the_two_steps(dev, capturable):
+    """iris_agc_clip_adam (AGC + clipvalue + Adam in one launch, sj_train.py:145-155, :434-435) against iris_agc_clip followed by
+    torch.optim.Adam's fused update: four training steps of the v9 CRNN from the same state on the same batches - the clipped
+    gradients left in p.grad equal (bit for bit behind the last MIOpen pass: the same clip arithmetic), parameters and both moments to fp32 rounding of one
+    update (1e-6 of each tensor's peak; Adam's first steps are +-lr whatever the gradient's size, so a wrong moment or bias
+    correction shows at 1e-1), the step counters equal; the optimiser states are interchangeable (state_dict of one loaded into
+    the other continues identically); a learning-rate change is seen (device tensor for a capturable optimiser, float otherwise)."""
+    from challenge_amd import sj_train as S
+    S.configure_miopen()
+    cfg = S.ARGS().get(['--v', '9', '--n_mels', '32', '--n_frame', '64', '--n_chan', '1', '--batch_size', '4'])
+    torch.manual_seed(3)
+    base = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+    gen = torch.Generator(device=dev).manual_seed(8)
+    batches = [(torch.rand(4, 32, 64, 1, generator=gen, device=dev), (torch.rand(4, 2, 3, generator=gen, device=dev) < 0.3).float())
+               for _ in range(5)]
+
+    def make(fused):
+        m = S.get_model(cfg).to(dev).to(memory_format=torch.channels_last)
+        m.load_state_dict(base.state_dict())
+        m.compile(S.make_optimizer(cfg, m.parameters(), capturable=capturable), S.binary_crossentropy, clipvalue=cfg.clipvalue)
+        return m
+
+    def set_lr(m, lr):
+        for g in m.optimizer.param_groups:
+            if torch.is_tensor(g['lr']):
+                g['lr'].fill_(lr)
+            else:
+                g['lr'] = lr
+
+    def rel(a, b):
+        return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+    try:
+        # (1) the launch itself, on identical inputs: the same synthetic gradients (some units far above their clip norm, some
+        # elements above clipvalue, some tiny) handed to both forms for four steps
+        from challenge_amd.hip_autograd import FusedAGC
+        S.FUSED_ADAM = True
+        a, b = make(True), make(False)
+        fa, fb = FusedAGC(list(a.parameters())), FusedAGC(list(b.parameters()))
+        assert fa.attach_adam(a.optimizer)
+        for k in range(4):
+            for p, q in zip(a.parameters(), b.parameters()):
+                gr = torch.randn(p.shape, generator=gen, device=dev).contiguous(memory_format=torch.channels_last if p.dim() == 4 else torch.contiguous_format)
+                gr = gr * float(10.0 ** float(torch.randint(-6, 1, (1,), generator=gen, device=dev)))
+                p.grad, q.grad = gr.clone(memory_format=torch.preserve_format), gr.clone(memory_format=torch.preserve_format)
+            if k == 2:
+                set_lr(a, 3e-4), set_lr(b, 3e-4)
+            assert fa.adam_step(0.01, 1e-3, cfg.clipvalue)
+            fb(0.01, 1e-3, cfg.clipvalue)
+            b.optimizer.step()
+            for (n, p), q in zip(a.named_parameters(), b.parameters()):
+                sa, sb = a.optimizer.state[p], b.optimizer.state[q]
+                assert rel(p.grad, q.grad) <= 3e-7, (k, n)   # the clipped gradient (two compilations of the norm sums: one ulp of the clip factor)
+                assert rel(p, q) <= 1e-6, (k, n, rel(p, q))
+                assert rel(sa['exp_avg'], sb['exp_avg']) <= 1e-6 and rel(sa['exp_avg_sq'], sb['exp_avg_sq']) <= 1e-6, (k, n)
+                assert float(sa['step']) == float(sb['step']) == k + 1
+        # (2) inside train_step (the raw gradients of the two models differ in last bits behind this geometry's one MIOpen pass)
+        S.FUSED_ADAM = True
+        a = make(True)
+        S.FUSED_ADAM = False
+        b = make(False)
+        for k, batch in enumerate(batches[:4]):
+            if k == 2:
+                set_lr(a, 3e-4), set_lr(b, 3e-4)
+            S.FUSED_ADAM = True
+            la = a.train_step(batch)['loss']
+            assert a._fused_agc._adam is a.optimizer          # the one-launch path ran
+            S.FUSED_ADAM = False
+            lb = b.train_step(batch)['loss']
+            assert b._fused_agc._adam is None
+            if k == 0:   # same state, same batch: the clipped gradients left in p.grad are the same (bit for bit wherever the
+                # raw gradients are - the layers behind the one MIOpen pass of this geometry, whose atomics move last bits)
+                assert abs(float(la) - float(lb)) <= 1e-6
+                same = 0
+                for (n, p), q in zip(a.named_parameters(), b.parameters()):
+                    assert rel(p.grad, q.grad) <= 1e-4, (n, rel(p.grad, q.grad))
+                    same += bool(torch.equal(p.grad, q.grad))
+                assert same >= 40, same
+            # the two models' raw gradients differ in last bits (MIOpen's atomics), Adam's first steps turn that into a few per cent
+            # of a step on near-zero elements and the trajectories drift apart from there: a sanity bound, (1) is the real check
+            assert abs(float(la) - float(lb)) <= 2e-4 * (k + 1), (k, float(la), float(lb))
+            for (n, p), q in zip(a.named_parameters(), b.parameters()):
+                sa, sb = a.optimizer.state[p], b.optimizer.state[q]
+                assert float((p - q).abs().max()) <= 0.25 * 1e-3 * (k + 1), (k, n)
+                assert float(sa['step']) == float(sb['step']) == k + 1
+        # interchangeable state: torch's optimiser continues from the fused one's state and vice versa
+        S.FUSED_ADAM = False
+        c = make(False)
+        c.load_state_dict(a.state_dict())
+        c.optimizer.load_state_dict(a.optimizer.state_dict())
+        S.FUSED_ADAM = True
+        d = make(True)
+        d.load_state_dict(a.state_dict())
+        d.optimizer.load_state_dict(a.optimizer.state_dict())
+        S.FUSED_ADAM = False
+        c.train_step(batches[4])
+        S.FUSED_ADAM = True
+        d.train_step(batches[4])
+        a.train_step(batches[4])
+        for (n, p), q, r in zip(a.named_parameters(), c.parameters(), d.parameters()):
+            assert float((q - p).abs().max()) <= 2.5e-4 and float((r - p).abs().max()) <= 2.5e-4, n
+    finally:
+        S.FUSED_ADAM = True
