@@ -163,6 +163,9 @@ class FusedAGC:
             return False
         if not (g.get('fused') or g.get('capturable')) or not isinstance(g['betas'][0], float) or not isinstance(g['betas'][1], float):
             return False
+        lr = g['lr']
+        if torch.is_tensor(lr) and not (lr.is_cuda and lr.dtype == torch.float32 and lr.numel() == 1):
+            return False   # (the kernel reads a device-side learning rate as ONE fp32 value)
         return all(p.is_cuda and p.dtype == torch.float32 for p in g['params'])
 
     def attach_adam(self, opt) -> bool:
