@@ -551,6 +551,9 @@ class _PackBook:
         cin, cout = (co, ci) if transposed else (ci, co)
         out = ent[0] if ent is not None else torch.empty(_fe.wino_packed_len(cin, cout, b3), dtype=torch.float32, device=weight.device)
         _fe.wino_pack_weights_device(weight, transposed=transposed, out=out, split_bf16=b3)
+        if ent is None and len(self.entries) >= 64:   # layers called on their own with ever new weights: drop what has died
+            for k in [k for k, e in self.entries.items() if e[2]() is None]:
+                del self.entries[k]
         self.entries[key] = [out, weight._version, weakref.ref(weight)]
         return out
 
